@@ -1,0 +1,165 @@
+/*
+ * nis_hip.h -- C ABI of libnis_hip.so: MI355X (gfx950) kernels for the neural-importance-sampling
+ * hot path of NGoetz/NF (`nisrep`).
+ *
+ * The reference is pure Python on PyTorch and has no FFI / plugin registry; the boundary a
+ * maintainer would bind is therefore the set of tensor-level operations its Python methods
+ * perform.  Each entry point below names the reference code it replaces (paths relative to
+ * /root/reference/nisrep).  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless it says "host".
+ *   - the caller owns all buffers (inputs, outputs, workspace); nothing is allocated or freed
+ *     on the launch path, so every call may be captured into a hipGraph.
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*).
+ *   - return value: 0 = ok, negative = NIS_E_* below.  No exceptions cross the boundary.
+ *   - all arithmetic is IEEE float64 (the reference runs in torch.double); bin indices int32.
+ *
+ * Data layout ("column planes")
+ *   The flow state is kept as struct-of-arrays: plane p holds one variable for all N samples,
+ *   planes + p*ld (ld >= N).  A permutation layer (RollLayer / MaskLayer / DeMaskLayer,
+ *   normalizing_flows/layers/layers.py:6-51,80-91) never moves data: it only renames planes.
+ */
+#ifndef NIS_HIP_H
+#define NIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NIS_MAX_DIM     32   /* max flow dimension d (n_flow)                        */
+#define NIS_MAX_HIDDEN  8    /* max hidden layers of a conditioner                    */
+#define NIS_MAX_WIDTH   64   /* max hidden width / pass-through size                  */
+#define NIS_MAX_BINS    128  /* max n_bins for PWLin; PWQuad is limited to 32         */
+#define NIS_MAX_CELLS   64
+#define NIS_MAX_LEGS    10   /* RAMBO: max number of final-state particles            */
+
+enum { NIS_PWLIN = 0, NIS_PWQUAD = 1 };
+enum { NIS_BN_EVAL = 0, NIS_BN_TRAIN = 1 };
+enum { NIS_F64 = 0, NIS_F32 = 1 };
+
+enum {
+  NIS_OK = 0,
+  NIS_E_ARG = -1,        /* invalid argument (shape / size limits)            */
+  NIS_E_UNSUPPORTED = -2,/* configuration outside the compiled kernel set     */
+  NIS_E_WORKSPACE = -3,  /* workspace too small                               */
+  NIS_E_HIP = -4,        /* a HIP runtime call failed (see nis_last_error)    */
+  NIS_E_NODEVICE = -5
+};
+
+/* Built-in integrands (device functions), so that f(X)*J never leaves the chip.
+ * NIS_F_CAMEL : README.md:35-36   exp(-|x-.75|^2/s^2)+exp(-|x-.25|^2/s^2), p0=0.75 p1=0.25 p2=0.2 (2 columns)
+ * NIS_F_NORMAL: manager.py:39-40  exp(-sum (x-mu)^2/(2 sigma^2))/(sigma sqrt((2pi)^d)), p0=mu p1=sigma
+ * NIS_F_ONE   : f == 1 (integrates the Jacobian; mean J -> 1)
+ */
+enum { NIS_F_CAMEL = 0, NIS_F_NORMAL = 1, NIS_F_ONE = 2 };
+
+/* One coupling cell (PWLin: layers/coupling_cells.py:73-142, PWQuad: :144-228) with its
+ * conditioner (RectNN :230-254).  `in_col[j]` is the state plane that feeds the cell's local
+ * column j (0..P-1 pass-through, P..d-1 transformed): the composition of all permutation
+ * layers in front of the cell.  Transformed columns are written back to the same planes. */
+typedef struct nis_cell_desc {
+  int32_t kind;                    /* NIS_PWLIN | NIS_PWQUAD                                  */
+  int32_t d;                       /* flow_size                                                */
+  int32_t P;                       /* pass_through_size                                        */
+  int32_t K;                       /* n_bins                                                   */
+  int32_t n_hidden;                /* number of hidden layers L (len(NN_layers))               */
+  int32_t width[NIS_MAX_HIDDEN];   /* hidden widths                                            */
+  int32_t in_col[NIS_MAX_DIM];     /* plane index per local column                             */
+} nis_cell_desc;
+
+/* Parameter blob of one cell, float64, in the order of the reference's nn.Sequential
+ * (coupling_cells.py:236-252):
+ *   BN_0.weight[P] BN_0.bias[P] Lin_0.weight[w0*P]
+ *   BN_1.weight[w0] BN_1.bias[w0] Lin_1.weight[w1*w0] ... BN_L.weight BN_L.bias
+ *   Lin_L.weight[(T*out)*w_{L-1}] Lin_L.bias[T*out]          (Linear weights row-major (out,in))
+ * Running-statistics blob:  for l = 0..L: running_mean[f_l] running_var[f_l]   (f_0=P, f_l=w_{l-1})
+ */
+size_t nis_cell_param_count(const nis_cell_desc* c);
+size_t nis_cell_running_count(const nis_cell_desc* c);
+
+typedef struct nis_flow nis_flow;   /* opaque model handle (topology only, no parameters) */
+
+/* Build a handle for a Sequential of cells (manager.py:474-499 PWLinManager.create_model,
+ * :518-600 PWQuadManager.create_model).  out_col[c] = plane holding logical output column c
+ * after the last permutation layer.  Host call. */
+int nis_flow_create(const nis_cell_desc* cells, int32_t n_cells, int32_t d, const int32_t* out_col,
+                    nis_flow** out);
+void nis_flow_destroy(nis_flow* f);
+
+/* Bytes of device workspace nis_flow_forward needs for a batch of N samples. */
+size_t nis_flow_workspace_bytes(const nis_flow* f, int64_t N);
+
+/* Forward pass of the whole model on N samples: AddJacobian (layers.py:75-77) + every cell.
+ *   w        (N,d) row-major, dtype w_dtype (integrate() draws float32, manager.py:390); with
+ *            w_has_jac != 0 it is (N,d+1) and its last column is the incoming Jacobian, i.e. the
+ *            tensor AddJacobian / a previous cell produced (coupling_cells.py:169)
+ *   params   host array [n_cells] of device pointers to the parameter blobs
+ *   running  host array [n_cells] of device pointers to the running-stat blobs
+ *            (read in NIS_BN_EVAL; read-modify-written in NIS_BN_TRAIN, momentum 0.1, unbiased var)
+ *   planes   (d+1, ld) float64 state; on return plane out_col[c] holds X[:,c], plane d holds J
+ *   xj_out   optional (N,d+1) row-major float64 = the reference's model output XJ (may be NULL)
+ *   bins_out optional int32 [sum_cells T_c][ld] bin index per transformed column (may be NULL)
+ * bn_mode NIS_BN_TRAIN reproduces train-mode BatchNorm1d (batch statistics over all N rows),
+ * which is what the reference uses during training AND integrate(). */
+int nis_flow_forward(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N,
+                     const double* const* params, double* const* running, int32_t bn_mode,
+                     double* planes, int64_t ld, double* xj_out, int32_t* bins_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* f(X)*J for a built-in integrand straight from the planes + streaming moments of the result:
+ * out4 = {count, mean, M2 = sum (v-mean)^2, max}   (torch.mean/var/max at manager.py:399-400,
+ * :241-249).  fres_out (N) optional.  workspace >= nis_moments_workspace_bytes(). */
+int nis_integrand_moments(const double* planes, int64_t ld, int64_t N, int32_t d, const int32_t* out_col_host,
+                          int32_t f_kind, const double* f_params_host, double* fres_out, double* out4,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Streaming moments of a vector (optionally of the product a[i]*b[i], b may be NULL). */
+size_t nis_moments_workspace_bytes(void);
+int nis_moments(const double* a, const double* b, int64_t N, double* out4,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* RAMBO on diet, FlatInvertiblePhasespace.generateKinematics_batch with pdf=None
+ * (PhaseSpace/flat_phase_space_generator.py:139-308 and helpers :313-441, PhaseSpace/utils.py).
+ *   r        random numbers, (N, ncol) row-major (r_ld = ncol) or column planes (r_col_major != 0,
+ *            column c at r + r_cols[c]*r_ld); ncol = 3n-4 (+2 when pdf_active)
+ *   momenta  optional (N, 2+n, 4) row-major, COM frame (flat_phase_space_generator.py:282,308)
+ *   weight   (N)
+ * flags: bit0 pdf_active, bit1 tau, bit2 "lab boost applied" decided by the caller
+ *        (batch-global test of utils.py:139). */
+typedef struct nis_rambo_desc {
+  int32_t n_final;
+  int32_t flags;
+  double  initial_masses[2];
+  double  final_masses[NIS_MAX_LEGS];
+  double  E_cm;
+  double  pT_mincut, delR_mincut, rap_maxcut;
+  int32_t bisect_levels;           /* lattice bisection depth (reference executes 120-180)   */
+  int32_t reserved;
+} nis_rambo_desc;
+enum { NIS_RAMBO_PDF_ACTIVE = 1, NIS_RAMBO_TAU = 2, NIS_RAMBO_LAB_BOOST = 4 };
+
+int nis_rambo_forward(const nis_rambo_desc* desc_host, const double* r, int64_t r_ld, int32_t r_col_major,
+                      const int32_t* r_cols_host, int64_t N, double* momenta, double* weight,
+                      int32_t* status, void* stream);
+
+/* Live timing of ONE kernel class with HIP events recorded on the launch stream around every launch of
+ * that class (bench.py's roofline leg).  kernel_class: 0 cell-apply, 1 BN statistics, 2 ingest,
+ * 3 integrand+moments, 4 rambo, 5 emit, 6 pack, 7 moments.  nis_prof_read synchronises the recorded
+ * events and returns the summed duration and the launch count since nis_prof_enable. */
+int nis_prof_enable(int32_t kernel_class, int32_t max_launches);
+int nis_prof_read(double* total_ms, int32_t* launches);
+int nis_prof_disable(void);
+
+/* Diagnostics. */
+const char* nis_last_error(void);      /* host string describing the last NIS_E_HIP failure */
+int nis_version(void);
+int nis_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIS_HIP_H */

@@ -1,0 +1,69 @@
+"""Build libnis_hip.so (gfx950) in-tree with hipcc.  `python -m nf_amd.build [--force]`.
+
+The five conditioner-width translation units compile in parallel; objects go to nf_amd/csrc/build/,
+the shared library to nf_amd/lib/libnis_hip.so (git-ignored, travels to the GPU box with the snapshot).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libnis_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+UNITS = [("api", "api.hip", []), ("rambo", "rambo.hip", [])] + \
+        [(f"flow_wm{w}", "flow_wm.hip", [f"-DNIS_WM={w}"]) for w in (4, 8, 16, 32, 64)]
+
+
+def _sources():
+    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    out.append(os.path.join(os.path.dirname(HERE), "include", "nis_hip.h"))
+    return out
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(unit):
+    name, src, defs = unit
+    obj = os.path.join(OBJ, name + ".o")
+    cmd = [HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {name}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return obj, r.stderr
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    deps = _sources()
+    if not force and not _stale(LIB, deps):
+        return LIB
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        results = list(ex.map(_compile, UNITS))
+    objs = [o for o, _ in results]
+    if verbose:
+        for _, err in results:
+            if err.strip():
+                print(err, file=sys.stderr)
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose=True)
+    print(path)

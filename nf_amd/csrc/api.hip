@@ -1,0 +1,560 @@
+// Host side of libnis_hip.so (C ABI of include/nis_hip.h) + the small streaming kernels:
+// parameter packing, ingest (row-major w -> column planes), emit (planes -> row-major XJ),
+// built-in integrands and the moment reductions.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "flow_kernels.h"
+
+static thread_local std::string g_err;
+static int fail_hip(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return NIS_E_HIP;
+}
+#define HIP_OK(call)                                   \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) return fail_hip(e_, #call);  \
+  } while (0)
+
+extern "C" const char* nis_last_error(void) { return g_err.c_str(); }
+extern "C" int nis_version(void) { return 100; }
+extern "C" int nis_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// live per-launch timing of one kernel class
+static struct {
+  bool on = false;
+  int cls = -1;
+  std::vector<hipEvent_t> ev;   // pairs: start, stop
+  int used = 0;
+} g_prof;
+
+void nis_prof_mark(int kernel_class, int begin, hipStream_t s) {
+  if (!g_prof.on || kernel_class != g_prof.cls) return;
+  if (g_prof.used + 1 >= (int)g_prof.ev.size() && begin) return;
+  if (begin) {
+    (void)hipEventRecord(g_prof.ev[g_prof.used], s);
+  } else if (g_prof.used + 1 < (int)g_prof.ev.size()) {
+    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
+    g_prof.used += 2;
+  }
+}
+
+extern "C" int nis_prof_disable(void) {
+  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  g_prof.on = false;
+  g_prof.used = 0;
+  return NIS_OK;
+}
+
+extern "C" int nis_prof_enable(int32_t kernel_class, int32_t max_launches) {
+  nis_prof_disable();
+  if (max_launches < 1) return NIS_E_ARG;
+  g_prof.ev.resize(2 * (size_t)max_launches);
+  for (auto& e : g_prof.ev) HIP_OK(hipEventCreate(&e));
+  g_prof.cls = kernel_class;
+  g_prof.used = 0;
+  g_prof.on = true;
+  return NIS_OK;
+}
+
+extern "C" int nis_prof_read(double* total_ms, int32_t* launches) {
+  if (!total_ms || !launches) return NIS_E_ARG;
+  double tot = 0.0;
+  for (int i = 0; i + 1 < g_prof.used; i += 2) {
+    HIP_OK(hipEventSynchronize(g_prof.ev[i + 1]));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = g_prof.used / 2;
+  return NIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sizes
+static inline int cell_T(const nis_cell_desc& c) { return c.d - c.P; }
+static inline int cell_out(const nis_cell_desc& c) { return c.kind == NIS_PWQUAD ? 2 * c.K + 1 : c.K; }
+static inline int cell_R(const nis_cell_desc& c) { return cell_T(c) * cell_out(c); }
+static inline int cell_feat(const nis_cell_desc& c, int l) { return l == 0 ? c.P : c.width[l - 1]; }
+
+extern "C" size_t nis_cell_param_count(const nis_cell_desc* c) {
+  size_t n = 0;
+  for (int l = 0; l <= c->n_hidden; ++l) {
+    const int F = cell_feat(*c, l);
+    const int O = l < c->n_hidden ? c->width[l] : cell_R(*c);
+    n += 2 * (size_t)F + (size_t)O * F;
+  }
+  return n + cell_R(*c);
+}
+extern "C" size_t nis_cell_running_count(const nis_cell_desc* c) {
+  size_t n = 0;
+  for (int l = 0; l <= c->n_hidden; ++l) n += 2 * (size_t)cell_feat(*c, l);
+  return n;
+}
+
+struct CellLayout {
+  int WM, KM;
+  size_t off_wp, off_wlast, off_bias, off_gb, off_coef, off_part;   // in doubles from the workspace body
+};
+
+struct nis_flow {
+  int d, n_cells;
+  std::vector<nis_cell_desc> cells;
+  std::vector<CellLayout> lay;
+  std::vector<int> bins_row;
+  int out_col[NIS_MAX_DIM];
+  size_t body_doubles;
+  // packing cache
+  int64_t packed_version = -1;
+  int packed_mode = -1;
+  const void* packed_ws = nullptr;
+  std::vector<const double*> packed_params;
+};
+
+static const size_t WS_HEADER = 256;   // bytes: status word + padding
+
+static int validate_cell(const nis_cell_desc& c, int d) {
+  if (c.kind != NIS_PWLIN && c.kind != NIS_PWQUAD) return NIS_E_ARG;
+  if (c.d != d || c.P < 1 || c.P >= d || c.K < 1) return NIS_E_ARG;
+  if (c.n_hidden < 1 || c.n_hidden > NIS_MAX_HIDDEN) return NIS_E_UNSUPPORTED;
+  int m = c.P;
+  for (int l = 0; l < c.n_hidden; ++l) {
+    if (c.width[l] < 1) return NIS_E_ARG;
+    m = std::max(m, c.width[l]);
+  }
+  if (nis_pick_wm(m) < 0) return NIS_E_UNSUPPORTED;
+  if (c.kind == NIS_PWQUAD && nis_pick_km(c.K) < 0) return NIS_E_UNSUPPORTED;
+  if (c.kind == NIS_PWLIN && c.K > NIS_MAX_BINS) return NIS_E_UNSUPPORTED;
+  for (int j = 0; j < d; ++j)
+    if (c.in_col[j] < 0 || c.in_col[j] >= d) return NIS_E_ARG;
+  return NIS_OK;
+}
+
+extern "C" int nis_flow_create(const nis_cell_desc* cells, int32_t n_cells, int32_t d, const int32_t* out_col, nis_flow** out) {
+  if (!cells || !out || !out_col || n_cells < 1 || n_cells > NIS_MAX_CELLS || d < 2 || d > NIS_MAX_DIM) return NIS_E_ARG;
+  nis_flow* f = new nis_flow();
+  f->d = d;
+  f->n_cells = n_cells;
+  size_t off = 0;
+  int brow = 0;
+  for (int i = 0; i < n_cells; ++i) {
+    const nis_cell_desc& c = cells[i];
+    int rc = validate_cell(c, d);
+    if (rc != NIS_OK) {
+      delete f;
+      return rc;
+    }
+    int m = c.P;
+    for (int l = 0; l < c.n_hidden; ++l) m = std::max(m, c.width[l]);
+    CellLayout L;
+    L.WM = nis_pick_wm(m);
+    L.KM = c.kind == NIS_PWQUAD ? nis_pick_km(c.K) : 4;
+    const size_t WM = L.WM, R = cell_R(c), nl = c.n_hidden;
+    L.off_wp = off;      off += nl * WM * WM;
+    L.off_wlast = off;   off += R * WM;
+    L.off_bias = off;    off += (R + 7) / 8 * 8;
+    L.off_gb = off;      off += (nl + 1) * 2 * WM;
+    L.off_coef = off;    off += (nl + 1) * 2 * WM;
+    L.off_part = off;    off += (nl + 1) * (size_t)NIS_MAXB * WM * 3;
+    f->cells.push_back(c);
+    f->lay.push_back(L);
+    f->bins_row.push_back(brow);
+    brow += cell_T(c);
+  }
+  for (int j = 0; j < d; ++j) {
+    if (out_col[j] < 0 || out_col[j] >= d) {
+      delete f;
+      return NIS_E_ARG;
+    }
+    f->out_col[j] = out_col[j];
+  }
+  f->body_doubles = off;
+  f->packed_params.assign(n_cells, nullptr);
+  *out = f;
+  return NIS_OK;
+}
+
+extern "C" void nis_flow_destroy(nis_flow* f) { delete f; }
+
+extern "C" size_t nis_flow_workspace_bytes(const nis_flow* f, int64_t) { return WS_HEADER + f->body_doubles * sizeof(double); }
+
+// ---------------------------------------------------------------------------------------------
+// k_pack: reference-order parameter blob -> zero-padded WM-strided weights (+ eval-mode BN affine).
+__global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double* __restrict__ prm, const double* __restrict__ run,
+                                                  int eval_mode, double* wp, double* wlast, double* bias, double* gb) {
+  const int tid = blockIdx.x * NIS_TPB + threadIdx.x, nth = gridDim.x * NIS_TPB;
+  size_t off = 0;
+  int roff = 0;
+  for (int l = 0; l <= c.L; ++l) {
+    const int F = cellk_feat(c, l);
+    const int O = l < c.L ? c.width[l] : c.R;
+    const double* gam = prm + off;
+    const double* bet = prm + off + F;
+    const double* W = prm + off + 2 * F;
+    for (int j = tid; j < WM; j += nth) {
+      const double g = j < F ? gam[j] : 0.0, b = j < F ? bet[j] : 0.0;
+      gb[(l * 2 + 0) * WM + j] = g;
+      gb[(l * 2 + 1) * WM + j] = b;
+      if (eval_mode) {                       // BatchNorm1d.eval(): running statistics
+        double sc = 0.0, sh = 0.0;
+        if (j < F) {
+          sc = g / sqrt(run[roff + F + j] + NIS_BN_EPS);
+          sh = b - run[roff + j] * sc;
+        }
+        c.coef[(l * 2 + 0) * WM + j] = sc;
+        c.coef[(l * 2 + 1) * WM + j] = sh;
+      }
+    }
+    if (l < c.L) {
+      double* dst = wp + (size_t)l * WM * WM;
+      for (int e = tid; e < WM * WM; e += nth) {
+        const int j = e / WM, i = e % WM;
+        dst[e] = (j < O && i < F) ? W[(size_t)j * F + i] : 0.0;
+      }
+    } else {
+      for (size_t e = tid; e < (size_t)c.R * WM; e += nth) {
+        const int r = (int)(e / WM), i = (int)(e % WM);
+        wlast[e] = (i < F) ? W[(size_t)r * F + i] : 0.0;
+      }
+      const double* bs = W + (size_t)O * F;
+      for (int r = tid; r < c.R; r += nth) bias[r] = bs[r];
+    }
+    off += 2 * (size_t)F + (size_t)O * F;
+    roff += 2 * F;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ingest / emit.  256 samples per workgroup are transposed through LDS so that both the row-major
+// side and the plane side move as contiguous 8-byte-per-lane streams.
+struct ColMap {
+  int col[NIS_MAX_DIM + 1];
+};
+
+template <typename TIN>
+__global__ __launch_bounds__(NIS_TPB) void k_ingest(const TIN* __restrict__ w, long N, int d, double* __restrict__ planes, long ld) {
+  extern __shared__ double tile[];                              // [sample][d] with +1 skew per 32 rows
+  const long nblk = (N + NIS_TPB - 1) / NIS_TPB;
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long i0 = blk * NIS_TPB;
+    const int ns = (int)min((long)NIS_TPB, N - i0);
+    const int tot = ns * d;
+    for (int e = threadIdx.x; e < tot; e += NIS_TPB) {
+      const int s = e / d, cidx = e - s * d;
+      tile[s * d + cidx + s / 32] = (double)w[i0 * d + e];
+    }
+    __syncthreads();
+    const int s = threadIdx.x;
+    if (s < ns)
+      for (int cidx = 0; cidx < d; ++cidx) planes[(size_t)cidx * ld + i0 + s] = tile[s * d + cidx + s / 32];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(NIS_TPB) void k_emit(const double* __restrict__ planes, long ld, long N, int d, ColMap m,
+                                                  double* __restrict__ xj) {
+  extern __shared__ double tile[];
+  const int dd = d + 1;
+  const long nblk = (N + NIS_TPB - 1) / NIS_TPB;
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long i0 = blk * NIS_TPB;
+    const int ns = (int)min((long)NIS_TPB, N - i0);
+    const int s = threadIdx.x;
+    if (s < ns)
+      for (int cidx = 0; cidx < dd; ++cidx) tile[s * dd + cidx + s / 32] = planes[(size_t)m.col[cidx] * ld + i0 + s];
+    __syncthreads();
+    const int tot = ns * dd;
+    for (int e = threadIdx.x; e < tot; e += NIS_TPB) {
+      const int r = e / dd, cidx = e - r * dd;
+      xj[i0 * dd + e] = tile[r * dd + cidx + r / 32];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// moments: partial record per workgroup = (count, mean, M2, max)
+__device__ __forceinline__ void block_moments(double v, bool valid, bool& first, double& shift, double& S1, double& S2, double& cnt,
+                                              double& vmax) {
+  if (first) {
+    shift = wave_first(v);
+    first = false;
+  }
+  if (valid) {
+    const double t = v - shift;
+    S1 += t;
+    S2 = fma(t, t, S2);
+    cnt += 1.0;
+    vmax = fmax(vmax, v);
+  }
+}
+
+__device__ __forceinline__ void block_moments_finish(double shift, double S1, double S2, double cnt, double vmax, double* part) {
+  __shared__ double wm[NIS_TPB / NIS_WAVE][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double nw = wave_sum(cnt), s1 = wave_sum(S1), s2 = wave_sum(S2), mx = wave_max(vmax);
+  if (lane == 0) {
+    wm[wave][0] = nw;
+    wm[wave][1] = nw > 0.0 ? shift + s1 / nw : 0.0;
+    wm[wave][2] = nw > 0.0 ? fmax(s2 - s1 * s1 / nw, 0.0) : 0.0;
+    wm[wave][3] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Mom t = {0.0, 0.0, 0.0};
+    double m = -__builtin_huge_val();
+    for (int w = 0; w < NIS_TPB / NIS_WAVE; ++w) {
+      Mom q = {wm[w][0], wm[w][1], wm[w][2]};
+      t = mom_merge(t, q);
+      m = fmax(m, wm[w][3]);
+    }
+    part[0] = t.n;
+    part[1] = t.mean;
+    part[2] = t.m2;
+    part[3] = m;
+  }
+}
+
+struct IntegrandArgs {
+  int out_col[NIS_MAX_DIM];
+  int d, kind, jplane, pad;
+  double p[4];
+};
+
+__device__ __forceinline__ double eval_integrand(const IntegrandArgs& a, const double* planes, long ld, long i) {
+  if (a.kind == NIS_F_CAMEL) {                                                  // README.md:35-36
+    const double x0 = planes[(size_t)a.out_col[0] * ld + i], x1 = planes[(size_t)a.out_col[1] * ld + i];
+    const double s2 = a.p[2] * a.p[2];
+    const double e1 = -((x0 - a.p[0]) * (x0 - a.p[0]) + (x1 - a.p[0]) * (x1 - a.p[0])) / s2;
+    const double e2 = -((x0 - a.p[1]) * (x0 - a.p[1]) + (x1 - a.p[1]) * (x1 - a.p[1])) / s2;
+    return exp(e1) + exp(e2);
+  } else if (a.kind == NIS_F_NORMAL) {                                          // manager.py:39-40
+    const double mu = a.p[0], sg = a.p[1];
+    double s = 0.0;
+    for (int c = 0; c < a.d; ++c) {
+      const double x = planes[(size_t)a.out_col[c] * ld + i] - mu;
+      s += (x * x) / (2 * sg * sg);
+    }
+    return exp(-s) / (sg * sqrt(pow(2 * M_PI, (double)a.d)));
+  }
+  return 1.0;
+}
+
+__global__ __launch_bounds__(NIS_TPB) void k_integrand_moments(const double* __restrict__ planes, long ld, long N, IntegrandArgs a,
+                                                               double* __restrict__ fres, double* __restrict__ partials) {
+  double S1 = 0, S2 = 0, cnt = 0, vmax = -__builtin_huge_val(), shift = 0;
+  bool first = true;
+  const long stride = (long)gridDim.x * NIS_TPB;
+  const long nit = (N + stride - 1) / stride;
+  for (long it = 0; it < nit; ++it) {
+    const long i = it * stride + (long)blockIdx.x * NIS_TPB + threadIdx.x;
+    const bool valid = i < N;
+    double v = 0.0;
+    if (valid) {
+      v = eval_integrand(a, planes, ld, i) * planes[(size_t)a.jplane * ld + i];
+      if (fres) fres[i] = v;
+    }
+    block_moments(v, valid, first, shift, S1, S2, cnt, vmax);
+  }
+  block_moments_finish(shift, S1, S2, cnt, vmax, partials + (size_t)blockIdx.x * 4);
+}
+
+__global__ __launch_bounds__(NIS_TPB) void k_moments(const double* __restrict__ va, const double* __restrict__ vb, long N,
+                                                     double* __restrict__ partials) {
+  double S1 = 0, S2 = 0, cnt = 0, vmax = -__builtin_huge_val(), shift = 0;
+  bool first = true;
+  const long stride = (long)gridDim.x * NIS_TPB;
+  const long nit = (N + stride - 1) / stride;
+  for (long it = 0; it < nit; ++it) {
+    const long i = it * stride + (long)blockIdx.x * NIS_TPB + threadIdx.x;
+    const bool valid = i < N;
+    double v = 0.0;
+    if (valid) v = vb ? va[i] * vb[i] : va[i];
+    block_moments(v, valid, first, shift, S1, S2, cnt, vmax);
+  }
+  block_moments_finish(shift, S1, S2, cnt, vmax, partials + (size_t)blockIdx.x * 4);
+}
+
+// one workgroup: merge the per-workgroup records in a fixed order -> out4 = {n, mean, M2, max}
+__global__ __launch_bounds__(NIS_TPB) void k_moments_final(const double* __restrict__ partials, int nparts, double* __restrict__ out4) {
+  __shared__ double sm[NIS_TPB][4];
+  Mom t = {0.0, 0.0, 0.0};
+  double m = -__builtin_huge_val();
+  for (int b = threadIdx.x; b < nparts; b += NIS_TPB) {
+    Mom q = {partials[b * 4 + 0], partials[b * 4 + 1], partials[b * 4 + 2]};
+    t = mom_merge(t, q);
+    m = fmax(m, partials[b * 4 + 3]);
+  }
+  sm[threadIdx.x][0] = t.n;
+  sm[threadIdx.x][1] = t.mean;
+  sm[threadIdx.x][2] = t.m2;
+  sm[threadIdx.x][3] = m;
+  __syncthreads();
+  for (int s = NIS_TPB / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      Mom a = {sm[threadIdx.x][0], sm[threadIdx.x][1], sm[threadIdx.x][2]};
+      Mom b = {sm[threadIdx.x + s][0], sm[threadIdx.x + s][1], sm[threadIdx.x + s][2]};
+      a = mom_merge(a, b);
+      sm[threadIdx.x][0] = a.n;
+      sm[threadIdx.x][1] = a.mean;
+      sm[threadIdx.x][2] = a.m2;
+      sm[threadIdx.x][3] = fmax(sm[threadIdx.x][3], sm[threadIdx.x + s][3]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out4[0] = sm[0][0];
+    out4[1] = sm[0][1];
+    out4[2] = sm[0][2];
+    out4[3] = sm[0][3];
+  }
+}
+
+static int stream_grid(int64_t N) { return (int)std::max<int64_t>(1, std::min<int64_t>(NIS_MAXB, (N + NIS_TPB - 1) / NIS_TPB)); }
+
+extern "C" size_t nis_moments_workspace_bytes(void) { return (size_t)NIS_MAXB * 4 * sizeof(double); }
+
+extern "C" int nis_moments(const double* a, const double* b, int64_t N, double* out4, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  if (!a || !out4 || N < 1) return NIS_E_ARG;
+  if (!workspace || workspace_bytes < nis_moments_workspace_bytes()) return NIS_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = stream_grid(N);
+  hipLaunchKernelGGL(k_moments, dim3(grid), dim3(NIS_TPB), 0, s, a, b, (long)N, (double*)workspace);
+  HIP_OK(hipGetLastError());
+  hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(NIS_TPB), 0, s, (const double*)workspace, grid, out4);
+  HIP_OK(hipGetLastError());
+  return NIS_OK;
+}
+
+extern "C" int nis_integrand_moments(const double* planes, int64_t ld, int64_t N, int32_t d, const int32_t* out_col_host,
+                                     int32_t f_kind, const double* f_params_host, double* fres_out, double* out4, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  if (!planes || !out_col_host || !out4 || N < 1 || d < 1 || d > NIS_MAX_DIM || ld < N) return NIS_E_ARG;
+  if (f_kind == NIS_F_CAMEL && d < 2) return NIS_E_ARG;
+  if (!workspace || workspace_bytes < nis_moments_workspace_bytes()) return NIS_E_WORKSPACE;
+  IntegrandArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int c = 0; c < d; ++c) a.out_col[c] = out_col_host[c];
+  a.d = d;
+  a.kind = f_kind;
+  a.jplane = d;
+  for (int k = 0; k < 4; ++k) a.p[k] = f_params_host ? f_params_host[k] : 0.0;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = stream_grid(N);
+  {
+    NisProfScope ps(NIS_K_INTEGRAND, s);
+    hipLaunchKernelGGL(k_integrand_moments, dim3(grid), dim3(NIS_TPB), 0, s, planes, (long)ld, (long)N, a, fres_out,
+                       (double*)workspace);
+  }
+  HIP_OK(hipGetLastError());
+  hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(NIS_TPB), 0, s, (const double*)workspace, grid, out4);
+  HIP_OK(hipGetLastError());
+  return NIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int WM>
+static int run_cell(const CellK& c, double* planes, long ld, long N, int bn_mode, int km, int* bins, int grid, hipStream_t s) {
+  if (bn_mode == NIS_BN_TRAIN)
+    for (int l = 0; l <= c.L; ++l) {
+      NisProfScope ps(NIS_K_STATS, s);
+      HIP_OK(launch_stats<WM>(c, planes, ld, N, l, grid, s));
+    }
+  NisProfScope ps(NIS_K_APPLY, s);
+  HIP_OK(launch_apply<WM>(c, planes, ld, N, bn_mode == NIS_BN_TRAIN ? 1 : 0, km, bins, grid, s));
+  return NIS_OK;
+}
+
+extern "C" int nis_flow_forward(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N, const double* const* params,
+                                double* const* running, int32_t bn_mode, double* planes, int64_t ld, double* xj_out,
+                                int32_t* bins_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!f || !w || !params || !running || !planes || N < 1 || ld < N) return NIS_E_ARG;
+  if (bn_mode != NIS_BN_EVAL && bn_mode != NIS_BN_TRAIN) return NIS_E_ARG;
+  if (w_dtype != NIS_F64 && w_dtype != NIS_F32) return NIS_E_ARG;
+  if (!workspace || workspace_bytes < nis_flow_workspace_bytes(f, N)) return NIS_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int* status = (int*)workspace;
+  double* body = (double*)((char*)workspace + WS_HEADER);
+  HIP_OK(hipMemsetAsync(status, 0, sizeof(int), s));
+  const int d = f->d;
+  const int grid = stream_grid(N);
+  const int tgrid = (int)std::min<int64_t>(2048, (N + NIS_TPB - 1) / NIS_TPB);
+  const size_t tile_bytes = ((size_t)NIS_TPB * (d + 1) + 16) * sizeof(double);
+  const int wcols = w_has_jac ? d + 1 : d;
+
+  nis_prof_mark(NIS_K_INGEST, 1, s);
+  if (w_dtype == NIS_F64)
+    hipLaunchKernelGGL(k_ingest<double>, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const double*)w, (long)N, wcols, planes, (long)ld);
+  else
+    hipLaunchKernelGGL(k_ingest<float>, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const float*)w, (long)N, wcols, planes, (long)ld);
+  nis_prof_mark(NIS_K_INGEST, 0, s);
+  HIP_OK(hipGetLastError());
+
+  for (int ci = 0; ci < f->n_cells; ++ci) {
+    const nis_cell_desc& cd = f->cells[ci];
+    const CellLayout& L = f->lay[ci];
+    if (!params[ci] || !running[ci]) return NIS_E_ARG;
+    CellK c;
+    memset(&c, 0, sizeof(c));
+    c.kind = cd.kind;
+    c.d = d;
+    c.P = cd.P;
+    c.T = d - cd.P;
+    c.K = cd.K;
+    c.L = cd.n_hidden;
+    c.out = cell_out(cd);
+    c.R = cell_R(cd);
+    for (int l = 0; l < cd.n_hidden; ++l) c.width[l] = cd.width[l];
+    for (int j = 0; j < d; ++j) c.in_plane[j] = cd.in_col[j];
+    c.jplane = d;
+    c.first = (ci == 0 && !w_has_jac) ? 1 : 0;
+    c.nparts = grid;
+    c.maxb = NIS_MAXB;
+    c.bins_row = f->bins_row[ci];
+    c.wp = body + L.off_wp;
+    c.wlast = body + L.off_wlast;
+    c.bias = body + L.off_bias;
+    c.gb = body + L.off_gb;
+    c.coef = body + L.off_coef;
+    c.partials = body + L.off_part;
+    c.running = running[ci];
+    c.status = status;
+    // (re)pack the padded parameter image; cheap (one small launch per cell)
+    {
+      const int pgrid = (int)std::min<size_t>(64, ((size_t)c.R * L.WM + NIS_TPB - 1) / NIS_TPB);
+      hipLaunchKernelGGL(k_pack, dim3(std::max(1, pgrid)), dim3(NIS_TPB), 0, s, c, L.WM, params[ci], (const double*)running[ci],
+                         bn_mode == NIS_BN_EVAL ? 1 : 0, body + L.off_wp, body + L.off_wlast, body + L.off_bias, body + L.off_gb);
+      HIP_OK(hipGetLastError());
+    }
+    int rc;
+    switch (L.WM) {
+      case 4: rc = run_cell<4>(c, planes, ld, N, bn_mode, L.KM, bins_out, grid, s); break;
+      case 8: rc = run_cell<8>(c, planes, ld, N, bn_mode, L.KM, bins_out, grid, s); break;
+      case 16: rc = run_cell<16>(c, planes, ld, N, bn_mode, L.KM, bins_out, grid, s); break;
+      case 32: rc = run_cell<32>(c, planes, ld, N, bn_mode, L.KM, bins_out, grid, s); break;
+      case 64: rc = run_cell<64>(c, planes, ld, N, bn_mode, L.KM, bins_out, grid, s); break;
+      default: rc = NIS_E_UNSUPPORTED;
+    }
+    if (rc != NIS_OK) return rc;
+  }
+  if (xj_out) {
+    ColMap m;
+    for (int j = 0; j < d; ++j) m.col[j] = f->out_col[j];
+    m.col[d] = d;
+    hipLaunchKernelGGL(k_emit, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const double*)planes, (long)ld, (long)N, d, m, xj_out);
+    HIP_OK(hipGetLastError());
+  }
+  return NIS_OK;
+}

@@ -1,0 +1,294 @@
+// "RAMBO on diet" (Plaetzer 2013) batched 2 -> n phase-space map: one thread per sample, every
+// 4-vector in registers (n is a template parameter so all leg indices are compile-time).
+//
+// Reference restated: PhaseSpace/flat_phase_space_generator.py:139-308 (generateKinematics_batch),
+// :313-359 (bisect_vec_batch), :363-406 (intermediate masses + massive reweighting), :408-441
+// (initial state), PhaseSpace/utils.py:5-19 (set_square), :58-106 (boosts), :124-132 (uniform_distr),
+// :134-146 (lab boost), :151-187 (pseudo-rapidity, delta-phi, delta-R).  pdf == None (density 1).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "nis_common.h"
+
+struct RamboK {
+  nis_rambo_desc d;
+  double flat_ab;      // (2pi)^(4-3n) (pi/2)^(n-1)
+  double flat_fact;    // (n-1)! (n-2)!
+  double flat_const;   // full flat weight for a scalar E_cm (pdf_active == 0)
+  double msum[NIS_MAX_LEGS];   // msum[i] = sum_{j>=i} m_j
+  double mtot;
+  double tau_min;
+  int cols[3 * NIS_MAX_LEGS];  // column -> plane (column-major input) or identity
+  long r_ld;
+  int col_major;
+  int ncol;
+};
+
+#define RB_EPS 1.4901161193847656e-08     /* np.finfo(float).eps ** 0.5   (utils.py:151) */
+#define RB_HUGE 1.7976931348623157e308    /* np.finfo(float).max */
+
+__device__ __forceinline__ double rb_rho(double M, double N, double m) {          // :107-113
+  const double Msqr = M * M;
+  return sqrt((Msqr - (N + m) * (N + m)) * (Msqr - (N - m) * (N - m))) / (8. * Msqr);
+}
+
+__device__ __forceinline__ double rb_ipow(double x, int e) {
+  double p = 1.0;
+  for (int k = 0; k < e; ++k) p *= x;
+  return p;
+}
+
+struct V4 {
+  double e, x, y, z;
+};
+
+__device__ __forceinline__ void rb_set_square(V4& p, double sq) { p.e = sqrt((p.x * p.x + p.y * p.y + p.z * p.z) + sq); }   // utils.py:5-19
+
+__device__ __forceinline__ void rb_boost(V4& p, double bx, double by, double bz) {                                          // utils.py:58-81
+  const double b2 = bx * bx + by * by + bz * bz;
+  const double gamma = 1.0 / sqrt(1.0 - b2);
+  const double bp = p.x * bx + p.y * by + p.z * bz;
+  const double gamma2 = b2 > 0 ? (gamma - 1.0) / b2 : 0.0;
+  const double factor = gamma2 * bp + gamma * p.e;
+  p.x += factor * bx;
+  p.y += factor * by;
+  p.z += factor * bz;
+  p.e = gamma * (p.e + bp);
+}
+
+__device__ __forceinline__ double rb_pseudorap(const V4& p) {                                                               // utils.py:151-157
+  const double pt = sqrt(p.x * p.x + p.y * p.y);
+  const double th = atan2(pt, p.z);
+  return (pt < RB_EPS && fabs(p.z) < RB_EPS) ? RB_HUGE : -log(tan(th / 2.));
+}
+
+__device__ __forceinline__ double rb_delphi(const V4& a, const V4& b) {                                                     // utils.py:170-180
+  const double pt1 = sqrt(a.x * a.x + a.y * a.y), pt2 = sqrt(b.x * b.x + b.y * b.y);
+  double tmp = a.x * b.x + a.y * b.y;
+  tmp /= (pt1 * pt2);
+  double r = fabs(tmp) > 1.0 ? acos(tmp / fabs(tmp)) : acos(tmp);
+  if (pt1 == 0. || pt2 == 0.) r = RB_HUGE;
+  return r;
+}
+
+template <int NF>
+__global__ __launch_bounds__(NIS_TPB) void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict__ momenta,
+                                                   double* __restrict__ weight, int* __restrict__ status) {
+  const long stride = (long)gridDim.x * NIS_TPB;
+  const bool pdf_active = k.d.flags & NIS_RAMBO_PDF_ACTIVE;
+  const bool use_tau = k.d.flags & NIS_RAMBO_TAU;
+  const bool lab_boost = k.d.flags & NIS_RAMBO_LAB_BOOST;
+  constexpr int NPS = 3 * NF - 4;                    // phase-space columns; +2 (tau, ycm | x2, x1) with PDFs
+  for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < N; i += stride) {
+    double rv[NPS + 2];
+    bool nan_in = false;
+#pragma unroll
+    for (int c = 0; c < NPS + 2; ++c) {
+      rv[c] = 0.5;
+      if (c < k.ncol) {
+        rv[c] = k.col_major ? r[(size_t)k.cols[c] * k.r_ld + i] : r[(size_t)i * k.r_ld + c];
+        nan_in |= (rv[c] != rv[c]);
+      }
+    }
+    if (nan_in) atomicOr(status, 2);                  // the reference raises PhaseSpaceGeneratorError (:147-149)
+
+    // ---- PDFs: tau / y_cm sampling (:157-187)
+    double wgt = 1.0, x1 = 1.0, x2 = 1.0, E = k.d.E_cm;
+    if (pdf_active) {
+      if (use_tau) {
+        const double d_tau = 1.0 - k.tau_min;
+        const double tau = k.tau_min + d_tau * rv[NPS];
+        const double ymin = 0.5 * log(tau);
+        const double d_y = (-ymin) - ymin;
+        const double ycm = ymin + d_y * rv[NPS + 1];
+        x1 = sqrt(tau) * exp(ycm);
+        x2 = sqrt(tau) * exp(-ycm);
+        E = sqrt(tau) * k.d.E_cm;
+        wgt *= d_tau * d_y;
+      } else {
+        x1 = rv[NPS + 1];
+        x2 = rv[NPS];
+        E = sqrt(x1 * x2) * k.d.E_cm;
+      }
+      if (x1 < 1e-4 || x2 < 1e-4) wgt *= 0.0;         // x_cut (:185-186); pdf density == 1
+    }
+
+    // ---- intermediate masses: lattice bisection per column (:313-359), then :363-406
+    double M[NF], Kk[NF];
+    M[0] = E - k.mtot;
+#pragma unroll
+    for (int c = 0; c < NF - 2; ++c) {
+      const int e = NF - 2 - c;
+      const double v = rv[c];
+      double left = 0.0, right = 1.0, scale = 0.5, u = -1.0;
+      for (int level = 0; level < k.d.bisect_levels; ++level) {
+        u = (left + right) * scale;
+        const double chk = rb_ipow(u, e) * ((double)(e + 1) - (double)e * u);      // massless_map :101-103
+        left *= 2.;
+        right *= 2.;
+        const double adder = (v <= chk) ? -0.5 : 0.5;
+        left += adder + 0.5;
+        right += adder - 0.5;
+        scale *= 0.5;
+      }
+      M[c + 1] = sqrt(u * (M[c] * M[c]));                                           // :370
+    }
+    double w_ps = pdf_active ? k.flat_ab * (rb_ipow(E * E, NF - 2) / k.flat_fact) : k.flat_const;   // :81-97
+#pragma unroll
+    for (int c = 0; c < NF - 1; ++c) {
+      Kk[c] = M[c];
+      M[c] += k.msum[c];                                                            // :391-392
+    }
+    w_ps *= 8. * rb_rho(M[NF - 2], k.d.final_masses[NF - 1], k.d.final_masses[NF - 2]);   // :394-397
+    double prod = 1.0;
+#pragma unroll
+    for (int c = 0; c < NF - 2; ++c)
+      prod *= (rb_rho(M[c], M[c + 1], k.d.final_masses[c]) / rb_rho(Kk[c], Kk[c + 1], 0.)) * (M[c + 1] / Kk[c + 1]);   // :400-401
+    w_ps *= prod;
+    w_ps *= rb_ipow(Kk[0] / M[0], 2 * NF - 4);                                      // :403
+    double wtot = wgt * w_ps;
+
+    // ---- sequential two-body decays (:223-278)
+    V4 mom[NF + 2];
+    V4 Q = {M[0], 0., 0., 0.};
+    M[NF - 1] = k.d.final_masses[NF - 1];
+    bool bad_boost = false;
+#pragma unroll
+    for (int c = 0; c < NF - 1; ++c) {
+      const double q = 4. * M[c] * rb_rho(M[c], M[c + 1], k.d.final_masses[c]);     // :228
+      const double cos_t = 2. * rv[NF - 2 + 2 * c] - 1.;
+      const double sin_t = sqrt(1. - cos_t * cos_t);
+      const double phi = 2 * M_PI * rv[NF - 2 + 2 * c + 1];
+      const double cos_p = cos(phi);
+      const double sq = sqrt(1. - cos_p * cos_p);
+      const double sin_p = phi > M_PI ? -sq : sq;                                   // :241-243
+      V4 p = {0., q * sin_t * cos_p, q * sin_t * sin_p, q * cos_t};
+      const double m2 = k.d.final_masses[c] * k.d.final_masses[c];
+      rb_set_square(p, m2);
+      bad_boost |= (Q.e <= 0.) || ((Q.e * Q.e - Q.x * Q.x - Q.y * Q.y - Q.z * Q.z) < 0.);   // utils.py:33
+      rb_boost(p, Q.x / Q.e, Q.y / Q.e, Q.z / Q.e);
+      rb_set_square(p, m2);
+      mom[2 + c] = p;
+      Q.e -= p.e;
+      Q.x -= p.x;
+      Q.y -= p.y;
+      Q.z -= p.z;
+      rb_set_square(Q, M[c + 1] * M[c + 1]);
+    }
+    mom[NF + 1] = Q;
+    if (bad_boost) atomicOr(status, 8);
+
+    // ---- initial state (:408-441)
+    if (k.d.initial_masses[0] == 0. || k.d.initial_masses[1] == 0.) {
+      mom[0] = {E / 2.0, 0., 0., E / 2.0};
+      mom[1] = {E / 2.0, 0., 0., -(E / 2.0)};
+    } else {
+      const double M1 = k.d.initial_masses[0] * k.d.initial_masses[0], M2 = k.d.initial_masses[1] * k.d.initial_masses[1];
+      const double E2_ = E * E;
+      const double E1 = (E2_ + M1 - M2) / E, E2 = (E2_ - M1 + M2) / E;
+      const double Z = sqrt(E2_ * E2_ - 2 * E2_ * M1 - 2 * E2_ * M2 + M1 * M1 - 2 * M1 * M2 + M2 * M2) / E;
+      mom[0] = {E1 / 2.0, 0., 0., Z / 2.0};
+      mom[1] = {E2 / 2.0, 0., 0., -(Z / 2.0)};
+    }
+    if (momenta) {                                   // COM-frame copy is what the reference returns (:282,308)
+      double* o = momenta + (size_t)i * (NF + 2) * 4;
+#pragma unroll
+      for (int l = 0; l < NF + 2; ++l) {
+        reinterpret_cast<double2*>(o)[2 * l] = make_double2(mom[l].e, mom[l].x);
+        reinterpret_cast<double2*>(o)[2 * l + 1] = make_double2(mom[l].y, mom[l].z);
+      }
+    }
+
+    // ---- lab frame (utils.py:134-146); the batch-global "any zero reference" test is the caller's
+    if (lab_boost) {
+      const double rx = mom[0].x * x1 + mom[1].x * x2, ry = mom[0].y * x1 + mom[1].y * x2, rz = mom[0].z * x1 + mom[1].z * x2;
+      const double re = mom[0].e * x1 + mom[1].e * x2;
+      if (rx * rx + ry * ry + rz * rz == 0.) atomicOr(status, 4);
+      const double bx = rx / re, by = ry / re, bz = rz / re;
+#pragma unroll
+      for (int l = 0; l < NF + 2; ++l) rb_boost(mom[l], bx, by, bz);
+    }
+
+    // ---- cuts (:285-301)
+    double ptmin = RB_HUGE;
+#pragma unroll
+    for (int l = 0; l < NF; ++l) ptmin = fmin(ptmin, fabs(sqrt(mom[2 + l].x * mom[2 + l].x + mom[2 + l].y * mom[2 + l].y)));
+    double factor = (ptmin < k.d.pT_mincut) ? 0.0 : 1.0;
+    const bool need_eta = (k.d.delR_mincut > 0.) || (k.d.rap_maxcut > 0.);
+    if (need_eta) {
+      double eta[NF];
+#pragma unroll
+      for (int l = 0; l < NF; ++l) eta[l] = rb_pseudorap(mom[2 + l]);
+      if (k.d.delR_mincut > 0.) {
+#pragma unroll
+        for (int a = 1; a < NF; ++a)
+#pragma unroll
+          for (int b = 0; b < a; ++b) {
+            const double de = eta[a] - eta[b], dp = rb_delphi(mom[2 + a], mom[2 + b]);
+            if (fabs(sqrt(de * de + dp * dp)) < k.d.delR_mincut) factor = 0.0;
+          }
+      }
+      if (k.d.rap_maxcut > 0.) {
+        double emax = eta[0];
+#pragma unroll
+        for (int l = 1; l < NF; ++l) emax = fmax(emax, eta[l]);
+        if (k.d.rap_maxcut < fabs(emax)) factor = 0.0;                              // |max eta|, not max |eta| (:298-301)
+      }
+    }
+    wtot *= factor;
+    const double shat = x1 * x2 * (k.d.E_cm * k.d.E_cm);
+    weight[i] = wtot / (2 * shat);
+  }
+}
+
+static double host_fact(int n) {
+  double f = 1.0;
+  for (int i = 2; i <= n; ++i) f *= i;
+  return f;
+}
+
+extern "C" int nis_rambo_forward(const nis_rambo_desc* dh, const double* r, int64_t r_ld, int32_t r_col_major,
+                                 const int32_t* r_cols_host, int64_t N, double* momenta, double* weight, int32_t* status,
+                                 void* stream) {
+  if (!dh || !r || !weight || !status || N < 1) return NIS_E_ARG;
+  const int n = dh->n_final;
+  if (n < 2 || n > NIS_MAX_LEGS) return NIS_E_UNSUPPORTED;
+  RamboK k;
+  memset(&k, 0, sizeof(k));
+  k.d = *dh;
+  if (k.d.bisect_levels <= 0) k.d.bisect_levels = 120;
+  const bool pdf_active = dh->flags & NIS_RAMBO_PDF_ACTIVE;
+  k.ncol = 3 * n - 4 + (pdf_active ? 2 : 0);
+  k.r_ld = r_ld;
+  k.col_major = r_col_major;
+  if (!r_col_major && r_ld < k.ncol) return NIS_E_ARG;
+  if (r_col_major && r_ld < N) return NIS_E_ARG;
+  for (int c = 0; c < k.ncol; ++c) k.cols[c] = (r_col_major && r_cols_host) ? r_cols_host[c] : c;
+  k.flat_ab = pow(2 * M_PI, 4 - 3 * n) * pow(M_PI / 2.0, n - 1);
+  k.flat_fact = host_fact(n - 1) * host_fact(n - 2);
+  k.flat_const = k.flat_ab * (pow(dh->E_cm * dh->E_cm, n - 2) / k.flat_fact);
+  double acc = 0.0;
+  for (int i = n - 1; i >= 0; --i) {          // torch.cumsum over the flipped masses (:391)
+    acc += dh->final_masses[i];
+    k.msum[i] = acc;
+  }
+  double tot = 0.0;
+  for (int i = 0; i < n; ++i) tot += dh->final_masses[i];   // torch.sum(masses_t) (:162,:384)
+  k.mtot = tot;
+  const double base = (tot > 1.0 ? tot : 1.0) / dh->E_cm;   // absolute_Ecm_min = 1 (:68,:164-165)
+  k.tau_min = base * base;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (N + NIS_TPB - 1) / NIS_TPB));
+#define RB_CASE(NFV)                                                                                              \
+  case NFV:                                                                                                       \
+    hipLaunchKernelGGL(k_rambo<NFV>, dim3(grid), dim3(NIS_TPB), 0, s, k, r, (long)N, momenta, weight, (int*)status); \
+    break;
+  NisProfScope ps(NIS_K_RAMBO, s);
+  switch (n) {
+    RB_CASE(2) RB_CASE(3) RB_CASE(4) RB_CASE(5) RB_CASE(6) RB_CASE(7) RB_CASE(8) RB_CASE(9) RB_CASE(10)
+    default: return NIS_E_UNSUPPORTED;
+  }
+#undef RB_CASE
+  return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
+}

@@ -1,0 +1,186 @@
+"""Host engine: turns a Sequential of coupling cells + permutation layers into one
+`nis_flow` handle and drives libnis_hip.so (no arithmetic happens in Python / torch here).
+
+Reference call sites this replaces: `self.model(self.format_input(w, dev))`
+(/root/reference/nisrep/normalizing_flows/manager.py:174-178, :225-229, :341, :396-397).
+"""
+import ctypes as C
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import CellDesc
+
+
+def _param_tensors(cell):
+    """Parameters / BN buffers of a cell in C-ABI blob order (= order of the reference's nn.Sequential)."""
+    bns = [m for m in cell.NN if isinstance(m, torch.nn.BatchNorm1d)]
+    lins = [m for m in cell.NN if isinstance(m, torch.nn.Linear)]
+    ps, rs = [], []
+    for l, bn in enumerate(bns):
+        ps += [bn.weight, bn.bias, lins[l].weight]
+        rs += [(bn, "running_mean"), (bn, "running_var")]
+    ps.append(lins[-1].bias)
+    return ps, rs, bns
+
+
+def _same_device(a, b):
+    a, b = torch.device(a), torch.device(b)
+    return a.type == b.type and (a.index or 0) == (b.index or 0)
+
+
+def _is_flat(cell, dev):
+    flat, run = getattr(cell, "_flat", None), getattr(cell, "_running", None)
+    if flat is None or run is None or not _same_device(flat.device, dev):
+        return False
+    ps, rs, _ = _param_tensors(cell)
+    base, off = flat.data_ptr(), 0
+    for p in ps:
+        if p.data_ptr() != base + 8 * off or p.dtype != torch.double:
+            return False
+        off += p.numel()
+    base, off = run.data_ptr(), 0
+    for bn, name in rs:
+        t = getattr(bn, name)
+        if t.data_ptr() != base + 8 * off or t.dtype != torch.double:
+            return False
+        off += t.numel()
+    return True
+
+
+def ensure_flat(cell, device=None):
+    """Keep one contiguous float64 blob per cell for parameters and one for BN running statistics
+    (layout: include/nis_hip.h).  The nn.Parameters / buffers are VIEWS into the blobs, so optimisers,
+    state_dict(), load_state_dict() keep working while the kernels read a single pointer.  .to(),
+    .double() and deepcopy break the aliasing; it is detected here (pointer check) and rebuilt."""
+    ps, rs, bns = _param_tensors(cell)
+    dev = torch.device(device) if device is not None else ps[0].device
+    if _is_flat(cell, dev):
+        return
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1).to(device=dev, dtype=torch.double) for p in ps])
+        run = torch.cat([getattr(bn, n).detach().reshape(-1).to(device=dev, dtype=torch.double) for bn, n in rs])
+        trk = torch.stack([bn.num_batches_tracked.detach().to(dev).to(torch.long) for bn in bns])
+        off = 0
+        for p in ps:
+            n = p.numel()
+            p.data = flat[off:off + n].view(p.shape)
+            if p.grad is not None:
+                p.grad = p.grad.to(device=dev, dtype=torch.double)
+            off += n
+        off = 0
+        for bn, name in rs:
+            n = getattr(bn, name).numel()
+            bn._buffers[name] = run[off:off + n]
+            off += n
+        for i, bn in enumerate(bns):
+            bn._buffers["num_batches_tracked"] = trk[i]
+    cell._flat, cell._running, cell._tracked = flat, run, trk
+
+
+def cell_desc(cell, in_col):
+    d = CellDesc()
+    d.kind = cell.KIND
+    d.d = cell.flow_size
+    d.P = cell.pass_through_size
+    d.K = cell.n_bins
+    widths = cell.hidden_widths
+    d.n_hidden = len(widths)
+    if len(widths) > _lib.NIS_MAX_HIDDEN:
+        raise _lib.NisError(f"conditioner depth {len(widths)} > {_lib.NIS_MAX_HIDDEN}")
+    for i, w in enumerate(widths):
+        d.width[i] = int(w)
+    for j, p in enumerate(in_col):
+        d.in_col[j] = int(p)
+    return d
+
+
+class FlowEngine:
+    """One `nis_flow` handle for an ordered list of (cell, in_col) + the final column map."""
+
+    def __init__(self, cells, in_cols, out_col, d):
+        self.L = _lib.lib()
+        self.cells = list(cells)
+        self.d = d
+        self.out_col = list(out_col)
+        n = len(self.cells)
+        arr = (CellDesc * n)(*[cell_desc(c, ic) for c, ic in zip(self.cells, in_cols)])
+        oc = (C.c_int32 * d)(*self.out_col)
+        h = C.c_void_p()
+        _lib.check(self.L.nis_flow_create(arr, n, d, oc, C.byref(h)), "nis_flow_create")
+        self.handle = h
+        self._descs = arr
+        self.n_bins_rows = sum(c.transform_size for c in self.cells)
+        self._finalizer = weakref.finalize(self, self.L.nis_flow_destroy, h)
+
+    def forward(self, w, has_jac, train, want_xj=True, want_bins=False):
+        """w: (N,d) or (N,d+1) CUDA tensor (float32/float64).  Returns dict(planes, xj, bins, status)."""
+        _lib.require_gpu()
+        if not w.is_cuda:
+            raise _lib.NisError("nf_amd kernels need the sample batch on the GPU (no CPU fallback)")
+        if w.dtype not in (torch.float32, torch.float64):
+            w = w.to(torch.double)
+        w = w.contiguous()
+        N = w.shape[0]
+        cols = self.d + (1 if has_jac else 0)
+        if w.dim() != 2 or w.shape[1] != cols:
+            raise ValueError(f"expected input of shape (N,{cols}), got {tuple(w.shape)}")
+        if train and N < 2:
+            raise ValueError("Expected more than 1 value per channel when training")   # torch BatchNorm1d error
+        dev = w.device
+        n = len(self.cells)
+        pp = (C.c_void_p * n)()
+        rp = (C.c_void_p * n)()
+        for i, c in enumerate(self.cells):
+            ensure_flat(c, dev)
+            pp[i] = c._flat.data_ptr()
+            rp[i] = c._running.data_ptr()
+        wsb = self.L.nis_flow_workspace_bytes(self.handle, N)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        planes = torch.empty((self.d + 1, N), dtype=torch.double, device=dev)
+        xj = torch.empty((N, self.d + 1), dtype=torch.double, device=dev) if want_xj else None
+        bins = torch.empty((self.n_bins_rows, N), dtype=torch.int32, device=dev) if want_bins else None
+        rc = self.L.nis_flow_forward(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
+                                     1 if has_jac else 0, N, pp, rp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL,
+                                     planes.data_ptr(), N, xj.data_ptr() if want_xj else None,
+                                     bins.data_ptr() if want_bins else None, ws.data_ptr(), wsb, _lib.stream_ptr())
+        _lib.check(rc, "nis_flow_forward")
+        if train:
+            for c in self.cells:           # BatchNorm1d.num_batches_tracked += 1 (one add per cell)
+                c._tracked.add_(1)
+        return dict(planes=planes, xj=xj, bins=bins, status=ws[:4].view(torch.int32), ws=ws)
+
+
+def moments_of(planes, d, out_col, f_kind, f_params, want_fres=False):
+    """f(X)*J from the planes + (count, mean, M2, max) on device.  Returns (out4 tensor, fres or None)."""
+    L = _lib.lib()
+    N = planes.shape[1]
+    dev = planes.device
+    out4 = torch.empty(4, dtype=torch.double, device=dev)
+    wsb = L.nis_moments_workspace_bytes()
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    fres = torch.empty(N, dtype=torch.double, device=dev) if want_fres else None
+    oc = (C.c_int32 * d)(*out_col)
+    fp = (C.c_double * 4)(*(list(f_params) + [0.0] * 4)[:4])
+    rc = L.nis_integrand_moments(planes.data_ptr(), N, N, d, oc, f_kind, fp, fres.data_ptr() if want_fres else None,
+                                 out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr())
+    _lib.check(rc, "nis_integrand_moments")
+    return out4, fres
+
+
+def moments(a, b=None):
+    """(count, mean, M2, max) of a (or a*b) as a 4-element device tensor: the HIP replacement of the
+    torch.mean / torch.var / torch.max passes at manager.py:149-165, :241-268, :399-400."""
+    _lib.require_gpu()
+    L = _lib.lib()
+    a = a.detach().to(torch.double).contiguous()
+    if b is not None:
+        b = b.detach().to(torch.double).contiguous()
+    out4 = torch.empty(4, dtype=torch.double, device=a.device)
+    wsb = L.nis_moments_workspace_bytes()
+    ws = torch.empty(wsb, dtype=torch.uint8, device=a.device)
+    rc = L.nis_moments(a.data_ptr(), b.data_ptr() if b is not None else None, a.numel(), out4.data_ptr(),
+                       ws.data_ptr(), wsb, _lib.stream_ptr())
+    _lib.check(rc, "nis_moments")
+    return out4

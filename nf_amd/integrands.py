@@ -1,0 +1,43 @@
+"""Integrands known to libnis_hip.so.  Each object is an ordinary callable on a (N, d) tensor (torch
+ops, any device -- this is what a user of the reference would write, README.md:35-36) and ALSO carries
+`nis_kind` / `nis_params`, which lets `BasicManager.integrate` evaluate f(X)*J inside the HIP kernel
+without materialising X."""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class Camel:
+    """exp(-|x-a|^2/s^2) + exp(-|x-b|^2/s^2) on the first two columns (README.md:35-36: a=.75, b=.25, s=.2)."""
+    nis_kind = _lib.NIS_F_CAMEL
+
+    def __init__(self, a=0.75, b=0.25, s=0.2):
+        self.a, self.b, self.s = a, b, s
+        self.nis_params = (a, b, s)
+
+    def __call__(self, x):
+        a, b, s = self.a, self.b, self.s
+        return torch.exp(-((x[:, 0] - a) ** 2 + (x[:, 1] - a) ** 2) / (s ** 2)) + \
+            torch.exp(-((x[:, 0] - b) ** 2 + (x[:, 1] - b) ** 2) / (s ** 2))
+
+
+class Normal:
+    """manager.py:39-40 `normal(x, mu, sigma, n_flow)`."""
+    nis_kind = _lib.NIS_F_NORMAL
+
+    def __init__(self, mu, sigma, n_flow):
+        self.mu, self.sigma, self.n_flow = mu, sigma, n_flow
+        self.nis_params = (mu, sigma)
+
+    def __call__(self, x):
+        return (torch.exp(-torch.sum((x - self.mu) ** 2 / (2 * self.sigma ** 2), -1))) / \
+            (self.sigma * np.sqrt((2 * np.pi) ** self.n_flow))
+
+
+class One:
+    nis_kind = _lib.NIS_F_ONE
+    nis_params = ()
+
+    def __call__(self, x):
+        return torch.ones_like(x[:, 0])

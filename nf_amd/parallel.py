@@ -1,0 +1,100 @@
+"""Multi-GPU sampling: one process per GPU, samples sharded, ONE collective to combine the estimators.
+
+The reference has no distributed code; this is the MI355X-native scaling path the
+north star asks for: independent sample shards on the 8 GPUs of a node and a single RCCL all-reduce
+over xGMI of the per-rank moment records.  Every rank writes its (nitn, 4) records
+{count, mean, M2, max} into its own slot of a zero-initialised (world, nitn, 4) buffer; the all-reduce
+(SUM) of that buffer is an exact gather (x + 0 is exact), after which every rank merges the slots in
+rank order with Chan's update -- deterministic and free of the cancellation a sum of squares has.
+Payload: world * nitn * 32 bytes, latency bound.
+
+Each shard is its own train-mode BatchNorm batch ("independent batches", SURVEY.md 8(e) option 2): it is
+parity-checked per shard; shards of an eval-mode model reproduce the single-batch result exactly.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def merge_moments(recs):
+    """Merge moment records along axis -2: recs (..., R, 4) -> (..., 4).  NumPy or torch input."""
+    is_t = torch.is_tensor(recs)
+    a = recs.detach().cpu().numpy() if is_t else np.asarray(recs, dtype=np.float64)
+    out = np.zeros(a.shape[:-2] + (4,))
+    out[..., 3] = -np.inf
+    for r in range(a.shape[-2]):
+        n_b, mean_b, m2_b, mx_b = a[..., r, 0], a[..., r, 1], a[..., r, 2], a[..., r, 3]
+        n_a, mean_a, m2_a = out[..., 0].copy(), out[..., 1].copy(), out[..., 2].copy()
+        n = n_a + n_b
+        with np.errstate(divide="ignore", invalid="ignore"):
+            fb = np.where(n > 0, n_b / np.where(n > 0, n, 1), 0.0)
+        delta = mean_b - mean_a
+        out[..., 0] = n
+        out[..., 1] = np.where(n_b > 0, mean_a + delta * fb, mean_a)
+        out[..., 2] = np.where(n_b > 0, m2_a + m2_b + delta * delta * (n_a * fb), m2_a)
+        out[..., 3] = np.where(n_b > 0, np.maximum(out[..., 3], mx_b), out[..., 3])
+    return torch.as_tensor(out) if is_t else out
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); backend "nccl" (= RCCL)
+    on GPUs, "gloo" on CPU.  Returns (rank, world_size, local_rank)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+    return rank, ws, local
+
+
+def allreduce_moments(local, group=None):
+    """local: (nitn, 4) float64 records of this rank (any device).  Returns the merged (nitn, 4) records,
+    identical on every rank.  One all-reduce."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    buf = torch.zeros((ws,) + tuple(local.shape), dtype=torch.double, device=local.device)
+    buf[rank] = local
+    # max slot: an empty rank holds -inf there, which must not poison the SUM -> sanitise per slot
+    buf[rank, ..., 3] = torch.nan_to_num(local[..., 3], neginf=0.0)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    recs = buf.movedim(0, -2)                       # (nitn, world, 4)
+    return merge_moments(recs).to(local.device)
+
+
+def shard_size(total, rank, ws):
+    """Contiguous split of `total` samples: the first total % ws ranks take one extra."""
+    base, rem = divmod(int(total), ws)
+    return base + (1 if rank < rem else 0)
+
+
+def integrate_sharded(manager, f, nitn, neval, dev=None):
+    """`BasicManager.integrate` with the neval points of every iteration split across the ranks of the
+    default process group.  Same return convention (two 0-d float32 CPU tensors), same on every rank."""
+    rank, ws = world()
+    if manager.best_model is None:
+        print("No model has been trained")
+        return (0, 0)
+    dev = manager._device(dev if dev is not None else manager._model_device())
+    n_local = shard_size(neval, rank, ws)
+    local = manager.moments_batches(f, int(nitn), n_local, dev)
+    mom = allreduce_moments(local).cpu()
+    var = (mom[:, 2] / (mom[:, 0] - 1.0)).to(torch.float32)
+    mean = mom[:, 1].to(torch.float32)
+    sig = torch.sum(mean / var) / torch.sum(1 / var)
+    sig_err = torch.sqrt(1 / torch.sum(1 / var)) / np.sqrt(int(neval) * int(nitn))
+    return (sig, sig_err)

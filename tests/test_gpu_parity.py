@@ -1,0 +1,357 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the drop-in classes / the C ABI, against
+(1) the golden vectors the reference produced and (2) the NumPy oracle on fresh seeded inputs, plus
+size-independent properties at BASELINE.json's full batch sizes.
+
+Tolerances (float64 everywhere): bin indices bit-exact; values rtol 1e-9 (different summation order in
+the conditioner, device libm exp/log within 1-2 ulp, batch statistics merged pairwise instead of
+sequentially).  float32 results of integrate(): rtol 2e-6."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import flow as oflow
+from oracle import rambo as orambo
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-9, 1e-12
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def make_cell(m, sd):
+    from nf_amd.normalizing_flows.layers.coupling_cells import PWLin, PWQuad
+    cls = PWQuad if m["kind"] == "pwquad" else PWLin
+    cell = cls(m["d"], m["P"], m["K"], list(m["NN"])).double()
+    cell.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    return cell.to(dev())
+
+
+def build_manager(m, sd=None):
+    from nf_amd.normalizing_flows.manager import PWLinManager, PWQuadManager
+    if m["kind"] == "pwquad":
+        NF = PWQuadManager(n_flow=m["d"])
+        NF.create_model(m["n_cells"], m["K"], list(m["NN"]))
+    else:
+        NF = PWLinManager(n_flow=m["d"])
+        NF.create_model(m["P"], m["n_cells"], m["K"], list(m["NN"]), m["roll"])
+    if sd is not None:
+        NF._model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    return NF
+
+
+def plan_from_meta(m):
+    if m["kind"] == "pwquad":
+        return oflow.plan_pwquad(m["d"], m["n_cells"], m["K"])
+    return oflow.plan_pwlin(m["d"], m["P"], m["n_cells"], m["K"], m["roll"])
+
+
+# ------------------------------------------------------------------------------ single cells
+@pytest.mark.parametrize("case", golden("cells.npz").cases())
+def test_cell_vs_reference_golden(case, g_cells):
+    m = g_cells.meta[case]
+    cell = make_cell(m, g_cells.sub(case, "sd"))
+    cell.train(m["mode"] == "train")
+    x = torch.as_tensor(g_cells.get(case, "x")).to(dev())
+    res = cell._own_engine().forward(x, True, cell.training, want_xj=True, want_bins=True)
+    torch.cuda.synchronize()
+    assert int(res["status"][0]) == 0
+    bins = t2n(res["bins"]).T.reshape(-1)                       # (T,N) -> reference order (N,T)
+    np.testing.assert_array_equal(bins, g_cells.get(case, "bins").reshape(-1))
+    np.testing.assert_allclose(t2n(res["xj"]), g_cells.get(case, "y"), rtol=RTOL, atol=ATOL)
+    sd_now = cell.state_dict()
+    for k, v in g_cells.sub(case, "sd_after").items():
+        np.testing.assert_allclose(t2n(sd_now[k]), v, rtol=1e-11, atol=1e-14, err_msg=k)
+
+
+@pytest.mark.parametrize("kind,d,P,K,NN,N", [("pwquad", 2, 1, 4, [3, 3, 3], 5000), ("pwquad", 6, 2, 9, [12, 5], 3001),
+                                             ("pwlin", 4, 2, 50, [9], 4097), ("pwquad", 12, 5, 20, [40, 33], 2500),
+                                             ("pwlin", 9, 3, 128, [64, 64], 700), ("pwquad", 3, 2, 32, [2, 2, 2, 2], 999)])
+@pytest.mark.parametrize("train", [True, False])
+def test_cell_vs_oracle_seeded(kind, d, P, K, NN, N, train):
+    from nf_amd.normalizing_flows.layers.coupling_cells import PWLin, PWQuad
+    torch.manual_seed(d * 100 + K)
+    cell = (PWQuad if kind == "pwquad" else PWLin)(d, P, K, list(NN)).double()
+    with torch.no_grad():
+        for p in cell.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+        for mod in cell.NN:
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.uniform_(0, 0.5)
+                mod.running_var.uniform_(0.1, 1.0)
+    params = {"c." + k: t2n(v) for k, v in cell.state_dict().items()}
+    x = torch.rand(N, d + 1, dtype=torch.double)
+    x[:, -1] += 0.5
+    if kind == "pwlin":
+        x[:, :d] *= (1 - 1e-12)
+    want, upd = {}, {}
+    y_ref = oflow.cell_forward(x.numpy(), params, "c", kind, P, K, train, upd, want)
+    cell = cell.to(dev()).train(train)
+    res = cell._own_engine().forward(x.to(dev()), True, train, want_xj=True, want_bins=True)
+    np.testing.assert_array_equal(t2n(res["bins"]).T, want["bins"])
+    np.testing.assert_allclose(t2n(res["xj"]), y_ref, rtol=RTOL, atol=ATOL)
+    if train:
+        sd = cell.state_dict()
+        for k, v in upd.items():
+            np.testing.assert_allclose(t2n(sd[k[2:]]), v, rtol=1e-11, atol=1e-14, err_msg=k)
+
+
+def test_cell_module_call_is_differentiable():
+    """cell(x) is the reference's nn.Module surface: forward values from HIP, gradients available."""
+    from nf_amd.normalizing_flows.layers.coupling_cells import PWQuad
+    torch.manual_seed(3)
+    cell = PWQuad(3, 1, 5, [4, 4]).double().to(dev())
+    x = torch.rand(64, 4, dtype=torch.double, device=dev(), requires_grad=True)
+    y = cell(x)
+    (y[:, -1].var() + y[:, 1].sum()).backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    g = [p.grad for p in cell.parameters()]
+    assert all(gi is not None and torch.isfinite(gi).all() for gi in g)
+    # finite-difference check of one weight against the HIP forward
+    p = cell.NN[1].weight
+    eps = 1e-6
+    with torch.no_grad():
+        base = cell(x.detach())
+        p[0, 0] += eps
+        pert = cell(x.detach())
+        p[0, 0] -= eps
+    fd = ((pert[:, -1].var() + pert[:, 1].sum()) - (base[:, -1].var() + base[:, 1].sum())) / eps
+    assert abs(float(fd) - float(p.grad[0, 0])) < 1e-4 * max(1.0, abs(float(fd)))
+
+
+# ------------------------------------------------------------------------------ whole models
+@pytest.mark.parametrize("case", golden("models.npz").cases())
+def test_model_vs_reference_golden(case, g_models):
+    m = g_models.meta[case]
+    NF = build_manager(m, g_models.sub(case, "sd"))
+    w = torch.as_tensor(g_models.get(case, "w")).to(dev())
+    NF._model.train()
+    with torch.no_grad():
+        XJ = NF._model(NF.format_input(w, dev()))
+    np.testing.assert_allclose(t2n(XJ), g_models.get(case, "XJ_train"), rtol=RTOL, atol=ATOL)
+    sd = NF._model.state_dict()
+    for k, v in g_models.sub(case, "sd_after").items():
+        np.testing.assert_allclose(t2n(sd[k]), v, rtol=1e-10, atol=1e-14, err_msg=k)
+    NF._model.eval()
+    with torch.no_grad():
+        XJe = NF._model(NF.format_input(w, dev()))
+    np.testing.assert_allclose(t2n(XJe), g_models.get(case, "XJ_eval"), rtol=RTOL, atol=ATOL)
+    # the no-concat fast path returns the same numbers
+    res = NF._model.flow_forward(w, want_xj=True)
+    np.testing.assert_array_equal(t2n(res["xj"]), t2n(XJe))
+
+
+# ------------------------------------------------------------------------------ integrate
+class Replay:
+    def __init__(self, draws):
+        self.draws, self.i = draws, 0
+
+    def __call__(self, n, d, dtype, stage):
+        t = torch.as_tensor(self.draws[self.i])
+        self.i += 1
+        assert tuple(t.shape) == (n, d), (stage, tuple(t.shape), n, d)
+        return t.to(dtype)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("case", golden("integrate.npz").cases())
+def test_integrate_vs_reference_golden(case, fused, g_integrate):
+    from nf_amd import integrands
+    from nf_amd.normalizing_flows.manager import normal
+    m = g_integrate.meta[case]
+    NF = build_manager(m, g_integrate.sub(case, "sd"))
+    draws = g_integrate.get(case, "w")
+    if case.startswith("camel"):
+        f = integrands.Camel() if fused else (lambda x: integrands.Camel()(x))
+    else:
+        f = integrands.Normal(0.5, 0.25, 8) if fused else (lambda x: normal(x, 0.5, 0.25, 8))
+    NF.sample_hook = Replay(draws)
+    mom = t2n(NF.moments_batches(f, m["nitn"], m["neval"], dev()))
+    np.testing.assert_allclose(mom[:, 1], g_integrate.get(case, "mean"), rtol=1e-9)
+    np.testing.assert_allclose(mom[:, 2] / (mom[:, 0] - 1), g_integrate.get(case, "var"), rtol=1e-8)
+    # full call on a fresh copy of the state (running stats advance with every train-mode forward)
+    NF = build_manager(m, g_integrate.sub(case, "sd"))
+    NF.sample_hook = Replay(draws)
+    sig, sig_err = NF.integrate(f, m["nitn"], m["neval"], 0)
+    assert sig.dtype == torch.float32 and sig.device.type == "cpu" and sig.dim() == 0
+    np.testing.assert_allclose(float(sig), float(g_integrate.get(case, "sig")), rtol=2e-6)
+    np.testing.assert_allclose(float(sig_err), float(g_integrate.get(case, "sig_err")), rtol=2e-6)
+    sd = NF.best_model.state_dict()
+    for k, v in g_integrate.sub(case, "sd_after").items():
+        np.testing.assert_allclose(t2n(sd[k]), v, rtol=1e-9, atol=1e-14, err_msg=k)
+
+
+# ------------------------------------------------------------------------------ training
+def camel_torch(x):
+    return torch.exp(-((x[:, 0] - 0.75) ** 2 + (x[:, 1] - 0.75) ** 2) / (0.2 ** 2)) + \
+        torch.exp(-((x[:, 0] - 0.25) ** 2 + (x[:, 1] - 0.25) ** 2) / (0.2 ** 2))
+
+
+class RecordingAdamax(torch.optim.Adamax):
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.seen = []
+
+    def step(self, closure=None):
+        self.seen.append([p.grad.detach().clone() for g in self.param_groups for p in g["params"]])
+        return super().step(closure)
+
+
+@pytest.mark.parametrize("case", golden("training.npz").cases())
+def test_training_vs_reference_golden(case, g_training, tmp_path):
+    m = g_training.meta[case]
+    NF = build_manager(dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3]), g_training.sub(case, "init/sd"))
+    opt = RecordingAdamax(NF._model.parameters(), lr=2e-3, weight_decay=1e-4)
+    draws = [g_training.get(case, f"draw{i:03d}") for i in range(m["n_draws"])]
+    NF.sample_hook = Replay(draws)
+    ret = NF._train_variance_forward_seq(camel_torch, opt, True, str(tmp_path), m["batch"], m["epochs"], 0, False, True,
+                                         mini_batch_size=m["mbs"], integrate=True, preburn_time=m["preburn"],
+                                         loss_mode=m["loss_mode"])
+    hist = np.array([float(h) for h in NF.history])
+    np.testing.assert_allclose(hist, g_training.get(case, "history"), rtol=1e-8)
+    pnames = [k for k, _ in NF._model.named_parameters()]
+    assert pnames == m["pnames"]
+    for ei, grads in enumerate(opt.seen):
+        for pn, g in zip(pnames, grads):
+            ref = g_training.get(case, f"grad{ei}/{pn}")
+            np.testing.assert_allclose(t2n(g), ref, rtol=1e-6, atol=1e-9 * max(1.0, np.abs(ref).max()), err_msg=f"{ei}/{pn}")
+    np.testing.assert_allclose(np.array(ret), g_training.get(case, "ret"), rtol=1e-5)       # float32 estimator slots
+    for att in ("best_loss", "varJ", "DKL", "int_loss", "best_loss_rel"):
+        np.testing.assert_allclose(float(getattr(NF, att)), float(g_training.get(case, att)), rtol=1e-7, err_msg=att)
+    np.testing.assert_allclose(float(NF.best_var), float(g_training.get(case, "best_var")), rtol=1e-6)
+    assert int(NF.best_epoch) == int(g_training.get(case, "best_epoch"))
+    assert float(NF.best_func_count) == float(g_training.get(case, "best_func_count"))
+    for k, v in g_training.sub(case, "final/sd").items():
+        np.testing.assert_allclose(t2n(NF._model.state_dict()[k]), v, rtol=1e-7, atol=1e-10, err_msg=k)
+    ck = torch.load(str(tmp_path / "torch"), weights_only=False)
+    assert sorted(ck.keys()) == m["ckpt_keys"]
+
+
+# ------------------------------------------------------------------------------ RAMBO
+def make_ps(m):
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    return FlatInvertiblePhasespace(m["initial"], m["final"], pdf=None, pdf_active=m["pdf_active"], tau=m["tau"])
+
+
+@pytest.mark.parametrize("case", golden("rambo.npz").cases())
+def test_rambo_vs_reference_golden(case, g_rambo):
+    m = g_rambo.meta[case]
+    gen = make_ps(m)
+    r = torch.as_tensor(g_rambo.get(case, "r")).to(dev())
+    mom, wgt = gen.generateKinematics_batch(m["E_cm"], r, pT_mincut=m["cuts"][0], delR_mincut=m["cuts"][1],
+                                            rap_maxcut=m["cuts"][2], pdgs=[2, -1])
+    ref_m, ref_w = g_rambo.get(case, "momenta"), g_rambo.get(case, "weight")
+    np.testing.assert_array_equal(t2n(wgt) == 0, ref_w == 0)                     # identical cut decisions
+    np.testing.assert_allclose(t2n(mom), ref_m, rtol=1e-9, atol=1e-10 * np.abs(ref_m).max())
+    np.testing.assert_allclose(t2n(wgt), ref_w, rtol=1e-9)
+
+
+@pytest.mark.parametrize("n,massive,pdf", [(4, True, False), (6, False, True), (3, True, True), (8, False, False)])
+def test_rambo_vs_oracle_seeded(n, massive, pdf):
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    rng = np.random.default_rng(n)
+    final = [float(v) for v in (rng.uniform(5, 80, n) if massive else np.zeros(n))]
+    init = [0., 0.]
+    E = 13000. if pdf else 2000.
+    N = 20011
+    r = rng.random((N, 3 * n - 4 + (2 if pdf else 0)))
+    cuts = (10., 0.4, 4.0) if pdf else (-1, -1, -1)
+    want = {}
+    ref_m, ref_w = orambo.generate_kinematics(init, final, E, r, *cuts, pdf_active=pdf, tau=True, want=want)
+    gen = FlatInvertiblePhasespace(init, final, pdf=None, pdf_active=pdf, tau=True)
+    mom, wgt = gen.generateKinematics_batch(E, torch.as_tensor(r).to(dev()), *cuts)
+    # cut decisions may legitimately differ only for points within rounding of a cut threshold
+    differ = (t2n(wgt) == 0) != (ref_w == 0)
+    assert differ.sum() <= 2
+    ok = ~differ
+    np.testing.assert_allclose(t2n(mom), ref_m, rtol=1e-8, atol=1e-9 * E)
+    np.testing.assert_allclose(t2n(wgt)[ok], ref_w[ok], rtol=1e-8)
+
+
+def test_rambo_full_size_invariants():
+    """BASELINE metric-ii shape: 2->4 massive, E_cm=1000, N=1e6: momentum conservation, on-shell legs,
+    mean weight 0.02482, determinism."""
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    gen = FlatInvertiblePhasespace([100.] * 2, [100.] * 4, pdf=None, pdf_active=False)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    r = torch.rand(1_000_000, 8, dtype=torch.double, device=dev(), generator=g)
+    mom, wgt = gen.generateKinematics_batch(1000., r, pT_mincut=0, delR_mincut=0, rap_maxcut=-1, pdgs=[2, -1])
+    tot = mom[:, 2:].sum(1) - mom[:, :2].sum(1)
+    assert float(tot.abs().max()) < 1e-9 * 1000.
+    msq = mom[:, :, 0] ** 2 - (mom[:, :, 1:] ** 2).sum(-1)
+    assert float((msq - 1e4).abs().max()) < 1e-6 * 1e4
+    shat = 1000. ** 2
+    mean_w = float(wgt.mean()) * 2 * shat
+    assert abs(mean_w - 0.02482) < 3e-4 * 3
+    mom2, wgt2 = gen.generateKinematics_batch(1000., r, pT_mincut=0, delR_mincut=0, rap_maxcut=-1, pdgs=[2, -1])
+    assert torch.equal(wgt, wgt2) and torch.equal(mom, mom2)
+
+
+def test_rambo_nan_raises():
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace, PhaseSpaceGeneratorError
+    gen = FlatInvertiblePhasespace([0.] * 2, [0.] * 3)
+    r = torch.rand(100, 5, dtype=torch.double, device=dev())
+    r[7, 2] = float("nan")
+    with pytest.raises(PhaseSpaceGeneratorError):
+        gen.generateKinematics_batch(100., r)
+
+
+# ------------------------------------------------------------------------------ moments
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 1000, 131072 + 17, 3_000_001])
+def test_moments_vs_numpy(N):
+    from nf_amd.flow import moments
+    rng = np.random.default_rng(N)
+    a = rng.normal(3.0, 0.01, N)                   # |mean| >> sigma: a naive sum of squares would lose digits
+    out = t2n(moments(torch.as_tensor(a).to(dev())))
+    assert out[0] == N
+    np.testing.assert_allclose(out[1], a.mean(), rtol=1e-13)
+    if N > 1:
+        np.testing.assert_allclose(out[2] / (N - 1), a.var(ddof=1), rtol=1e-9)
+    assert out[3] == a.max()
+    b = rng.random(N)
+    out = t2n(moments(torch.as_tensor(a).to(dev()), torch.as_tensor(b).to(dev())))
+    np.testing.assert_allclose(out[1], (a * b).mean(), rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------ full-size properties
+def test_c2_full_batch_properties():
+    """C2 (2-D camel, PWQuad 2 cells, K=4, NN=[3]*3) at batch 1e6: every X in [0,1), mean J -> 1
+    (a flow preserves volume), bitwise determinism, and shard/merge == whole batch in eval mode."""
+    from nf_amd import integrands
+    from nf_amd.flow import moments_of
+    from nf_amd.normalizing_flows.manager import PWQuadManager
+    torch.manual_seed(0)
+    NF = PWQuadManager(n_flow=2)
+    NF.create_model(2, 4, [3] * 3)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    w = torch.rand(1_000_000, 2, dtype=torch.double, device=dev(), generator=g)
+    NF._model.train()
+    a = NF._model.flow_forward(w, want_xj=True)["xj"]
+    assert float(a[:, :2].min()) >= 0.0 and float(a[:, :2].max()) < 1.0
+    assert abs(float(a[:, 2].mean()) - 1.0) < 5e-3
+    NF._model.eval()
+    e1 = NF._model.flow_forward(w, want_xj=True)
+    e2 = NF._model.flow_forward(w, want_xj=True)
+    assert torch.equal(e1["xj"], e2["xj"])
+    eng = NF._model.engine()
+    whole, _ = moments_of(e1["planes"], 2, eng.out_col, integrands.Camel.nis_kind, integrands.Camel().nis_params)
+    parts = []
+    for s in range(4):
+        ws = w[s * 250_000:(s + 1) * 250_000]
+        res = NF._model.flow_forward(ws)
+        parts.append(t2n(moments_of(res["planes"], 2, eng.out_col, integrands.Camel.nis_kind,
+                                    integrands.Camel().nis_params)[0]))
+    from nf_amd.parallel import merge_moments
+    merged = merge_moments(np.stack(parts))
+    np.testing.assert_allclose(merged[:3], t2n(whole)[:3], rtol=1e-11)
+    assert merged[3] == t2n(whole)[3]
+    # camel integral over the unit square (truncated Gaussians) = 0.2323 within MC error
+    mean, var = merged[1], merged[2] / (merged[0] - 1)
+    assert abs(mean - 0.23228) < 5 * np.sqrt(var / 1e6)

@@ -1,0 +1,143 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header
+declares, the drop-in classes build the reference's topology / state_dict layout, permutation layers fold
+into the right plane maps, and the product path refuses to run without a GPU (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+from nf_amd import _lib
+from nf_amd.normalizing_flows.manager import PWLinManager, PWQuadManager, get_bin
+from nf_amd.normalizing_flows.layers.coupling_cells import PWLin, PWQuad
+from nf_amd.normalizing_flows.sequential import FlowSequential
+
+HAS_GPU = torch.cuda.is_available()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "nis_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nis_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    syms = header_symbols()
+    assert set(_lib.EXPORTS) <= set(syms)
+    for s in syms:
+        assert hasattr(L, s), f"libnis_hip.so does not export {s}"
+    assert L.nis_version() >= 100
+
+
+def test_struct_layout_matches_header():
+    # sizes the C side computes from the same descriptor must agree with the parameter count of the modules
+    L = _lib.lib()
+    for cls, kind in ((PWQuad, "pwquad"), (PWLin, "pwlin")):
+        cell = cls(8, 3, 6, [7, 5])
+        from nf_amd.flow import cell_desc, _param_tensors
+        d = cell_desc(cell, list(range(8)))
+        ps, rs, bns = _param_tensors(cell)
+        assert L.nis_cell_param_count(ctypes.byref(d)) == sum(p.numel() for p in ps)
+        assert L.nis_cell_running_count(ctypes.byref(d)) == sum(getattr(bn, n).numel() for bn, n in rs)
+        assert sum(p.numel() for p in ps) == sum(p.numel() for p in cell.parameters())
+
+
+def build_manager(m):
+    """create_model without a GPU: the model object is assigned before the warm-up forward raises."""
+    torch.manual_seed(0)
+    if m["kind"] == "pwquad":
+        NF = PWQuadManager(n_flow=m["d"])
+        args = (m["n_cells"], m["K"], list(m["NN"]))
+    else:
+        NF = PWLinManager(n_flow=m["d"])
+        args = (m["P"], m["n_cells"], m["K"], list(m["NN"]), m["roll"])
+    if HAS_GPU:
+        NF.create_model(*args)
+    else:
+        with pytest.raises(_lib.NisError):
+            NF.create_model(*args)
+    return NF
+
+
+@pytest.mark.parametrize("case", golden("models.npz").cases())
+def test_topology_and_state_dict_layout(case, g_models):
+    m = g_models.meta[case]
+    NF = build_manager(m)
+    model = NF._model
+    assert isinstance(model, FlowSequential)
+    names = [n + ":" + type(c).__name__ for n, c in model.named_children()]
+    assert names == m["children"]
+    assert [c.pass_through_size for c in model.children() if hasattr(c, "KIND")] == m["passes"]
+    sd_ref = g_models.sub(case, "sd")
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(sd_ref.keys())
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(sd_ref[k].shape), k
+    # loading the reference's state_dict works unchanged
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd_ref.items()})
+
+
+@pytest.mark.parametrize("case", golden("models.npz").cases())
+def test_plane_map_equals_running_the_permutation_layers(case, g_models):
+    """Folding Roll/Mask/DeMask into plane indices must equal executing them: push a tensor whose columns
+    hold their own index through the permutation layers (cells skipped: they keep column positions)."""
+    m = g_models.meta[case]
+    model = build_manager(m)._model
+    cells, in_cols, out_col, d = model.plan()
+    x = torch.arange(d + 1, dtype=torch.double).repeat(3, 1)
+    seen = []
+    for mod in model.children():
+        if hasattr(mod, "KIND"):
+            seen.append([int(v) for v in x[0, :d]])
+        else:
+            x = mod(x)
+    assert seen == in_cols
+    assert [int(v) for v in x[0, :d]] == out_col
+    assert int(x[0, d]) == d
+
+
+def test_get_bin():
+    assert get_bin(5, 4) == [0, 1, 0, 1]
+    assert get_bin(0) == [0]
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU behaviour")
+def test_no_silent_cpu_fallback():
+    cell = PWQuad(2, 1, 4, [3, 3, 3]).double()
+    with pytest.raises(_lib.NisError):
+        cell(torch.rand(8, 3, dtype=torch.double))
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    gen = FlatInvertiblePhasespace([100., 100.], [100.] * 4)
+    with pytest.raises(_lib.NisError):
+        gen.generateKinematics_batch(1000., torch.rand(8, 8, dtype=torch.double))
+    from nf_amd.flow import moments
+    with pytest.raises(_lib.NisError):
+        moments(torch.rand(10, dtype=torch.double))
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base in ("nf_amd", "nisrep"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith(".py"):
+                    src = open(os.path.join(dp, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_nisrep_import_paths():
+    import importlib
+    mgr = importlib.import_module("nisrep.normalizing_flows.manager")
+    assert mgr.PWQuadManager is PWQuadManager and hasattr(mgr, "torch") and hasattr(mgr, "normal")
+    ps = importlib.import_module("nisrep.PhaseSpace.flat_phase_space_generator")
+    assert hasattr(ps, "FlatInvertiblePhasespace") and hasattr(ps, "PhaseSpaceGeneratorError")
+    gen = ps.FlatInvertiblePhasespace([0., 0.], [0.] * 4)
+    assert gen.nDimPhaseSpace() == 8
+    np.testing.assert_allclose(ps.FlatInvertiblePhasespace.get_flatWeights(1000., 4),
+                               golden("rambo.npz").meta["m2to4_massive"]["flat"], rtol=1e-14)
