@@ -76,11 +76,12 @@ def bench_flow(args, rank, ws, dev):
     ws_draws = [torch.rand(BATCH, 2, dtype=torch.float32, device=dev, generator=g) for _ in range(total)]
     out = torch.zeros((args.steps, 4), dtype=torch.double, device=dev)
 
+    scratch = torch.zeros(4, dtype=torch.double, device=dev)
+    token = eng.pack_token()            # parameters do not change inside integrate(): pack the image once
+
     def step(i, slot):
-        res = model.flow_forward(ws_draws[i])
-        o4, _ = moments_of(res["planes"], eng.d, eng.out_col, f.nis_kind, f.nis_params)
-        if slot >= 0:
-            out[slot] = o4
+        # ONE library call: ingest(+BN_0 stats) -> [BN stats x3 -> cell apply] x2 with camel*J + moments fused
+        eng.integrate_step(ws_draws[i], True, f.nis_kind, f.nis_params, out[slot] if slot >= 0 else scratch, token=token)
 
     for i in range(args.warmup):
         step(i, -1)

@@ -100,15 +100,31 @@ size_t nis_flow_workspace_bytes(const nis_flow* f, int64_t N);
  *   params   host array [n_cells] of device pointers to the parameter blobs
  *   running  host array [n_cells] of device pointers to the running-stat blobs
  *            (read in NIS_BN_EVAL; read-modify-written in NIS_BN_TRAIN, momentum 0.1, unbiased var)
+ *   tracked  host array [n_cells] of device pointers to int64[L+1] num_batches_tracked counters,
+ *            incremented in NIS_BN_TRAIN (may be NULL)
+ *   pack_token  0: re-pack the parameter image every call; otherwise the zero-padded image kept in the
+ *            workspace is reused while token, bn_mode, workspace and blob pointers are unchanged
+ *            (the caller changes the token whenever parameters or running statistics changed)
  *   planes   (d+1, ld) float64 state; on return plane out_col[c] holds X[:,c], plane d holds J
  *   xj_out   optional (N,d+1) row-major float64 = the reference's model output XJ (may be NULL)
  *   bins_out optional int32 [sum_cells T_c][ld] bin index per transformed column (may be NULL)
  * bn_mode NIS_BN_TRAIN reproduces train-mode BatchNorm1d (batch statistics over all N rows),
  * which is what the reference uses during training AND integrate(). */
 int nis_flow_forward(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N,
-                     const double* const* params, double* const* running, int32_t bn_mode,
+                     const double* const* params, double* const* running, long long* const* tracked,
+                     int32_t bn_mode, int64_t pack_token,
                      double* planes, int64_t ld, double* xj_out, int32_t* bins_out,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* One iteration of BasicManager.integrate (manager.py:395-400) in a single call: model forward on the
+ * batch w, built-in integrand f(X)*J evaluated inside the last cell's kernel, moments
+ * out4 = {count, mean, M2, max}.  keep_planes == 0: X and J are never written (nothing reads them);
+ * fres_out (N) optional. */
+int nis_integrate_step(nis_flow* f, const void* w, int32_t w_dtype, int64_t N,
+                       const double* const* params, double* const* running, long long* const* tracked,
+                       int32_t bn_mode, int64_t pack_token, int32_t f_kind, const double* f_params_host,
+                       double* planes, int64_t ld, int32_t keep_planes, double* fres_out, double* out4,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* f(X)*J for a built-in integrand straight from the planes + streaming moments of the result:
  * out4 = {count, mean, M2 = sum (v-mean)^2, max}   (torch.mean/var/max at manager.py:399-400,

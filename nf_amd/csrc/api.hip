@@ -115,8 +115,10 @@ struct nis_flow {
   std::vector<int> bins_row;
   int out_col[NIS_MAX_DIM];
   size_t body_doubles;
-  // packing cache
-  int64_t packed_version = -1;
+  size_t off_fpart;                 // moment records of the fused integrand (NIS_MAXB x 4)
+  // packing cache: the padded parameter image in the workspace stays valid while the caller's token,
+  // BN mode, workspace and parameter pointers are unchanged
+  int64_t packed_token = 0;
   int packed_mode = -1;
   const void* packed_ws = nullptr;
   std::vector<const double*> packed_params;
@@ -172,6 +174,8 @@ extern "C" int nis_flow_create(const nis_cell_desc* cells, int32_t n_cells, int3
     f->bins_row.push_back(brow);
     brow += cell_T(c);
   }
+  f->off_fpart = off;
+  off += (size_t)NIS_MAXB * 4;
   for (int j = 0; j < d; ++j) {
     if (out_col[j] < 0 || out_col[j] >= d) {
       delete f;
@@ -242,9 +246,28 @@ struct ColMap {
   int col[NIS_MAX_DIM + 1];
 };
 
+struct IngestStats {
+  int P;                           // 0: no statistics
+  int sel[NIS_PMAX_FUSED];         // input column of pass-through feature p of the first cell
+  int wm;                          // record stride of that cell
+  double* partials;                // its BN_0 records (one per workgroup)
+  int* status;                     // zeroed here (first launch of a forward)
+};
+
 template <typename TIN>
-__global__ __launch_bounds__(NIS_TPB) void k_ingest(const TIN* __restrict__ w, long N, int d, double* __restrict__ planes, long ld) {
+__global__ __launch_bounds__(NIS_TPB) void k_ingest(const TIN* __restrict__ w, long N, int d, double* __restrict__ planes, long ld,
+                                                    IngestStats st) {
   extern __shared__ double tile[];                              // [sample][d] with +1 skew per 32 rows
+  constexpr int NW = NIS_TPB / NIS_WAVE, NF = NIS_PMAX_FUSED;
+  __shared__ double wshift[NW][NF];
+  __shared__ double wmom[NW][NF][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && st.status) *st.status = 0;
+  double S1[NF], S2[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) S1[f] = S2[f] = 0.0;
+  double cnt = 0.0;
+  bool firstit = true;
   const long nblk = (N + NIS_TPB - 1) / NIS_TPB;
   for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const long i0 = blk * NIS_TPB;
@@ -256,10 +279,32 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest(const TIN* __restrict__ w, l
     }
     __syncthreads();
     const int s = threadIdx.x;
-    if (s < ns)
+    if (s < ns) {
       for (int cidx = 0; cidx < d; ++cidx) planes[(size_t)cidx * ld + i0 + s] = tile[s * d + cidx + s / 32];
+      if (st.P > 0) {
+        double v[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) v[f] = (f < st.P) ? tile[s * d + st.sel[f] + s / 32] : 0.0;
+        if (firstit) {
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const double s0 = wave_first(v[f]);
+            if (lane == 0) wshift[wave][f] = s0;
+          }
+          firstit = false;
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const double t = v[f] - wshift[wave][f];
+          S1[f] += t;
+          S2[f] = fma(t, t, S2[f]);
+        }
+        cnt += 1.0;
+      }
+    }
     __syncthreads();
   }
+  if (st.P > 0) emit_records<NF, NW>(S1, S2, cnt, wshift, wmom, st.P, st.partials + (size_t)blockIdx.x * st.wm * 3);
 }
 
 __global__ __launch_bounds__(NIS_TPB) void k_emit(const double* __restrict__ planes, long ld, long N, int d, ColMap m,
@@ -465,47 +510,81 @@ extern "C" int nis_integrand_moments(const double* planes, int64_t ld, int64_t N
 }
 
 // ---------------------------------------------------------------------------------------------
+struct RunOpts {
+  int w_has_jac = 0;
+  int bn_mode = NIS_BN_TRAIN;
+  int64_t pack_token = 0;          // 0: always repack
+  long long* const* tracked = nullptr;
+  double* xj_out = nullptr;
+  int32_t* bins_out = nullptr;
+  int f_kind = -1;                 // >= 0: built-in integrand, moments -> out4
+  const double* f_params = nullptr;
+  double* fres_out = nullptr;
+  double* out4 = nullptr;
+  int keep_planes = 1;             // 0 with f_kind >= 0: X / J are not stored
+};
+
 template <int WM>
-static int run_cell(const CellK& c, double* planes, long ld, long N, int bn_mode, int km, int* bins, int grid, hipStream_t s) {
+static int run_cell(const CellK& c, double* planes, long ld, long N, int bn_mode, int km, int* bins, const FuseF& fz, bool need_stats0,
+                    int grid_stats, int grid_apply, hipStream_t s) {
   if (bn_mode == NIS_BN_TRAIN)
-    for (int l = 0; l <= c.L; ++l) {
+    for (int l = need_stats0 ? 0 : 1; l <= c.L; ++l) {
       NisProfScope ps(NIS_K_STATS, s);
-      HIP_OK(launch_stats<WM>(c, planes, ld, N, l, grid, s));
+      HIP_OK(launch_stats<WM>(c, planes, ld, N, l, grid_stats, s));
     }
   NisProfScope ps(NIS_K_APPLY, s);
-  HIP_OK(launch_apply<WM>(c, planes, ld, N, bn_mode == NIS_BN_TRAIN ? 1 : 0, km, bins, grid, s));
+  HIP_OK(launch_apply<WM>(c, planes, ld, N, bn_mode == NIS_BN_TRAIN ? 1 : 0, km, bins, fz, grid_apply, s));
   return NIS_OK;
 }
 
-extern "C" int nis_flow_forward(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N, const double* const* params,
-                                double* const* running, int32_t bn_mode, double* planes, int64_t ld, double* xj_out,
-                                int32_t* bins_out, void* workspace, size_t workspace_bytes, void* stream) {
+static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, const double* const* params, double* const* running,
+                    double* planes, int64_t ld, void* workspace, size_t workspace_bytes, hipStream_t s, const RunOpts& o) {
   if (!f || !w || !params || !running || !planes || N < 1 || ld < N) return NIS_E_ARG;
-  if (bn_mode != NIS_BN_EVAL && bn_mode != NIS_BN_TRAIN) return NIS_E_ARG;
+  if (o.bn_mode != NIS_BN_EVAL && o.bn_mode != NIS_BN_TRAIN) return NIS_E_ARG;
   if (w_dtype != NIS_F64 && w_dtype != NIS_F32) return NIS_E_ARG;
   if (!workspace || workspace_bytes < nis_flow_workspace_bytes(f, N)) return NIS_E_WORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
   int* status = (int*)workspace;
   double* body = (double*)((char*)workspace + WS_HEADER);
-  HIP_OK(hipMemsetAsync(status, 0, sizeof(int), s));
   const int d = f->d;
-  const int grid = stream_grid(N);
-  const int tgrid = (int)std::min<int64_t>(2048, (N + NIS_TPB - 1) / NIS_TPB);
+  const bool train = o.bn_mode == NIS_BN_TRAIN;
+  const int nblk = (int)std::min<int64_t>(NIS_MAXB, (N + NIS_TPB - 1) / NIS_TPB);
+  const int grid_apply = std::max(1, nblk);
+  const int tgrid = std::max(1, nblk);
   const size_t tile_bytes = ((size_t)NIS_TPB * (d + 1) + 16) * sizeof(double);
-  const int wcols = w_has_jac ? d + 1 : d;
+  const int wcols = o.w_has_jac ? d + 1 : d;
 
+  // is the padded parameter image in this workspace still valid?
+  bool repack = o.pack_token == 0 || o.pack_token != f->packed_token || o.bn_mode != f->packed_mode || workspace != f->packed_ws;
+  for (int ci = 0; ci < f->n_cells && !repack; ++ci) repack = params[ci] != f->packed_params[ci];
+
+  // ---- ingest (+ BN_0 records of the first cell)
+  const nis_cell_desc& c0 = f->cells[0];
+  IngestStats ist;
+  memset(&ist, 0, sizeof(ist));
+  ist.status = status;
+  const bool ingest_stats = train && c0.P <= NIS_PMAX_FUSED;
+  if (ingest_stats) {
+    ist.P = c0.P;
+    for (int p = 0; p < c0.P; ++p) ist.sel[p] = c0.in_col[p];
+    ist.wm = f->lay[0].WM;
+    ist.partials = body + f->lay[0].off_part;
+  }
   nis_prof_mark(NIS_K_INGEST, 1, s);
   if (w_dtype == NIS_F64)
-    hipLaunchKernelGGL(k_ingest<double>, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const double*)w, (long)N, wcols, planes, (long)ld);
+    hipLaunchKernelGGL(k_ingest<double>, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const double*)w, (long)N, wcols, planes, (long)ld, ist);
   else
-    hipLaunchKernelGGL(k_ingest<float>, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const float*)w, (long)N, wcols, planes, (long)ld);
+    hipLaunchKernelGGL(k_ingest<float>, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const float*)w, (long)N, wcols, planes, (long)ld, ist);
   nis_prof_mark(NIS_K_INGEST, 0, s);
   HIP_OK(hipGetLastError());
 
+  int prev_records = tgrid;           // records of BN_0 of the current cell written by the previous launch
+  bool have_stats0 = ingest_stats;
   for (int ci = 0; ci < f->n_cells; ++ci) {
     const nis_cell_desc& cd = f->cells[ci];
     const CellLayout& L = f->lay[ci];
     if (!params[ci] || !running[ci]) return NIS_E_ARG;
+    const int tpb_stats = nis_stats_tpb(L.WM);
+    const int grid_stats = (int)std::max<int64_t>(1, std::min<int64_t>(256, (N + tpb_stats - 1) / tpb_stats));
     CellK c;
     memset(&c, 0, sizeof(c));
     c.kind = cd.kind;
@@ -519,8 +598,9 @@ extern "C" int nis_flow_forward(nis_flow* f, const void* w, int32_t w_dtype, int
     for (int l = 0; l < cd.n_hidden; ++l) c.width[l] = cd.width[l];
     for (int j = 0; j < d; ++j) c.in_plane[j] = cd.in_col[j];
     c.jplane = d;
-    c.first = (ci == 0 && !w_has_jac) ? 1 : 0;
-    c.nparts = grid;
+    c.first = (ci == 0 && !o.w_has_jac) ? 1 : 0;
+    c.nparts[0] = have_stats0 ? prev_records : grid_stats;
+    for (int l = 1; l <= cd.n_hidden; ++l) c.nparts[l] = grid_stats;
     c.maxb = NIS_MAXB;
     c.bins_row = f->bins_row[ci];
     c.wp = body + L.off_wp;
@@ -530,31 +610,118 @@ extern "C" int nis_flow_forward(nis_flow* f, const void* w, int32_t w_dtype, int
     c.coef = body + L.off_coef;
     c.partials = body + L.off_part;
     c.running = running[ci];
+    c.tracked = (train && o.tracked) ? o.tracked[ci] : nullptr;
     c.status = status;
-    // (re)pack the padded parameter image; cheap (one small launch per cell)
-    {
+    // rider 1: BN_0 records of the next cell (every state column is in this thread's registers)
+    bool next_rider = false;
+    if (train && ci + 1 < f->n_cells && L.WM <= 8 && f->cells[ci + 1].P <= NIS_PMAX_FUSED) {
+      const nis_cell_desc& nx = f->cells[ci + 1];
+      next_rider = true;
+      c.next_P = nx.P;
+      for (int p = 0; p < nx.P; ++p) {
+        int src = -1;
+        for (int j = 0; j < d; ++j)
+          if (cd.in_col[j] == nx.in_col[p]) src = j;
+        c.next_src[p] = src;
+      }
+      for (int p = nx.P; p < NIS_PMAX_FUSED; ++p) c.next_src[p] = -1;
+      c.next_partials = body + f->lay[ci + 1].off_part;
+      c.next_wm = f->lay[ci + 1].WM;
+    }
+    // rider 2: built-in integrand + moment records in the last cell
+    FuseF fz;
+    memset(&fz, 0, sizeof(fz));
+    fz.kind = -1;
+    fz.write_planes = 1;
+    const bool last = ci + 1 == f->n_cells;
+    bool fused_f = false;
+    if (last && o.f_kind >= 0 && L.WM <= 8) {
+      fused_f = true;
+      fz.kind = o.f_kind;
+      fz.loc0 = fz.loc1 = -1;
+      for (int j = 0; j < d; ++j) {
+        if (cd.in_col[j] == f->out_col[0]) fz.loc0 = j;
+        if (d > 1 && cd.in_col[j] == f->out_col[1]) fz.loc1 = j;
+      }
+      for (int k = 0; k < 4; ++k) fz.p[k] = o.f_params ? o.f_params[k] : 0.0;
+      fz.partials = body + f->off_fpart;
+      fz.fres = o.fres_out;
+      fz.write_planes = (o.keep_planes || o.xj_out) ? 1 : 0;
+    }
+    if (repack) {
       const int pgrid = (int)std::min<size_t>(64, ((size_t)c.R * L.WM + NIS_TPB - 1) / NIS_TPB);
+      NisProfScope ps(NIS_K_PACK, s);
       hipLaunchKernelGGL(k_pack, dim3(std::max(1, pgrid)), dim3(NIS_TPB), 0, s, c, L.WM, params[ci], (const double*)running[ci],
-                         bn_mode == NIS_BN_EVAL ? 1 : 0, body + L.off_wp, body + L.off_wlast, body + L.off_bias, body + L.off_gb);
+                         train ? 0 : 1, body + L.off_wp, body + L.off_wlast, body + L.off_bias, body + L.off_gb);
       HIP_OK(hipGetLastError());
     }
     int rc;
+    const bool need0 = !have_stats0;
     switch (L.WM) {
-      case 4: rc = run_cell<4>(c, planes, ld, N, bn_mode, L.KM, bins_out, grid, s); break;
-      case 8: rc = run_cell<8>(c, planes, ld, N, bn_mode, L.KM, bins_out, grid, s); break;
-      case 16: rc = run_cell<16>(c, planes, ld, N, bn_mode, L.KM, bins_out, grid, s); break;
-      case 32: rc = run_cell<32>(c, planes, ld, N, bn_mode, L.KM, bins_out, grid, s); break;
-      case 64: rc = run_cell<64>(c, planes, ld, N, bn_mode, L.KM, bins_out, grid, s); break;
+      case 4: rc = run_cell<4>(c, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, s); break;
+      case 8: rc = run_cell<8>(c, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, s); break;
+      case 16: rc = run_cell<16>(c, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, s); break;
+      case 32: rc = run_cell<32>(c, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, s); break;
+      case 64: rc = run_cell<64>(c, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, s); break;
       default: rc = NIS_E_UNSUPPORTED;
     }
     if (rc != NIS_OK) return rc;
+    have_stats0 = next_rider;
+    prev_records = grid_apply;
+    if (last && o.f_kind >= 0) {
+      if (fused_f) {
+        NisProfScope ps(NIS_K_MOMENTS, s);
+        hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(NIS_TPB), 0, s, (const double*)(body + f->off_fpart), grid_apply, o.out4);
+        HIP_OK(hipGetLastError());
+      } else {
+        int rc2 = nis_integrand_moments(planes, ld, N, d, f->out_col, o.f_kind, o.f_params, o.fres_out, o.out4, body + f->off_fpart,
+                                        (size_t)NIS_MAXB * 4 * sizeof(double), (void*)s);
+        if (rc2 != NIS_OK) return rc2;
+      }
+    }
   }
-  if (xj_out) {
+  f->packed_token = o.pack_token;
+  f->packed_mode = o.bn_mode;
+  f->packed_ws = workspace;
+  for (int ci = 0; ci < f->n_cells; ++ci) f->packed_params[ci] = params[ci];
+  if (o.xj_out) {
     ColMap m;
     for (int j = 0; j < d; ++j) m.col[j] = f->out_col[j];
     m.col[d] = d;
-    hipLaunchKernelGGL(k_emit, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const double*)planes, (long)ld, (long)N, d, m, xj_out);
+    NisProfScope ps(NIS_K_EMIT, s);
+    hipLaunchKernelGGL(k_emit, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const double*)planes, (long)ld, (long)N, d, m, o.xj_out);
     HIP_OK(hipGetLastError());
   }
   return NIS_OK;
+}
+
+extern "C" int nis_flow_forward(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N, const double* const* params,
+                                double* const* running, long long* const* tracked, int32_t bn_mode, int64_t pack_token, double* planes,
+                                int64_t ld, double* xj_out, int32_t* bins_out, void* workspace, size_t workspace_bytes, void* stream) {
+  RunOpts o;
+  o.w_has_jac = w_has_jac;
+  o.bn_mode = bn_mode;
+  o.pack_token = pack_token;
+  o.tracked = tracked;
+  o.xj_out = xj_out;
+  o.bins_out = bins_out;
+  return flow_run(f, w, w_dtype, N, params, running, planes, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
+}
+
+extern "C" int nis_integrate_step(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, const double* const* params,
+                                  double* const* running, long long* const* tracked, int32_t bn_mode, int64_t pack_token,
+                                  int32_t f_kind, const double* f_params_host, double* planes, int64_t ld, int32_t keep_planes,
+                                  double* fres_out, double* out4, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!out4 || f_kind < 0) return NIS_E_ARG;
+  if (f_kind == NIS_F_CAMEL && f && f->d < 2) return NIS_E_ARG;
+  RunOpts o;
+  o.bn_mode = bn_mode;
+  o.pack_token = pack_token;
+  o.tracked = tracked;
+  o.f_kind = f_kind;
+  o.f_params = f_params_host;
+  o.fres_out = fres_out;
+  o.out4 = out4;
+  o.keep_planes = keep_planes;
+  return flow_run(f, w, w_dtype, N, params, running, planes, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
 }

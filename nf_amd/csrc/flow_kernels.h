@@ -1,7 +1,8 @@
 // Coupling-cell kernels (templates).  One thread owns one sample; the conditioner activations live
 // in registers (compile-time width WM, zero padded), weights arrive through scalar loads, BatchNorm
 // affine coefficients through LDS broadcast reads.  Train-mode BatchNorm needs the batch statistics
-// of every BN layer, so a cell is   [k_bn_stats(l) for l = 0..L]  ->  k_cell_apply :
+// of every BN layer, so a cell is   [k_bn_stats(l) for l = 1..L]  ->  k_cell_apply   (the BN_0 records
+// ride along in the launch that produces the cell's input: k_ingest or the previous k_cell_apply):
 // k_bn_stats(l) recomputes layers < l from the pass-through planes and emits per-workgroup
 // (count, mean, M2) records; the NEXT launch merges them in its prologue (fixed order ->
 // bitwise reproducible) into scale/shift.  No atomics, no grid barrier: the kernel boundary is
@@ -15,48 +16,62 @@
 // ---------------------------------------------------------------------------------------------
 // Prologue: bring the BN affine form (scale, shift) of layers [0, upto) into LDS.
 //   layers < fresh : already finalised by an earlier launch -> c.coef (global)
-//   layer == fresh : merge the partial records of the previous statistics launch (train mode)
-// lds_coef layout: [layer][0: scale, 1: shift][WM].  `red` is scratch of 3*NIS_TPB doubles.
-// Workgroup 0 additionally publishes the fresh coefficients and applies the running-stat update.
-template <int WM>
+//   layer == fresh : merge the partial records of the producing launch (train mode).
+// The records are merged as sums shifted by record 0's mean (no divisions, |shift error| ~ sigma/sqrt(n)),
+// TPB/WM slices per feature, then an LDS tree.  lds_coef: [layer][0: scale, 1: shift][WM];
+// `red`: 3*TPB doubles.  Workgroup 0 publishes the fresh coefficients, applies the running-stat update
+// (momentum 0.1, unbiased variance) and bumps num_batches_tracked.
+template <int WM, int TPB>
 __device__ __forceinline__ void load_coefs(const CellK& c, int upto, int fresh, double* lds_coef, double* red) {
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < upto * 2 * WM; idx += NIS_TPB) {
+  for (int idx = tid; idx < upto * 2 * WM; idx += TPB) {
     const int l = idx / (2 * WM);
     if (l != fresh) lds_coef[idx] = c.coef[idx];
   }
   if (fresh >= 0 && fresh < upto) {
-    constexpr int S = NIS_TPB / WM;          // slices of partial records per feature
+    constexpr int S = TPB / WM;              // slices of partial records per feature (power of two)
     const int j = tid % WM, s = tid / WM;
     const double* part = c.partials + (size_t)fresh * c.maxb * WM * 3;
-    Mom acc = {0.0, 0.0, 0.0};
-    for (int b = s; b < c.nparts; b += S) {
+    const int np = c.nparts[fresh];
+    const double ref = part[j * 3 + 1];      // mean of record 0 (workgroup 0 always owns samples)
+    double an = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int b = s; b < np; b += S) {
       const double* q = part + ((size_t)b * WM + j) * 3;
-      Mom m = {q[0], q[1], q[2]};
-      acc = mom_merge(acc, m);
+      const double n = q[0], dl = q[1] - ref;
+      an += n;
+      a1 = fma(n, dl, a1);
+      a2 += fma(n * dl, dl, q[2]);
     }
-    red[(s * WM + j) * 3 + 0] = acc.n;
-    red[(s * WM + j) * 3 + 1] = acc.mean;
-    red[(s * WM + j) * 3 + 2] = acc.m2;
+    red[(s * WM + j) * 3 + 0] = an;
+    red[(s * WM + j) * 3 + 1] = a1;
+    red[(s * WM + j) * 3 + 2] = a2;
     __syncthreads();
-    if (s == 0) {
-      Mom t = {0.0, 0.0, 0.0};
-      for (int q = 0; q < S; ++q) {
-        Mom m = {red[(q * WM + j) * 3 + 0], red[(q * WM + j) * 3 + 1], red[(q * WM + j) * 3 + 2]};
-        t = mom_merge(t, m);
+#pragma unroll
+    for (int h = S / 2; h > 0; h >>= 1) {
+      if (s < h) {
+        red[(s * WM + j) * 3 + 0] += red[((s + h) * WM + j) * 3 + 0];
+        red[(s * WM + j) * 3 + 1] += red[((s + h) * WM + j) * 3 + 1];
+        red[(s * WM + j) * 3 + 2] += red[((s + h) * WM + j) * 3 + 2];
       }
+      __syncthreads();
+    }
+    if (s == 0) {
+      const double n = red[j * 3 + 0], s1 = red[j * 3 + 1], s2 = red[j * 3 + 2];
       const int F = cellk_feat(c, fresh);
       double scale = 0.0, shift = 0.0;
       if (j < F) {
-        const double var_b = t.m2 / t.n;                         // biased variance normalises the batch
+        const double mean = ref + s1 / n;
+        const double m2 = fmax(s2 - s1 * s1 / n, 0.0);
+        const double var_b = m2 / n;                             // biased variance normalises the batch
         const double g = c.gb[(fresh * 2 + 0) * WM + j], be = c.gb[(fresh * 2 + 1) * WM + j];
         scale = g / sqrt(var_b + NIS_BN_EPS);
-        shift = be - t.mean * scale;
+        shift = be - mean * scale;
         if (blockIdx.x == 0) {
           double* run = c.running + cellk_running_off(c, fresh);
-          const double unb = t.n > 1.0 ? t.m2 / (t.n - 1.0) : var_b;   // running_var takes the unbiased one
-          run[j] = (1.0 - NIS_BN_MOM) * run[j] + NIS_BN_MOM * t.mean;
+          const double unb = n > 1.0 ? m2 / (n - 1.0) : var_b;   // running_var takes the unbiased one
+          run[j] = (1.0 - NIS_BN_MOM) * run[j] + NIS_BN_MOM * mean;
           run[F + j] = (1.0 - NIS_BN_MOM) * run[F + j] + NIS_BN_MOM * unb;
+          if (j == 0 && c.tracked) c.tracked[fresh] += 1;
         }
       }
       lds_coef[(fresh * 2 + 0) * WM + j] = scale;
@@ -68,6 +83,37 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int upto, int fresh, 
     }
   }
   __syncthreads();
+}
+
+// Per-feature records of a workgroup: every thread holds cnt and S1[f], S2[f] (sums of v - shift, (v - shift)^2
+// with the wave-uniform shift wshift[wave][f]).  out: record f at out[f*3 .. f*3+2].
+template <int F, int NW>
+__device__ __forceinline__ void emit_records(const double (&S1)[F], const double (&S2)[F], double cnt, double (*wshift)[F],
+                                             double (*wmom)[F][3], int nvalid, double* out) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double nw = wave_sum(cnt);
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    const double s1 = wave_sum(S1[f]);
+    const double s2 = wave_sum(S2[f]);
+    if (lane == 0) {
+      const bool any = nw > 0.0;
+      wmom[wave][f][0] = nw;
+      wmom[wave][f][1] = any ? wshift[wave][f] + s1 / nw : 0.0;
+      wmom[wave][f][2] = any ? fmax(s2 - s1 * s1 / nw, 0.0) : 0.0;
+    }
+  }
+  __syncthreads();
+  if (tid < F && tid < nvalid) {
+    Mom t = {0.0, 0.0, 0.0};
+    for (int w = 0; w < NW; ++w) {
+      Mom m = {wmom[w][tid][0], wmom[w][tid][1], wmom[w][tid][2]};
+      t = mom_merge(t, m);
+    }
+    out[tid * 3 + 0] = t.n;
+    out[tid * 3 + 1] = t.mean;
+    out[tid * 3 + 2] = t.m2;
+  }
 }
 
 // h <- W(WMxWM, row-major, zero padded) * a
@@ -88,9 +134,8 @@ __device__ __forceinline__ void load_passthrough(const CellK& c, const double* p
   for (int p = 0; p < WM; ++p) a[p] = (p < c.P) ? planes[(size_t)c.in_plane[p < NIS_MAX_DIM ? p : 0] * ld + i] : 0.0;
 }
 
-// Conditioner up to (and excluding) BN layer `upto`: returns the pre-BN activations of that layer
-// in `a` (upto == 0: the raw pass-through block).  For the full hidden stack call with upto = L
-// and then apply BN_L + ReLU (hidden_stack does that when `finish`).
+// Conditioner up to (and excluding) BN layer `upto`: leaves the pre-BN activations of that layer in `a`
+// (upto == 0: the raw pass-through block).  With `finish`, BN_upto (+ReLU) is applied as well.
 template <int WM>
 __device__ __forceinline__ void hidden_stack(const CellK& c, const double* lds_coef, int upto, bool finish, double (&a)[WM]) {
   double b[WM];
@@ -120,22 +165,23 @@ __device__ __forceinline__ void hidden_stack(const CellK& c, const double* lds_c
 
 // ---------------------------------------------------------------------------------------------
 // Batch statistics of BN layer `layer` (0..L): partial (count, mean, M2) per workgroup & feature.
-template <int WM>
-__global__ __launch_bounds__(NIS_TPB) void k_bn_stats(CellK c, const double* __restrict__ planes, long ld, long N, int layer) {
+template <int WM, int TPB>
+__global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restrict__ planes, long ld, long N, int layer) {
+  constexpr int NW = TPB / NIS_WAVE;
   __shared__ double lds_coef[NIS_MAX_HIDDEN * 2 * WM];
-  __shared__ double red[3 * NIS_TPB];
-  __shared__ double wshift[NIS_TPB / NIS_WAVE][WM];
-  __shared__ double wmom[NIS_TPB / NIS_WAVE][WM][3];
+  __shared__ double red[3 * TPB];
+  __shared__ double wshift[NW][WM];
+  __shared__ double wmom[NW][WM][3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  load_coefs<WM>(c, layer, layer - 1, lds_coef, red);
+  load_coefs<WM, TPB>(c, layer, layer - 1, lds_coef, red);
 
   double S1[WM], S2[WM];
 #pragma unroll
   for (int j = 0; j < WM; ++j) S1[j] = S2[j] = 0.0;
   double cnt = 0.0;
-  const long stride = (long)gridDim.x * NIS_TPB;
+  const long stride = (long)gridDim.x * TPB;
   bool firstit = true;
-  for (long i = (long)blockIdx.x * NIS_TPB + tid; i < N; i += stride) {
+  for (long i = (long)blockIdx.x * TPB + tid; i < N; i += stride) {
     double a[WM];
     load_passthrough<WM>(c, planes, ld, i, a);
     hidden_stack<WM>(c, lds_coef, layer, false, a);
@@ -155,34 +201,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_bn_stats(CellK c, const double* __r
     }
     cnt += 1.0;
   }
-  // wave -> workgroup -> one record per feature
-  const double nw = wave_sum(cnt);
-#pragma unroll
-  for (int j = 0; j < WM; ++j) {
-    const double s1 = wave_sum(S1[j]);
-    const double s2 = wave_sum(S2[j]);
-    if (lane == 0) {
-      if (nw > 0.0) {
-        wmom[wave][j][0] = nw;
-        wmom[wave][j][1] = wshift[wave][j] + s1 / nw;
-        wmom[wave][j][2] = fmax(s2 - s1 * s1 / nw, 0.0);
-      } else {
-        wmom[wave][j][0] = wmom[wave][j][1] = wmom[wave][j][2] = 0.0;
-      }
-    }
-  }
-  __syncthreads();
-  if (tid < WM) {
-    Mom t = {0.0, 0.0, 0.0};
-    for (int w = 0; w < NIS_TPB / NIS_WAVE; ++w) {
-      Mom m = {wmom[w][tid][0], wmom[w][tid][1], wmom[w][tid][2]};
-      t = mom_merge(t, m);
-    }
-    double* q = c.partials + (((size_t)layer * c.maxb + blockIdx.x) * WM + tid) * 3;
-    q[0] = t.n;
-    q[1] = t.mean;
-    q[2] = t.m2;
-  }
+  emit_records<WM, NW>(S1, S2, cnt, wshift, wmom, WM, c.partials + ((size_t)layer * c.maxb + blockIdx.x) * WM * 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -203,6 +222,9 @@ __device__ __forceinline__ double lerp_torch(double a, double b, double w) {
 
 // Piecewise-quadratic transform of one column (coupling_cells.py:167-225).  V: K+1 vertex heights
 // (raw exp), W: K bin widths (raw exp).  Returns y; *jf = d y / d x; *bin = bin index.
+// The cumulative widths that decide the bin are formed exactly as the reference does (cumsum of the raw
+// exponentials, then a true division by the total), so the selected bin is bit-identical for identical
+// conditioner outputs; the remaining normalisations multiply by a reciprocal (<= 1 ulp from a division).
 template <int KM>
 __device__ __forceinline__ double pwquad_column(double xb, int K, double (&V)[KM + 1], double (&W)[KM], double* jf, int* bin) {
   xb = (xb > 1.0 - 1e-6) ? 1.0 - 1e-6 : xb;                       // :167
@@ -226,16 +248,18 @@ __device__ __forceinline__ double pwquad_column(double xb, int K, double (&V)[KM
       }
     }
   if (idx > K - 1) idx = K - 1;
-#pragma unroll
-  for (int k = 0; k < KM; ++k)
-    if (k < K) W[k] = W[k] / wn;                                  // :184
+  const double iwn = 1.0 / wn;
   double area = 0.0;
 #pragma unroll
   for (int k = 0; k < KM; ++k)
-    if (k < K) area += (V[k] + V[k + 1]) / 2 * W[k];              // :194
+    if (k < K) {
+      W[k] = W[k] * iwn;                                          // :184
+      area += (V[k] + V[k + 1]) / 2 * W[k];                       // :194
+    }
+  const double iarea = 1.0 / area;
 #pragma unroll
   for (int k = 0; k < KM + 1; ++k)
-    if (k <= K) V[k] = V[k] / area;                               // :196-197
+    if (k <= K) V[k] = V[k] * iarea;                              // :196-197
   double vw = 0.0, shift = 0.0, Wb = 1.0, Vb = 0.0, Vb1 = 0.0;
 #pragma unroll
   for (int k = 0; k < KM; ++k)
@@ -256,20 +280,59 @@ __device__ __forceinline__ double pwquad_column(double xb, int K, double (&V)[KM
   return y1 + y2 + shift;                                         // :220
 }
 
-// Full cell: conditioner with finalised BN + bijector, in place on the transformed planes.
+// Full cell: conditioner with finalised BN + bijector, in place on the transformed planes.  Optional riders:
+//   * BN_0 records of the NEXT cell (its pass-through columns are all in this thread's registers),
+//   * a built-in integrand f(X)*J with its moment records (last cell), optionally without storing X, J.
 template <int KIND, int WM, int KM>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
-                                                        int* __restrict__ bins_out) {
+                                                        int* __restrict__ bins_out, FuseF fz) {
+  constexpr int NW = NIS_TPB / NIS_WAVE;
+  constexpr int NF = NIS_PMAX_FUSED;
   __shared__ double lds_coef[(NIS_MAX_HIDDEN + 1) * 2 * WM];
   __shared__ double red[3 * NIS_TPB];
-  const int tid = threadIdx.x;
-  load_coefs<WM>(c, c.L + 1, bn_train ? c.L : -1, lds_coef, red);
+  __shared__ double wshift[NW][NF];
+  __shared__ double wmom[NW][NF][3];
+  __shared__ double fmom[NW][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  load_coefs<WM, NIS_TPB>(c, c.L + 1, bn_train ? c.L : -1, lds_coef, red);
   nis_cptr wl = as_const(c.wlast);
   nis_cptr bias = as_const(c.bias);
+  constexpr bool RIDERS = WM <= 8;          // wide conditioners keep their registers for the GEMV
+  const bool next = RIDERS && c.next_P > 0;
+  const bool fuse = RIDERS && fz.kind >= 0;
+  double nS1[NF], nS2[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) nS1[f] = nS2[f] = 0.0;
+  double cnt = 0.0, fS1 = 0.0, fS2 = 0.0, fmax_ = -__builtin_huge_val(), fshift = 0.0;
+  bool firstit = true;
   const long stride = (long)gridDim.x * NIS_TPB;
   for (long i = (long)blockIdx.x * NIS_TPB + tid; i < N; i += stride) {
     double a[WM];
     load_passthrough<WM>(c, planes, ld, i, a);
+    double nv[NF];
+    double c0 = 0.0, c1 = 0.0, nsum = 0.0;
+    if (next) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        nv[f] = 0.0;
+#pragma unroll
+        for (int p = 0; p < (WM < NIS_MAX_DIM ? WM : NIS_MAX_DIM); ++p)
+          if (c.next_src[f] == p) nv[f] = a[p];
+      }
+    }
+    if (fuse) {
+      if (fz.kind == NIS_F_CAMEL) {
+#pragma unroll
+        for (int p = 0; p < (WM < NIS_MAX_DIM ? WM : NIS_MAX_DIM); ++p) {
+          if (fz.loc0 == p) c0 = a[p];
+          if (fz.loc1 == p) c1 = a[p];
+        }
+      } else if (fz.kind == NIS_F_NORMAL) {
+#pragma unroll
+        for (int p = 0; p < (WM < NIS_MAX_DIM ? WM : NIS_MAX_DIM); ++p)
+          if (p < c.P) nsum += ((a[p] - fz.p[0]) * (a[p] - fz.p[0])) / (2 * fz.p[1] * fz.p[1]);
+      }
+    }
     hidden_stack<WM>(c, lds_coef, c.L, true, a);
     double jprod = 1.0;
     for (int t = 0; t < c.T; ++t) {
@@ -309,26 +372,75 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
         y = qn * alpha + below / tot;                                                 // :123,136-139
         jf = qn;                                                                      // :141
       }
-      col[i] = y;
+      if (fz.write_planes) col[i] = y;
       jprod *= jf;
       if (bins_out) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
+      if (next) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+          if (c.next_src[f] == c.P + t) nv[f] = y;
+      }
+      if (fuse) {
+        if (fz.loc0 == c.P + t) c0 = y;
+        if (fz.loc1 == c.P + t) c1 = y;
+        if (fz.kind == NIS_F_NORMAL) nsum += ((y - fz.p[0]) * (y - fz.p[0])) / (2 * fz.p[1] * fz.p[1]);
+      }
     }
     double* jp = planes + (size_t)c.jplane * ld;
-    const double jin = c.first ? 1.0 : jp[i];
-    jp[i] = jin * jprod;
+    const double jout = (c.first ? 1.0 : jp[i]) * jprod;
+    if (fz.write_planes) jp[i] = jout;
+    if (next) {
+      if (firstit) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const double s0 = wave_first(nv[f]);
+          if (lane == 0) wshift[wave][f] = s0;
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const double t = nv[f] - wshift[wave][f];
+        nS1[f] += t;
+        nS2[f] = fma(t, t, nS2[f]);
+      }
+    }
+    if (fuse) {
+      double fv = 1.0;
+      if (fz.kind == NIS_F_CAMEL) {                                                   // README.md:35-36
+        const double s2 = fz.p[2] * fz.p[2];
+        const double e1 = -((c0 - fz.p[0]) * (c0 - fz.p[0]) + (c1 - fz.p[0]) * (c1 - fz.p[0])) / s2;
+        const double e2 = -((c0 - fz.p[1]) * (c0 - fz.p[1]) + (c1 - fz.p[1]) * (c1 - fz.p[1])) / s2;
+        fv = exp(e1) + exp(e2);
+      } else if (fz.kind == NIS_F_NORMAL) {                                           // manager.py:39-40
+        fv = exp(-nsum) / (fz.p[1] * sqrt(pow(2 * M_PI, (double)c.d)));
+      }
+      const double v = fv * jout;
+      if (fz.fres) fz.fres[i] = v;
+      if (firstit) fshift = wave_first(v);
+      const double t = v - fshift;
+      fS1 += t;
+      fS2 = fma(t, t, fS2);
+      fmax_ = fmax(fmax_, v);
+    }
+    cnt += 1.0;
+    firstit = false;
   }
+  if (next) emit_records<NF, NW>(nS1, nS2, cnt, wshift, wmom, c.next_P, c.next_partials + (size_t)blockIdx.x * c.next_wm * 3);
+  if (fuse) block_record<NW>(fshift, fS1, fS2, cnt, fmax_, fmom, fz.partials + (size_t)blockIdx.x * 4);
 }
 
 // Host-side launchers, instantiated once per WM in flow_wm.hip.
 template <int WM>
 hipError_t launch_stats(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s);
 template <int WM>
-hipError_t launch_apply(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, int grid, hipStream_t s);
-#define NIS_DECL_WM(W)                                                                                             \
-  template <>                                                                                                      \
-  hipError_t launch_stats<W>(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s); \
-  template <>                                                                                                      \
-  hipError_t launch_apply<W>(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, int grid, hipStream_t s);
+hipError_t launch_apply(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz, int grid,
+                        hipStream_t s);
+#define NIS_DECL_WM(W)                                                                                                      \
+  template <>                                                                                                               \
+  hipError_t launch_stats<W>(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s);    \
+  template <>                                                                                                               \
+  hipError_t launch_apply<W>(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz, \
+                             int grid, hipStream_t s);
 NIS_DECL_WM(4)
 NIS_DECL_WM(8)
 NIS_DECL_WM(16)

@@ -4,11 +4,12 @@
 #include <stdint.h>
 #include "../../include/nis_hip.h"
 
-#define NIS_TPB 256          // threads per workgroup for the streaming kernels (4 waves)
+#define NIS_TPB 256          // threads per workgroup of the apply / streaming kernels (4 waves)
 #define NIS_WAVE 64
-#define NIS_MAXB 512         // max workgroups of a statistics/apply launch (= max partial records)
+#define NIS_MAXB 2048        // max workgroups of any launch that emits partial records
 #define NIS_BN_EPS 1e-5      // torch.nn.BatchNorm1d default eps
 #define NIS_BN_MOM 0.1       // torch.nn.BatchNorm1d default momentum
+#define NIS_PMAX_FUSED 8     // max pass-through size whose BN_0 statistics ride along in ingest / apply
 
 // Uniform, read-only data (weights, coefficients written by an EARLIER launch) is read through the
 // constant address space so that hipcc emits s_load_* into SGPRs and v_fma_f64 takes the weight as
@@ -47,6 +48,18 @@ __device__ __forceinline__ double wave_first(double v) { return __shfl(v, 0, 64)
 
 static inline int nis_pick_wm(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 16 ? 16 : m <= 32 ? 32 : m <= 64 ? 64 : -1; }
 static inline int nis_pick_km(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : -1; }
+// workgroup size of the statistics kernel: as many waves as the register budget of width WM allows
+__host__ __device__ constexpr int nis_stats_tpb(int wm) { return wm <= 8 ? 1024 : wm <= 16 ? 512 : 256; }
+
+// Built-in integrand evaluated inside the last apply kernel (f(X)*J never leaves the chip).
+struct FuseF {
+  int kind;               // -1: none, else NIS_F_*
+  int loc0, loc1;         // local columns holding logical output columns 0 and 1 (camel)
+  int write_planes;       // 0: the transformed columns / Jacobian are not stored (nobody reads them)
+  double p[4];
+  double* partials;       // nblocks x 4 moment records
+  double* fres;           // optional per-sample f*J
+};
 
 // Per-launch view of one coupling cell (passed by value in the kernarg segment: every field is
 // wave-uniform, so plane indices / sizes live in SGPRs).
@@ -56,16 +69,21 @@ struct CellK {
   int in_plane[NIS_MAX_DIM];             // local column j -> state plane
   int jplane;                            // plane of the running Jacobian
   int first;                             // 1: J_in == 1 (AddJacobian), the J plane is not read
-  int nparts;                            // partial records written by the producing statistics launch
+  int nparts[NIS_MAX_HIDDEN + 1];        // records written for BN layer l by its producing launch
   int maxb;                              // stride (in records) between layers in `partials`
   int bins_row;                          // first row of this cell in bins_out
+  int next_P;                            // >0: also emit BN_0 records of the NEXT cell ...
+  int next_src[NIS_PMAX_FUSED];          // ... whose pass-through feature f is this cell's local column next_src[f]
   const double* wp;                      // padded hidden weights: L x WM x WM      (packed by k_pack)
   const double* wlast;                   // padded last layer:    R x WM
   const double* bias;                    // R
   const double* gb;                      // (L+1) x 2 x WM  gamma | beta, zero padded
   double* coef;                          // (L+1) x 2 x WM  scale | shift  (finalised BN affine form)
   double* partials;                      // (L+1) x maxb x WM x 3
+  double* next_partials;                 // BN_0 records of the next cell (maxb x WMnext x 3), stride next_wm
+  int next_wm;
   double* running;                       // reference-order running-stat blob (updated in train mode)
+  long long* tracked;                    // num_batches_tracked of the L+1 BN layers (incremented in train mode)
   int* status;                           // device error word (bit0: PWLin bin index out of range)
 };
 
@@ -87,3 +105,32 @@ struct NisProfScope {
   NisProfScope(int c, hipStream_t st) : cls(c), s(st) { nis_prof_mark(cls, 1, s); }
   ~NisProfScope() { nis_prof_mark(cls, 0, s); }
 };
+
+// ---- block-level accumulation of (count, mean, M2[, max]) with a wave-uniform shift --------------------
+// Every lane adds t = v - shift, t^2 (shift = the wave's first value, so |t| ~ sigma and the final
+// S2 - S1^2/n loses nothing); waves are then merged with Chan's update.
+template <int NW>
+__device__ __forceinline__ void block_record(double shift, double S1, double S2, double cnt, double vmax, double (*wm)[4], double* part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double nw = wave_sum(cnt), s1 = wave_sum(S1), s2 = wave_sum(S2), mx = wave_max(vmax);
+  if (lane == 0) {
+    wm[wave][0] = nw;
+    wm[wave][1] = nw > 0.0 ? shift + s1 / nw : 0.0;
+    wm[wave][2] = nw > 0.0 ? fmax(s2 - s1 * s1 / nw, 0.0) : 0.0;
+    wm[wave][3] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Mom t = {0.0, 0.0, 0.0};
+    double m = -__builtin_huge_val();
+    for (int w = 0; w < NW; ++w) {
+      Mom q = {wm[w][0], wm[w][1], wm[w][2]};
+      t = mom_merge(t, q);
+      m = fmax(m, wm[w][3]);
+    }
+    part[0] = t.n;
+    part[1] = t.mean;
+    part[2] = t.m2;
+    part[3] = m;
+  }
+}

@@ -97,7 +97,9 @@ def cell_desc(cell, in_col):
 
 
 class FlowEngine:
-    """One `nis_flow` handle for an ordered list of (cell, in_col) + the final column map."""
+    """One `nis_flow` handle for an ordered list of (cell, in_col) + the final column map.  Owns the
+    persistent device workspace (zero-padded parameter image, BN coefficients, partial records): its size
+    does not depend on the batch, and keeping it lets libnis_hip skip re-packing unchanged parameters."""
 
     def __init__(self, cells, in_cols, out_col, d):
         self.L = _lib.lib()
@@ -113,43 +115,91 @@ class FlowEngine:
         self._descs = arr
         self.n_bins_rows = sum(c.transform_size for c in self.cells)
         self._finalizer = weakref.finalize(self, self.L.nis_flow_destroy, h)
+        self._ws = None
+        self._sig = None
+        self._token = 0
+        self._stats_epoch = 0
 
-    def forward(self, w, has_jac, train, want_xj=True, want_bins=False):
-        """w: (N,d) or (N,d+1) CUDA tensor (float32/float64).  Returns dict(planes, xj, bins, status)."""
+    # ---- per-call plumbing
+    def _pointers(self, dev):
+        n = len(self.cells)
+        pp, rp, tp = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+        for i, c in enumerate(self.cells):
+            ensure_flat(c, dev)
+            pp[i], rp[i], tp[i] = c._flat.data_ptr(), c._running.data_ptr(), c._tracked.data_ptr()
+        return pp, rp, tp
+
+    def _workspace(self, dev):
+        wsb = self.L.nis_flow_workspace_bytes(self.handle, 1)
+        if self._ws is None or self._ws.device != dev or self._ws.numel() < wsb:
+            self._ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            self._sig = None
+        return self._ws, wsb
+
+    def pack_token(self):
+        """Changes whenever a parameter / BN buffer was modified (torch version counters) or a train-mode
+        forward of ours advanced the running statistics: libnis_hip then re-packs its parameter image."""
+        sig = (self._stats_epoch,) + tuple(t._version for c in self.cells for t in c.state_dict(keep_vars=True).values())
+        if sig != self._sig:
+            self._sig = sig
+            self._token += 1
+        return self._token
+
+    def _check_input(self, w, cols, train):
         _lib.require_gpu()
         if not w.is_cuda:
             raise _lib.NisError("nf_amd kernels need the sample batch on the GPU (no CPU fallback)")
         if w.dtype not in (torch.float32, torch.float64):
             w = w.to(torch.double)
         w = w.contiguous()
-        N = w.shape[0]
-        cols = self.d + (1 if has_jac else 0)
         if w.dim() != 2 or w.shape[1] != cols:
             raise ValueError(f"expected input of shape (N,{cols}), got {tuple(w.shape)}")
-        if train and N < 2:
+        if train and w.shape[0] < 2:
             raise ValueError("Expected more than 1 value per channel when training")   # torch BatchNorm1d error
-        dev = w.device
-        n = len(self.cells)
-        pp = (C.c_void_p * n)()
-        rp = (C.c_void_p * n)()
-        for i, c in enumerate(self.cells):
-            ensure_flat(c, dev)
-            pp[i] = c._flat.data_ptr()
-            rp[i] = c._running.data_ptr()
-        wsb = self.L.nis_flow_workspace_bytes(self.handle, N)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        return w
+
+    def forward(self, w, has_jac, train, want_xj=True, want_bins=False, token=None):
+        """w: (N,d) or (N,d+1) CUDA tensor (float32/float64).  Returns dict(planes, xj, bins, status)."""
+        w = self._check_input(w, self.d + (1 if has_jac else 0), train)
+        N, dev = w.shape[0], w.device
+        pp, rp, tp = self._pointers(dev)
+        ws, wsb = self._workspace(dev)
+        if token is None:
+            token = self.pack_token()
         planes = torch.empty((self.d + 1, N), dtype=torch.double, device=dev)
         xj = torch.empty((N, self.d + 1), dtype=torch.double, device=dev) if want_xj else None
         bins = torch.empty((self.n_bins_rows, N), dtype=torch.int32, device=dev) if want_bins else None
         rc = self.L.nis_flow_forward(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
-                                     1 if has_jac else 0, N, pp, rp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL,
-                                     planes.data_ptr(), N, xj.data_ptr() if want_xj else None,
+                                     1 if has_jac else 0, N, pp, rp, tp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL,
+                                     token, planes.data_ptr(), N, xj.data_ptr() if want_xj else None,
                                      bins.data_ptr() if want_bins else None, ws.data_ptr(), wsb, _lib.stream_ptr())
         _lib.check(rc, "nis_flow_forward")
         if train:
-            for c in self.cells:           # BatchNorm1d.num_batches_tracked += 1 (one add per cell)
-                c._tracked.add_(1)
+            self._stats_epoch += 1
         return dict(planes=planes, xj=xj, bins=bins, status=ws[:4].view(torch.int32), ws=ws)
+
+    def integrate_step(self, w, train, f_kind, f_params, out4, planes=None, token=None, want_fres=False):
+        """One integrate() iteration in ONE library call: flow forward + built-in integrand + moments -> out4
+        (a 4-element float64 device tensor/view).  X and J are not stored unless `planes` is wanted back."""
+        w = self._check_input(w, self.d, train)
+        N, dev = w.shape[0], w.device
+        pp, rp, tp = self._pointers(dev)
+        ws, wsb = self._workspace(dev)
+        if token is None:
+            token = self.pack_token()
+        keep = planes is not None
+        if planes is None:
+            planes = torch.empty((self.d + 1, N), dtype=torch.double, device=dev)
+        fres = torch.empty(N, dtype=torch.double, device=dev) if want_fres else None
+        fp = (C.c_double * 4)(*(list(f_params) + [0.0] * 4)[:4])
+        rc = self.L.nis_integrate_step(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
+                                       N, pp, rp, tp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL, token, f_kind, fp,
+                                       planes.data_ptr(), N, 1 if keep else 0, fres.data_ptr() if want_fres else None,
+                                       out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr())
+        _lib.check(rc, "nis_integrate_step")
+        if train:
+            self._stats_epoch += 1
+        return fres
 
 
 def moments_of(planes, d, out_col, f_kind, f_params, want_fres=False):

@@ -321,17 +321,15 @@ class BasicManager(ModelAPI):
         model.to(dev)
         out = torch.empty((nitn, 4), dtype=torch.double, device=dev)
         fused = hasattr(f, "nis_kind") and isinstance(model, FlowSequential)
+        eng = model.engine() if fused else None
         for i in range(nitn):
             w = self._uniform(neval, dev, torch.float32, "integrate")
-            if fused:
-                res = model.flow_forward(w)
-                eng = model.engine()
-                out4, _ = moments_of(res["planes"], eng.d, eng.out_col, f.nis_kind, f.nis_params)
+            if fused:                       # one library call per iteration, X / J never stored
+                eng.integrate_step(w, model.training, f.nis_kind, f.nis_params, out[i])
             else:
                 with torch.no_grad():
                     XJ = model(self.format_input(w, dev)).detach()
-                    out4 = hip_moments(f(XJ[:, :-1]), XJ[:, -1])
-            out[i] = out4
+                    out[i] = hip_moments(f(XJ[:, :-1]), XJ[:, -1])
         return out
 
 
