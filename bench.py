@@ -72,25 +72,31 @@ def bench_flow(args, rank, ws, dev):
     eng = model.engine()
     f = integrands.Camel()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    total = args.steps + args.warmup
-    ws_draws = [torch.rand(BATCH, 2, dtype=torch.float32, device=dev, generator=g) for _ in range(total)]
+    G = max(1, min(args.group, args.steps))
+    # resident inputs: one (G, BATCH, 2) float32 block per launch group (integrate() draws float32, manager.py:390)
+    n_groups = (args.steps + G - 1) // G
+    sizes = [min(G, args.steps - k * G) for k in range(n_groups)]
+    draws = [torch.rand(sz, BATCH, 2, dtype=torch.float32, device=dev, generator=g) for sz in sizes]
+    warm = torch.rand(G, BATCH, 2, dtype=torch.float32, device=dev, generator=g)
     out = torch.zeros((args.steps, 4), dtype=torch.double, device=dev)
-
-    scratch = torch.zeros(4, dtype=torch.double, device=dev)
+    scratch = torch.zeros((G, 4), dtype=torch.double, device=dev)
     token = eng.pack_token()            # parameters do not change inside integrate(): pack the image once
 
-    def step(i, slot):
-        # ONE library call: ingest(+BN_0 stats) -> [BN stats x3 -> cell apply] x2 with camel*J + moments fused
-        eng.integrate_step(ws_draws[i], True, f.nis_kind, f.nis_params, out[slot] if slot >= 0 else scratch, token=token)
+    def run_group(wblock, dst):
+        # ONE library call = len(wblock) steps: ingest(+BN_0 stats) -> [BN stats x3 -> cell apply] x2 with
+        # camel*J + moments fused into the last apply; the steps are the y dimension of every launch.
+        eng.integrate_steps(wblock, True, f.nis_kind, f.nis_params, dst, token=token)
 
-    for i in range(args.warmup):
-        step(i, -1)
+    for _ in range(max(1, (args.warmup + G - 1) // G)):
+        run_group(warm, scratch)
     L = _lib.lib()
     _lib.check(L.nis_prof_enable(K_CLASS[args.roofline_kernel], 4 * args.steps * 8), "nis_prof_enable")
     barrier_sync(ws)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, i)
+    done = 0
+    for k, wblock in enumerate(draws):
+        run_group(wblock, out[done:done + sizes[k]])
+        done += sizes[k]
     merged = allreduce_moments(out)                     # the single collective of the job
     barrier_sync(ws)
     dt = time.perf_counter() - t0
@@ -105,10 +111,13 @@ def bench_flow(args, rank, ws, dev):
     # pass-through, transformed and Jacobian columns and writes the transformed + Jacobian columns:
     # 8*((d+1) + (T+1)) B/sample; the first cell does not read J (it is 1): 8*(d + T+1).
     d, T = 2, 1
-    per_launch = {"apply": BATCH * 8 * ((d + 1) + (T + 1) - 0.5),      # mean of cell 0 (32 B) and cell 1 (40 B)
-                  "stats": BATCH * 8 * 1,                               # reads the P = 1 pass-through column
-                  "ingest": BATCH * (4 * d + 8 * d),
-                  "integrand": BATCH * 8 * (d + 1)}[args.roofline_kernel]
+    # One launch covers G steps.  Cell 0 reads xA, xB (J_in = 1) and writes yB, J: 32 B/sample; the last cell
+    # reads xA, xB, J and (integrand fused, X/J not stored) writes nothing: 24 B/sample -> mean 28 B.
+    gmean = args.steps / len(draws)
+    per_launch = {"apply": gmean * BATCH * 28.0,
+                  "stats": gmean * BATCH * 8 * 1,                       # reads the P = 1 pass-through column
+                  "ingest": gmean * BATCH * (4 * d + 8 * d),
+                  "integrand": gmean * BATCH * 8 * (d + 1)}[args.roofline_kernel]
     roof = None
     if kern_n > 0:
         avg_s = kern_ms / kern_n / 1e3
@@ -117,7 +126,8 @@ def bench_flow(args, rank, ws, dev):
                            "integrand": "k_integrand_moments"}[args.roofline_kernel],
                 "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                "avg_launch_us": round(avg_s * 1e6, 2), "launches": kern_n, "algorithmic_bytes_per_launch": per_launch}
+                "avg_launch_us": round(avg_s * 1e6, 2), "launches": kern_n, "steps_per_launch": gmean,
+                "algorithmic_bytes_per_launch": per_launch}
     return dict(dt=dt, samples=BATCH * args.steps * ws, sig=sig, sig_err=sig_err, roofline=roof, NF=NF)
 
 
@@ -182,6 +192,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--roofline-kernel", default="apply", choices=["apply", "stats", "ingest", "integrand"])
+    ap.add_argument("--group", type=int, default=10, help="steps fused into one launch set (independent BN batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     rank, ws, local = init_from_env("nccl")

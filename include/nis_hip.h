@@ -90,8 +90,8 @@ int nis_flow_create(const nis_cell_desc* cells, int32_t n_cells, int32_t d, cons
                     nis_flow** out);
 void nis_flow_destroy(nis_flow* f);
 
-/* Bytes of device workspace nis_flow_forward needs for a batch of N samples. */
-size_t nis_flow_workspace_bytes(const nis_flow* f, int64_t N);
+/* Bytes of device workspace for n_batches batched iterations (1 for nis_flow_forward); independent of N. */
+size_t nis_flow_workspace_bytes(const nis_flow* f, int64_t n_batches);
 
 /* Forward pass of the whole model on N samples: AddJacobian (layers.py:75-77) + every cell.
  *   w        (N,d) row-major, dtype w_dtype (integrate() draws float32, manager.py:390); with
@@ -116,15 +116,18 @@ int nis_flow_forward(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_
                      double* planes, int64_t ld, double* xj_out, int32_t* bins_out,
                      void* workspace, size_t workspace_bytes, void* stream);
 
-/* One iteration of BasicManager.integrate (manager.py:395-400) in a single call: model forward on the
- * batch w, built-in integrand f(X)*J evaluated inside the last cell's kernel, moments
- * out4 = {count, mean, M2, max}.  keep_planes == 0: X and J are never written (nothing reads them);
- * fres_out (N) optional. */
-int nis_integrate_step(nis_flow* f, const void* w, int32_t w_dtype, int64_t N,
-                       const double* const* params, double* const* running, long long* const* tracked,
-                       int32_t bn_mode, int64_t pack_token, int32_t f_kind, const double* f_params_host,
-                       double* planes, int64_t ld, int32_t keep_planes, double* fres_out, double* out4,
-                       void* workspace, size_t workspace_bytes, void* stream);
+/* n_batches iterations of BasicManager.integrate's loop body (manager.py:395-400) in ONE call: the
+ * iterations are independent given fixed parameters (each is its own train-mode BatchNorm batch), so they
+ * run as the y dimension of every launch and the per-launch latency is paid once for all of them.
+ *   w     (n_batches, N, d) row-major;  planes (n_batches, d+1, ld);  out4 (n_batches, 4) = {count, mean, M2, max}
+ * The built-in integrand f(X)*J is evaluated inside the last cell's kernel.  keep_planes == 0: X and J are
+ * never written (nothing reads them); fres_out (n_batches, N) optional.  Running statistics receive the
+ * n_batches momentum updates in batch order.  Workspace: nis_flow_workspace_bytes(f, n_batches). */
+int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_batches, int64_t N,
+                        const double* const* params, double* const* running, long long* const* tracked,
+                        int32_t bn_mode, int64_t pack_token, int32_t f_kind, const double* f_params_host,
+                        double* planes, int64_t ld, int32_t keep_planes, double* fres_out, double* out4,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* f(X)*J for a built-in integrand straight from the planes + streaming moments of the result:
  * out4 = {count, mean, M2 = sum (v-mean)^2, max}   (torch.mean/var/max at manager.py:399-400,

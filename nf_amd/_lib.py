@@ -25,7 +25,7 @@ ERRORS = {-1: "invalid argument", -2: "configuration outside the compiled kernel
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnis_hip.so")
 
 EXPORTS = ["nis_cell_param_count", "nis_cell_running_count", "nis_flow_create", "nis_flow_destroy",
-           "nis_flow_workspace_bytes", "nis_flow_forward", "nis_integrate_step", "nis_integrand_moments", "nis_moments_workspace_bytes",
+           "nis_flow_workspace_bytes", "nis_flow_forward", "nis_integrate_steps", "nis_integrand_moments", "nis_moments_workspace_bytes",
            "nis_moments", "nis_rambo_forward", "nis_prof_enable", "nis_prof_read", "nis_prof_disable", "nis_last_error", "nis_version", "nis_device_count"]
 
 
@@ -71,9 +71,9 @@ def lib():
     L.nis_flow_forward.restype = i32
     L.nis_flow_forward.argtypes = [vp, vp, i32, i32, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, vp, i64, vp, vp,
                                    vp, sz, vp]
-    L.nis_integrate_step.restype = i32
-    L.nis_integrate_step.argtypes = [vp, vp, i32, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, i32,
-                                     C.POINTER(C.c_double), vp, i64, i32, vp, vp, vp, sz, vp]
+    L.nis_integrate_steps.restype = i32
+    L.nis_integrate_steps.argtypes = [vp, vp, i32, i32, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, i32,
+                                      C.POINTER(C.c_double), vp, i64, i32, vp, vp, vp, sz, vp]
     L.nis_integrand_moments.restype = i32
     L.nis_integrand_moments.argtypes = [vp, i64, i64, i32, C.POINTER(i32), i32, C.POINTER(C.c_double), vp, vp, vp, sz, vp]
     L.nis_moments_workspace_bytes.restype = sz

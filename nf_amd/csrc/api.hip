@@ -3,6 +3,7 @@
 // built-in integrands and the moment reductions.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -105,26 +106,51 @@ extern "C" size_t nis_cell_running_count(const nis_cell_desc* c) {
 
 struct CellLayout {
   int WM, KM;
-  size_t off_wp, off_wlast, off_bias, off_gb, off_coef, off_part;   // in doubles from the workspace body
+  size_t off_wp, off_wlast, off_bias, off_gb, off_coef, off_part, off_gstat;   // in doubles from the workspace body
 };
 
 struct nis_flow {
   int d, n_cells;
   std::vector<nis_cell_desc> cells;
-  std::vector<CellLayout> lay;
   std::vector<int> bins_row;
   int out_col[NIS_MAX_DIM];
-  size_t body_doubles;
-  size_t off_fpart;                 // moment records of the fused integrand (NIS_MAXB x 4)
   // packing cache: the padded parameter image in the workspace stays valid while the caller's token,
-  // BN mode, workspace and parameter pointers are unchanged
+  // BN mode, workspace, batch count and parameter pointers are unchanged
   int64_t packed_token = 0;
   int packed_mode = -1;
+  int packed_G = 0;
   const void* packed_ws = nullptr;
   std::vector<const double*> packed_params;
 };
 
 static const size_t WS_HEADER = 256;   // bytes: status word + padding
+
+// Workspace body for G batched iterations: per cell the zero-padded parameter image (shared by all batches),
+// then per-batch BN coefficients, partial records and batch statistics; finally the integrand's moment records.
+static size_t flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay, size_t* off_fpart) {
+  size_t off = 0;
+  for (int i = 0; i < f->n_cells; ++i) {
+    const nis_cell_desc& c = f->cells[i];
+    int m = c.P;
+    for (int l = 0; l < c.n_hidden; ++l) m = std::max(m, c.width[l]);
+    CellLayout L;
+    L.WM = nis_pick_wm(m);
+    L.KM = c.kind == NIS_PWQUAD ? nis_pick_km(c.K) : 4;
+    if (c.kind == NIS_PWQUAD && L.KM == c.K) L.KM = -L.KM;        // K == KM: guard-free specialisation
+    const size_t WM = L.WM, R = cell_R(c), nl = c.n_hidden;
+    L.off_wp = off;      off += nl * WM * WM;
+    L.off_wlast = off;   off += R * WM;
+    L.off_bias = off;    off += (R + 7) / 8 * 8;
+    L.off_gb = off;      off += (nl + 1) * 2 * WM;
+    L.off_coef = off;    off += (size_t)G * (nl + 1) * 2 * WM;
+    L.off_gstat = off;   off += (size_t)G * (nl + 1) * 2 * WM;
+    L.off_part = off;    off += (nl + 1) * (size_t)G * NIS_MAXB * WM * 3;
+    if (lay) lay->push_back(L);
+  }
+  if (off_fpart) *off_fpart = off;
+  off += (size_t)G * NIS_MAXB * 4;
+  return off;
+}
 
 static int validate_cell(const nis_cell_desc& c, int d) {
   if (c.kind != NIS_PWLIN && c.kind != NIS_PWQUAD) return NIS_E_ARG;
@@ -148,34 +174,17 @@ extern "C" int nis_flow_create(const nis_cell_desc* cells, int32_t n_cells, int3
   nis_flow* f = new nis_flow();
   f->d = d;
   f->n_cells = n_cells;
-  size_t off = 0;
   int brow = 0;
   for (int i = 0; i < n_cells; ++i) {
-    const nis_cell_desc& c = cells[i];
-    int rc = validate_cell(c, d);
+    int rc = validate_cell(cells[i], d);
     if (rc != NIS_OK) {
       delete f;
       return rc;
     }
-    int m = c.P;
-    for (int l = 0; l < c.n_hidden; ++l) m = std::max(m, c.width[l]);
-    CellLayout L;
-    L.WM = nis_pick_wm(m);
-    L.KM = c.kind == NIS_PWQUAD ? nis_pick_km(c.K) : 4;
-    const size_t WM = L.WM, R = cell_R(c), nl = c.n_hidden;
-    L.off_wp = off;      off += nl * WM * WM;
-    L.off_wlast = off;   off += R * WM;
-    L.off_bias = off;    off += (R + 7) / 8 * 8;
-    L.off_gb = off;      off += (nl + 1) * 2 * WM;
-    L.off_coef = off;    off += (nl + 1) * 2 * WM;
-    L.off_part = off;    off += (nl + 1) * (size_t)NIS_MAXB * WM * 3;
-    f->cells.push_back(c);
-    f->lay.push_back(L);
+    f->cells.push_back(cells[i]);
     f->bins_row.push_back(brow);
-    brow += cell_T(c);
+    brow += cell_T(cells[i]);
   }
-  f->off_fpart = off;
-  off += (size_t)NIS_MAXB * 4;
   for (int j = 0; j < d; ++j) {
     if (out_col[j] < 0 || out_col[j] >= d) {
       delete f;
@@ -183,7 +192,6 @@ extern "C" int nis_flow_create(const nis_cell_desc* cells, int32_t n_cells, int3
     }
     f->out_col[j] = out_col[j];
   }
-  f->body_doubles = off;
   f->packed_params.assign(n_cells, nullptr);
   *out = f;
   return NIS_OK;
@@ -191,7 +199,10 @@ extern "C" int nis_flow_create(const nis_cell_desc* cells, int32_t n_cells, int3
 
 extern "C" void nis_flow_destroy(nis_flow* f) { delete f; }
 
-extern "C" size_t nis_flow_workspace_bytes(const nis_flow* f, int64_t) { return WS_HEADER + f->body_doubles * sizeof(double); }
+extern "C" size_t nis_flow_workspace_bytes(const nis_flow* f, int64_t n_batches) {
+  const int G = (int)std::max<int64_t>(1, n_batches);
+  return WS_HEADER + flow_layout(f, G, nullptr, nullptr) * sizeof(double);
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_pack: reference-order parameter blob -> zero-padded WM-strided weights (+ eval-mode BN affine).
@@ -250,8 +261,10 @@ struct IngestStats {
   int P;                           // 0: no statistics
   int sel[NIS_PMAX_FUSED];         // input column of pass-through feature p of the first cell
   int wm;                          // record stride of that cell
-  double* partials;                // its BN_0 records (one per workgroup)
+  double* partials;                // its BN_0 records (one per workgroup and batch)
   int* status;                     // zeroed here (first launch of a forward)
+  int maxb;                        // record stride between batches
+  long plane_gs;                   // doubles between the plane sets of consecutive batches
 };
 
 template <typename TIN>
@@ -262,7 +275,10 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest(const TIN* __restrict__ w, l
   __shared__ double wshift[NW][NF];
   __shared__ double wmom[NW][NF][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && st.status) *st.status = 0;
+  const int g = blockIdx.y;
+  w += (size_t)g * N * d;
+  planes += (size_t)g * st.plane_gs;
+  if (blockIdx.x == 0 && g == 0 && threadIdx.x == 0 && st.status) *st.status = 0;
   double S1[NF], S2[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) S1[f] = S2[f] = 0.0;
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest(const TIN* __restrict__ w, l
     }
     __syncthreads();
   }
-  if (st.P > 0) emit_records<NF, NW>(S1, S2, cnt, wshift, wmom, st.P, st.partials + (size_t)blockIdx.x * st.wm * 3);
+  if (st.P > 0) emit_records<NF, NW>(S1, S2, cnt, wshift, wmom, st.P, st.partials + ((size_t)g * st.maxb + blockIdx.x) * st.wm * 3);
 }
 
 __global__ __launch_bounds__(NIS_TPB) void k_emit(const double* __restrict__ planes, long ld, long N, int d, ColMap m,
@@ -432,8 +448,11 @@ __global__ __launch_bounds__(NIS_TPB) void k_moments(const double* __restrict__ 
 }
 
 // one workgroup: merge the per-workgroup records in a fixed order -> out4 = {n, mean, M2, max}
-__global__ __launch_bounds__(NIS_TPB) void k_moments_final(const double* __restrict__ partials, int nparts, double* __restrict__ out4) {
+__global__ __launch_bounds__(NIS_TPB) void k_moments_final(const double* __restrict__ partials, int nparts, double* __restrict__ out4,
+                                                           int maxb) {
   __shared__ double sm[NIS_TPB][4];
+  partials += (size_t)blockIdx.x * maxb * 4;
+  out4 += (size_t)blockIdx.x * 4;
   Mom t = {0.0, 0.0, 0.0};
   double m = -__builtin_huge_val();
   for (int b = threadIdx.x; b < nparts; b += NIS_TPB) {
@@ -478,7 +497,7 @@ extern "C" int nis_moments(const double* a, const double* b, int64_t N, double* 
   const int grid = stream_grid(N);
   hipLaunchKernelGGL(k_moments, dim3(grid), dim3(NIS_TPB), 0, s, a, b, (long)N, (double*)workspace);
   HIP_OK(hipGetLastError());
-  hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(NIS_TPB), 0, s, (const double*)workspace, grid, out4);
+  hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(NIS_TPB), 0, s, (const double*)workspace, grid, out4, 0);
   HIP_OK(hipGetLastError());
   return NIS_OK;
 }
@@ -504,13 +523,47 @@ extern "C" int nis_integrand_moments(const double* planes, int64_t ld, int64_t N
                        (double*)workspace);
   }
   HIP_OK(hipGetLastError());
-  hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(NIS_TPB), 0, s, (const double*)workspace, grid, out4);
+  hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(NIS_TPB), 0, s, (const double*)workspace, grid, out4, 0);
   HIP_OK(hipGetLastError());
   return NIS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
+static int device_cus() {
+  static int n = -1;
+  if (n < 0) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+    n = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+// x extent of a launch over G batches: one resident wave of workgroups (blocks_per_cu * CUs) shared by the
+// batches, never more workgroups than the batch has chunks of `tpb` samples, never more than NIS_MAXB records.
+static int grid_for(int blocks_per_cu, int G, int64_t N, int tpb) {
+  const int64_t resident = (int64_t)blocks_per_cu * device_cus();
+  int64_t gx = (resident + G - 1) / G;
+  gx = std::min<int64_t>(gx, (N + tpb - 1) / tpb);
+  gx = std::min<int64_t>(gx, NIS_MAXB);
+  return (int)std::max<int64_t>(1, gx);
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+template <int WM>
+static void cell_grids(int kind, int km, int G, int64_t N, int* gs, int* ga) {
+  static const int bs = env_int("NIS_STATS_BPC", 0), ba = env_int("NIS_APPLY_BPC", 0);   // tuning overrides
+  *gs = grid_for(bs > 0 ? bs : stats_blocks_per_cu<WM>(), G, N, nis_stats_tpb(WM));
+  *ga = grid_for(ba > 0 ? ba : apply_blocks_per_cu<WM>(kind, km), G, N, NIS_TPB);
+}
+
 struct RunOpts {
+  int G = 1;                       // batched iterations (w: (G,N,d), planes: (G,d+1,ld), out4: (G,4))
   int w_has_jac = 0;
   int bn_mode = NIS_BN_TRAIN;
   int64_t pack_token = 0;          // 0: always repack
@@ -527,13 +580,25 @@ struct RunOpts {
 template <int WM>
 static int run_cell(const CellK& c, double* planes, long ld, long N, int bn_mode, int km, int* bins, const FuseF& fz, bool need_stats0,
                     int grid_stats, int grid_apply, hipStream_t s) {
-  if (bn_mode == NIS_BN_TRAIN)
-    for (int l = need_stats0 ? 0 : 1; l <= c.L; ++l) {
+  if (bn_mode == NIS_BN_TRAIN) {
+    if (need_stats0) {
       NisProfScope ps(NIS_K_STATS, s);
-      HIP_OK(launch_stats<WM>(c, planes, ld, N, l, grid_stats, s));
+      HIP_OK(launch_stats<WM>(c, planes, ld, N, 0, grid_stats, s));
     }
-  NisProfScope ps(NIS_K_APPLY, s);
-  HIP_OK(launch_apply<WM>(c, planes, ld, N, bn_mode == NIS_BN_TRAIN ? 1 : 0, km, bins, fz, grid_apply, s));
+    if (c.G > 1) HIP_OK(launch_finalize<WM>(c, 0, s));
+    for (int l = 1; l <= c.L; ++l) {
+      {
+        NisProfScope ps(NIS_K_STATS, s);
+        HIP_OK(launch_stats<WM>(c, planes, ld, N, l, grid_stats, s));
+      }
+      if (c.G > 1) HIP_OK(launch_finalize<WM>(c, l, s));
+    }
+  }
+  {
+    NisProfScope ps(NIS_K_APPLY, s);
+    HIP_OK(launch_apply<WM>(c, planes, ld, N, bn_mode == NIS_BN_TRAIN ? 1 : 0, km, bins, fz, grid_apply, s));
+  }
+  if (bn_mode == NIS_BN_TRAIN && c.G > 1) HIP_OK(launch_running_update<WM>(c, s));
   return NIS_OK;
 }
 
@@ -542,19 +607,25 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   if (!f || !w || !params || !running || !planes || N < 1 || ld < N) return NIS_E_ARG;
   if (o.bn_mode != NIS_BN_EVAL && o.bn_mode != NIS_BN_TRAIN) return NIS_E_ARG;
   if (w_dtype != NIS_F64 && w_dtype != NIS_F32) return NIS_E_ARG;
-  if (!workspace || workspace_bytes < nis_flow_workspace_bytes(f, N)) return NIS_E_WORKSPACE;
+  const int G = o.G;
+  if (G < 1 || G > 65535) return NIS_E_ARG;
+  if (G > 1 && (o.xj_out || o.bins_out || o.w_has_jac)) return NIS_E_UNSUPPORTED;
+  if (!workspace || workspace_bytes < nis_flow_workspace_bytes(f, G)) return NIS_E_WORKSPACE;
+  std::vector<CellLayout> lay;
+  size_t off_fpart = 0;
+  flow_layout(f, G, &lay, &off_fpart);
   int* status = (int*)workspace;
   double* body = (double*)((char*)workspace + WS_HEADER);
   const int d = f->d;
   const bool train = o.bn_mode == NIS_BN_TRAIN;
-  const int nblk = (int)std::min<int64_t>(NIS_MAXB, (N + NIS_TPB - 1) / NIS_TPB);
-  const int grid_apply = std::max(1, nblk);
-  const int tgrid = std::max(1, nblk);
+  const int tgrid = grid_for(8, G, N, NIS_TPB);          // ingest / emit: 256-thread streaming workgroups
   const size_t tile_bytes = ((size_t)NIS_TPB * (d + 1) + 16) * sizeof(double);
   const int wcols = o.w_has_jac ? d + 1 : d;
+  const long plane_gs = (long)(d + 1) * ld;
 
   // is the padded parameter image in this workspace still valid?
-  bool repack = o.pack_token == 0 || o.pack_token != f->packed_token || o.bn_mode != f->packed_mode || workspace != f->packed_ws;
+  bool repack = o.pack_token == 0 || o.pack_token != f->packed_token || o.bn_mode != f->packed_mode || workspace != f->packed_ws ||
+                G != f->packed_G;
   for (int ci = 0; ci < f->n_cells && !repack; ++ci) repack = params[ci] != f->packed_params[ci];
 
   // ---- ingest (+ BN_0 records of the first cell)
@@ -562,18 +633,22 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   IngestStats ist;
   memset(&ist, 0, sizeof(ist));
   ist.status = status;
+  ist.maxb = NIS_MAXB;
+  ist.plane_gs = plane_gs;
   const bool ingest_stats = train && c0.P <= NIS_PMAX_FUSED;
   if (ingest_stats) {
     ist.P = c0.P;
     for (int p = 0; p < c0.P; ++p) ist.sel[p] = c0.in_col[p];
-    ist.wm = f->lay[0].WM;
-    ist.partials = body + f->lay[0].off_part;
+    ist.wm = lay[0].WM;
+    ist.partials = body + lay[0].off_part;
   }
   nis_prof_mark(NIS_K_INGEST, 1, s);
   if (w_dtype == NIS_F64)
-    hipLaunchKernelGGL(k_ingest<double>, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const double*)w, (long)N, wcols, planes, (long)ld, ist);
+    hipLaunchKernelGGL(k_ingest<double>, dim3(tgrid, G), dim3(NIS_TPB), tile_bytes, s, (const double*)w, (long)N, wcols, planes, (long)ld,
+                       ist);
   else
-    hipLaunchKernelGGL(k_ingest<float>, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const float*)w, (long)N, wcols, planes, (long)ld, ist);
+    hipLaunchKernelGGL(k_ingest<float>, dim3(tgrid, G), dim3(NIS_TPB), tile_bytes, s, (const float*)w, (long)N, wcols, planes, (long)ld,
+                       ist);
   nis_prof_mark(NIS_K_INGEST, 0, s);
   HIP_OK(hipGetLastError());
 
@@ -581,10 +656,16 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   bool have_stats0 = ingest_stats;
   for (int ci = 0; ci < f->n_cells; ++ci) {
     const nis_cell_desc& cd = f->cells[ci];
-    const CellLayout& L = f->lay[ci];
+    const CellLayout& L = lay[ci];
     if (!params[ci] || !running[ci]) return NIS_E_ARG;
-    const int tpb_stats = nis_stats_tpb(L.WM);
-    const int grid_stats = (int)std::max<int64_t>(1, std::min<int64_t>(256, (N + tpb_stats - 1) / tpb_stats));
+    int grid_stats = 1, grid_apply = 1;
+    switch (L.WM) {
+      case 4: cell_grids<4>(cd.kind, L.KM, G, N, &grid_stats, &grid_apply); break;
+      case 8: cell_grids<8>(cd.kind, L.KM, G, N, &grid_stats, &grid_apply); break;
+      case 16: cell_grids<16>(cd.kind, L.KM, G, N, &grid_stats, &grid_apply); break;
+      case 32: cell_grids<32>(cd.kind, L.KM, G, N, &grid_stats, &grid_apply); break;
+      default: cell_grids<64>(cd.kind, L.KM, G, N, &grid_stats, &grid_apply); break;
+    }
     CellK c;
     memset(&c, 0, sizeof(c));
     c.kind = cd.kind;
@@ -609,12 +690,16 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     c.gb = body + L.off_gb;
     c.coef = body + L.off_coef;
     c.partials = body + L.off_part;
+    c.gstat = body + L.off_gstat;
     c.running = running[ci];
     c.tracked = (train && o.tracked) ? o.tracked[ci] : nullptr;
     c.status = status;
+    c.G = G;
+    c.coef_gs = train ? (cd.n_hidden + 1) * 2 * L.WM : 0;     // eval: every batch shares the running-stat coefficients
+    c.plane_gs = plane_gs;
     // rider 1: BN_0 records of the next cell (every state column is in this thread's registers)
     bool next_rider = false;
-    if (train && ci + 1 < f->n_cells && L.WM <= 8 && f->cells[ci + 1].P <= NIS_PMAX_FUSED) {
+    if (train && ci + 1 < f->n_cells && L.WM <= 8 && f->cells[ci + 1].P <= (L.WM <= 4 ? 4 : NIS_PMAX_FUSED)) {
       const nis_cell_desc& nx = f->cells[ci + 1];
       next_rider = true;
       c.next_P = nx.P;
@@ -625,14 +710,16 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
         c.next_src[p] = src;
       }
       for (int p = nx.P; p < NIS_PMAX_FUSED; ++p) c.next_src[p] = -1;
-      c.next_partials = body + f->lay[ci + 1].off_part;
-      c.next_wm = f->lay[ci + 1].WM;
+      c.next_partials = body + lay[ci + 1].off_part;
+      c.next_wm = lay[ci + 1].WM;
     }
     // rider 2: built-in integrand + moment records in the last cell
     FuseF fz;
     memset(&fz, 0, sizeof(fz));
     fz.kind = -1;
     fz.write_planes = 1;
+    fz.maxb = NIS_MAXB;
+    fz.fres_gs = N;
     const bool last = ci + 1 == f->n_cells;
     bool fused_f = false;
     if (last && o.f_kind >= 0 && L.WM <= 8) {
@@ -644,10 +731,12 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
         if (d > 1 && cd.in_col[j] == f->out_col[1]) fz.loc1 = j;
       }
       for (int k = 0; k < 4; ++k) fz.p[k] = o.f_params ? o.f_params[k] : 0.0;
-      fz.partials = body + f->off_fpart;
+      if (o.f_kind == NIS_F_CAMEL) fz.p[3] = 1.0 / (fz.p[2] * fz.p[2]);
+      fz.partials = body + off_fpart;
       fz.fres = o.fres_out;
       fz.write_planes = (o.keep_planes || o.xj_out) ? 1 : 0;
     }
+    if (last && o.f_kind >= 0 && !fused_f && G > 1) return NIS_E_UNSUPPORTED;
     if (repack) {
       const int pgrid = (int)std::min<size_t>(64, ((size_t)c.R * L.WM + NIS_TPB - 1) / NIS_TPB);
       NisProfScope ps(NIS_K_PACK, s);
@@ -671,10 +760,11 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     if (last && o.f_kind >= 0) {
       if (fused_f) {
         NisProfScope ps(NIS_K_MOMENTS, s);
-        hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(NIS_TPB), 0, s, (const double*)(body + f->off_fpart), grid_apply, o.out4);
+        hipLaunchKernelGGL(k_moments_final, dim3(G), dim3(NIS_TPB), 0, s, (const double*)(body + off_fpart), grid_apply, o.out4,
+                           NIS_MAXB);
         HIP_OK(hipGetLastError());
       } else {
-        int rc2 = nis_integrand_moments(planes, ld, N, d, f->out_col, o.f_kind, o.f_params, o.fres_out, o.out4, body + f->off_fpart,
+        int rc2 = nis_integrand_moments(planes, ld, N, d, f->out_col, o.f_kind, o.f_params, o.fres_out, o.out4, body + off_fpart,
                                         (size_t)NIS_MAXB * 4 * sizeof(double), (void*)s);
         if (rc2 != NIS_OK) return rc2;
       }
@@ -683,6 +773,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   f->packed_token = o.pack_token;
   f->packed_mode = o.bn_mode;
   f->packed_ws = workspace;
+  f->packed_G = G;
   for (int ci = 0; ci < f->n_cells; ++ci) f->packed_params[ci] = params[ci];
   if (o.xj_out) {
     ColMap m;
@@ -708,13 +799,15 @@ extern "C" int nis_flow_forward(nis_flow* f, const void* w, int32_t w_dtype, int
   return flow_run(f, w, w_dtype, N, params, running, planes, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
 }
 
-extern "C" int nis_integrate_step(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, const double* const* params,
-                                  double* const* running, long long* const* tracked, int32_t bn_mode, int64_t pack_token,
-                                  int32_t f_kind, const double* f_params_host, double* planes, int64_t ld, int32_t keep_planes,
-                                  double* fres_out, double* out4, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_batches, int64_t N,
+                                   const double* const* params, double* const* running, long long* const* tracked, int32_t bn_mode,
+                                   int64_t pack_token, int32_t f_kind, const double* f_params_host, double* planes, int64_t ld,
+                                   int32_t keep_planes, double* fres_out, double* out4, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
   if (!out4 || f_kind < 0) return NIS_E_ARG;
   if (f_kind == NIS_F_CAMEL && f && f->d < 2) return NIS_E_ARG;
   RunOpts o;
+  o.G = n_batches;
   o.bn_mode = bn_mode;
   o.pack_token = pack_token;
   o.tracked = tracked;

@@ -22,16 +22,17 @@
 // `red`: 3*TPB doubles.  Workgroup 0 publishes the fresh coefficients, applies the running-stat update
 // (momentum 0.1, unbiased variance) and bumps num_batches_tracked.
 template <int WM, int TPB>
-__device__ __forceinline__ void load_coefs(const CellK& c, int upto, int fresh, double* lds_coef, double* red) {
+__device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int fresh, bool writer, double* lds_coef, double* red) {
   const int tid = threadIdx.x;
+  double* coef_g = c.coef + (size_t)g * c.coef_gs;
   for (int idx = tid; idx < upto * 2 * WM; idx += TPB) {
     const int l = idx / (2 * WM);
-    if (l != fresh) lds_coef[idx] = c.coef[idx];
+    if (l != fresh) lds_coef[idx] = coef_g[idx];
   }
   if (fresh >= 0 && fresh < upto) {
     constexpr int S = TPB / WM;              // slices of partial records per feature (power of two)
     const int j = tid % WM, s = tid / WM;
-    const double* part = c.partials + (size_t)fresh * c.maxb * WM * 3;
+    const double* part = c.partials + ((size_t)fresh * c.G + g) * c.maxb * WM * 3;
     const int np = c.nparts[fresh];
     const double ref = part[j * 3 + 1];      // mean of record 0 (workgroup 0 always owns samples)
     double an = 0.0, a1 = 0.0, a2 = 0.0;
@@ -63,22 +64,27 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int upto, int fresh, 
         const double mean = ref + s1 / n;
         const double m2 = fmax(s2 - s1 * s1 / n, 0.0);
         const double var_b = m2 / n;                             // biased variance normalises the batch
-        const double g = c.gb[(fresh * 2 + 0) * WM + j], be = c.gb[(fresh * 2 + 1) * WM + j];
-        scale = g / sqrt(var_b + NIS_BN_EPS);
+        const double gam = c.gb[(fresh * 2 + 0) * WM + j], be = c.gb[(fresh * 2 + 1) * WM + j];
+        scale = gam / sqrt(var_b + NIS_BN_EPS);
         shift = be - mean * scale;
-        if (blockIdx.x == 0) {
-          double* run = c.running + cellk_running_off(c, fresh);
+        if (writer) {
           const double unb = n > 1.0 ? m2 / (n - 1.0) : var_b;   // running_var takes the unbiased one
-          run[j] = (1.0 - NIS_BN_MOM) * run[j] + NIS_BN_MOM * mean;
-          run[F + j] = (1.0 - NIS_BN_MOM) * run[F + j] + NIS_BN_MOM * unb;
-          if (j == 0 && c.tracked) c.tracked[fresh] += 1;
+          if (c.G == 1) {
+            double* run = c.running + cellk_running_off(c, fresh);
+            run[j] = (1.0 - NIS_BN_MOM) * run[j] + NIS_BN_MOM * mean;
+            run[F + j] = (1.0 - NIS_BN_MOM) * run[F + j] + NIS_BN_MOM * unb;
+            if (j == 0 && c.tracked) c.tracked[fresh] += 1;
+          } else {                                               // applied in batch order by k_running_update
+            c.gstat[(((size_t)fresh * c.G + g) * 2 + 0) * WM + j] = mean;
+            c.gstat[(((size_t)fresh * c.G + g) * 2 + 1) * WM + j] = unb;
+          }
         }
       }
       lds_coef[(fresh * 2 + 0) * WM + j] = scale;
       lds_coef[(fresh * 2 + 1) * WM + j] = shift;
-      if (blockIdx.x == 0) {
-        c.coef[(fresh * 2 + 0) * WM + j] = scale;
-        c.coef[(fresh * 2 + 1) * WM + j] = shift;
+      if (writer) {
+        coef_g[(fresh * 2 + 0) * WM + j] = scale;
+        coef_g[(fresh * 2 + 1) * WM + j] = shift;
       }
     }
   }
@@ -173,35 +179,87 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
   __shared__ double wshift[NW][WM];
   __shared__ double wmom[NW][WM][3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  load_coefs<WM, TPB>(c, layer, layer - 1, lds_coef, red);
+  const int g = blockIdx.y;
+  planes += (size_t)g * c.plane_gs;
+  // G == 1: the previous layer's records are merged here; G > 1: k_bn_finalize already published the coefficients
+  load_coefs<WM, TPB>(c, g, layer, c.G == 1 ? layer - 1 : -1, blockIdx.x == 0, lds_coef, red);
 
   double S1[WM], S2[WM];
 #pragma unroll
   for (int j = 0; j < WM; ++j) S1[j] = S2[j] = 0.0;
   double cnt = 0.0;
   const long stride = (long)gridDim.x * TPB;
+  constexpr int U = WM <= 8 ? 4 : 1;           // samples in flight per thread: the loop is load-latency bound
+  constexpr int PU = WM <= 8 ? WM : 1;
   bool firstit = true;
-  for (long i = (long)blockIdx.x * TPB + tid; i < N; i += stride) {
-    double a[WM];
-    load_passthrough<WM>(c, planes, ld, i, a);
-    hidden_stack<WM>(c, lds_coef, layer, false, a);
-    if (firstit) {                      // wave-uniform shift = lane 0's first value (lane 0 owns the lowest index)
+  for (long i0 = (long)blockIdx.x * TPB + tid; i0 < N; i0 += stride * U) {
+    double pre[U][PU];
+    if (U > 1) {
 #pragma unroll
-      for (int j = 0; j < WM; ++j) {
-        const double s0 = wave_first(a[j]);
-        if (lane == 0) wshift[wave][j] = s0;
+      for (int u = 0; u < U; ++u) {
+        const long i = i0 + u * stride;
+#pragma unroll
+        for (int p = 0; p < PU; ++p) pre[u][p] = (p < c.P && i < N) ? planes[(size_t)c.in_plane[p] * ld + i] : 0.0;
       }
-      firstit = false;
     }
 #pragma unroll
-    for (int j = 0; j < WM; ++j) {
-      const double t = a[j] - wshift[wave][j];
-      S1[j] += t;
-      S2[j] = fma(t, t, S2[j]);
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * stride;
+      if (i < N) {
+        double a[WM];
+        if (U > 1) {
+#pragma unroll
+          for (int p = 0; p < WM; ++p) a[p] = p < PU ? pre[u][p < PU ? p : 0] : 0.0;
+        } else {
+          load_passthrough<WM>(c, planes, ld, i, a);
+        }
+        hidden_stack<WM>(c, lds_coef, layer, false, a);
+        if (firstit) {                  // wave-uniform shift = lane 0's first value (lane 0 owns the lowest index)
+#pragma unroll
+          for (int j = 0; j < WM; ++j) {
+            const double s0 = wave_first(a[j]);
+            if (lane == 0) wshift[wave][j] = s0;
+          }
+          firstit = false;
+        }
+#pragma unroll
+        for (int j = 0; j < WM; ++j) {
+          const double t = a[j] - wshift[wave][j];
+          S1[j] += t;
+          S2[j] = fma(t, t, S2[j]);
+        }
+        cnt += 1.0;
+      }
     }
-    cnt += 1.0;
   }
-  emit_records<WM, NW>(S1, S2, cnt, wshift, wmom, WM, c.partials + ((size_t)layer * c.maxb + blockIdx.x) * WM * 3);
+  emit_records<WM, NW>(S1, S2, cnt, wshift, wmom, WM, c.partials + (((size_t)layer * c.G + g) * c.maxb + blockIdx.x) * WM * 3);
+}
+
+// G > 1: one workgroup per batch merges the records of BN layer `layer` and publishes scale / shift (+ the batch
+// mean / unbiased variance for the running-statistics update), so consumers only read 2*WM coefficients.
+template <int WM>
+__global__ __launch_bounds__(1024) void k_bn_finalize(CellK c, int layer) {
+  __shared__ double lds_coef[(NIS_MAX_HIDDEN + 1) * 2 * WM];
+  __shared__ double red[3 * 1024];
+  load_coefs<WM, 1024>(c, blockIdx.x, layer + 1, layer, true, lds_coef, red);
+}
+
+// G > 1: apply the G momentum updates of every BN layer in batch order (BatchNorm1d semantics, momentum 0.1).
+template <int WM>
+__global__ void k_running_update(CellK c) {
+  const int l = blockIdx.x, j = threadIdx.x;
+  const int F = cellk_feat(c, l);
+  if (j < F) {
+    double* run = c.running + cellk_running_off(c, l);
+    double rm = run[j], rv = run[F + j];
+    for (int g = 0; g < c.G; ++g) {
+      rm = (1.0 - NIS_BN_MOM) * rm + NIS_BN_MOM * c.gstat[(((size_t)l * c.G + g) * 2 + 0) * WM + j];
+      rv = (1.0 - NIS_BN_MOM) * rv + NIS_BN_MOM * c.gstat[(((size_t)l * c.G + g) * 2 + 1) * WM + j];
+    }
+    run[j] = rm;
+    run[F + j] = rv;
+  }
+  if (j == 0 && c.tracked) c.tracked[l] += c.G;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -217,7 +275,9 @@ __device__ __forceinline__ double last_dot(nis_cptr wl, nis_cptr bias, int row, 
 
 // torch.lerp(start, end, weight) as the CPU kernel evaluates it (used at coupling_cells.py:224)
 __device__ __forceinline__ double lerp_torch(double a, double b, double w) {
-  return (w < 0.5) ? a + w * (b - a) : b - (b - a) * (1.0 - w);
+  const double d = b - a;
+  const double lo = a + w * d, hi = b - d * (1.0 - w);      // both sides, one select: no exec-masked branch
+  return (w < 0.5) ? lo : hi;
 }
 
 // Piecewise-quadratic transform of one column (coupling_cells.py:167-225).  V: K+1 vertex heights
@@ -225,8 +285,9 @@ __device__ __forceinline__ double lerp_torch(double a, double b, double w) {
 // The cumulative widths that decide the bin are formed exactly as the reference does (cumsum of the raw
 // exponentials, then a true division by the total), so the selected bin is bit-identical for identical
 // conditioner outputs; the remaining normalisations multiply by a reciprocal (<= 1 ulp from a division).
-template <int KM>
-__device__ __forceinline__ double pwquad_column(double xb, int K, double (&V)[KM + 1], double (&W)[KM], double* jf, int* bin) {
+template <int KM, bool KEXACT>
+__device__ __forceinline__ double pwquad_column(double xb, int Krt, double (&V)[KM + 1], double (&W)[KM], double* jf, int* bin) {
+  const int K = KEXACT ? KM : Krt;
   xb = (xb > 1.0 - 1e-6) ? 1.0 - 1e-6 : xb;                       // :167
   double wn = 0.0;
 #pragma unroll
@@ -241,13 +302,12 @@ __device__ __forceinline__ double pwquad_column(double xb, int K, double (&V)[KM
       run += W[k];
       const double cs = run / wn;                                 // Wsum/Wnorms :186
       const double v = (cs > xb) ? 0.0 : cs;
-      if (v > best) {
-        best = v;
-        idx = k + 1;
-        left = cs;                                                // Wsum2[idx]
-      }
+      const bool up = v > best;                                   // selects only (no divergent branch)
+      best = up ? v : best;
+      idx = up ? k + 1 : idx;
+      left = up ? cs : left;                                      // Wsum2[idx]
     }
-  if (idx > K - 1) idx = K - 1;
+  idx = (idx > K - 1) ? K - 1 : idx;
   const double iwn = 1.0 / wn;
   double area = 0.0;
 #pragma unroll
@@ -264,12 +324,11 @@ __device__ __forceinline__ double pwquad_column(double xb, int K, double (&V)[KM
 #pragma unroll
   for (int k = 0; k < KM; ++k)
     if (k < K) {
-      if (k == idx) {
-        shift = vw;                                               // VW[idx]  :209-211
-        Wb = W[k];
-        Vb = V[k];
-        Vb1 = V[k + 1];
-      }
+      const bool hit = k == idx;
+      shift = hit ? vw : shift;                                   // VW[idx]  :209-211
+      Wb = hit ? W[k] : Wb;
+      Vb = hit ? V[k] : Vb;
+      Vb1 = hit ? V[k + 1] : Vb1;
       vw += (V[k] + V[k + 1]) / 2 * W[k];
     }
   const double alpha = (xb - left) / Wb;                          // :206-207
@@ -283,18 +342,22 @@ __device__ __forceinline__ double pwquad_column(double xb, int K, double (&V)[KM
 // Full cell: conditioner with finalised BN + bijector, in place on the transformed planes.  Optional riders:
 //   * BN_0 records of the NEXT cell (its pass-through columns are all in this thread's registers),
 //   * a built-in integrand f(X)*J with its moment records (last cell), optionally without storing X, J.
-template <int KIND, int WM, int KM>
+template <int KIND, int WM, int KM, bool KEXACT>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                         int* __restrict__ bins_out, FuseF fz) {
   constexpr int NW = NIS_TPB / NIS_WAVE;
-  constexpr int NF = NIS_PMAX_FUSED;
+  constexpr int NF = WM <= 4 ? 4 : NIS_PMAX_FUSED;      // next-cell pass-through features tracked here (<= its P)
   __shared__ double lds_coef[(NIS_MAX_HIDDEN + 1) * 2 * WM];
   __shared__ double red[3 * NIS_TPB];
   __shared__ double wshift[NW][NF];
   __shared__ double wmom[NW][NF][3];
   __shared__ double fmom[NW][4];
+  __shared__ double etab[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  load_coefs<WM, NIS_TPB>(c, c.L + 1, bn_train ? c.L : -1, lds_coef, red);
+  const int g = blockIdx.y;
+  planes += (size_t)g * c.plane_gs;
+  nis_exp_init(etab);
+  load_coefs<WM, NIS_TPB>(c, g, c.L + 1, (bn_train && c.G == 1) ? c.L : -1, blockIdx.x == 0, lds_coef, red);
   nis_cptr wl = as_const(c.wlast);
   nis_cptr bias = as_const(c.bias);
   constexpr bool RIDERS = WM <= 8;          // wide conditioners keep their registers for the GEMV
@@ -311,22 +374,19 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
     load_passthrough<WM>(c, planes, ld, i, a);
     double nv[NF];
     double c0 = 0.0, c1 = 0.0, nsum = 0.0;
+    // riders read pass-through columns straight from their planes (uniform plane index, L1 hit: the line was
+    // just loaded for `a`); transformed columns are picked up inside the t loop by one uniform compare each
     if (next) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        nv[f] = 0.0;
-#pragma unroll
-        for (int p = 0; p < (WM < NIS_MAX_DIM ? WM : NIS_MAX_DIM); ++p)
-          if (c.next_src[f] == p) nv[f] = a[p];
+        const int src = c.next_src[f];
+        nv[f] = (src >= 0 && src < c.P) ? planes[(size_t)c.in_plane[src < 0 ? 0 : src] * ld + i] : 0.0;
       }
     }
     if (fuse) {
       if (fz.kind == NIS_F_CAMEL) {
-#pragma unroll
-        for (int p = 0; p < (WM < NIS_MAX_DIM ? WM : NIS_MAX_DIM); ++p) {
-          if (fz.loc0 == p) c0 = a[p];
-          if (fz.loc1 == p) c1 = a[p];
-        }
+        if (fz.loc0 >= 0 && fz.loc0 < c.P) c0 = planes[(size_t)c.in_plane[fz.loc0] * ld + i];
+        if (fz.loc1 >= 0 && fz.loc1 < c.P) c1 = planes[(size_t)c.in_plane[fz.loc1] * ld + i];
       } else if (fz.kind == NIS_F_NORMAL) {
 #pragma unroll
         for (int p = 0; p < (WM < NIS_MAX_DIM ? WM : NIS_MAX_DIM); ++p)
@@ -344,10 +404,13 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
       if (KIND == NIS_PWQUAD) {
         double V[KM + 1], W[KM];
 #pragma unroll
-        for (int k = 0; k < KM + 1; ++k) V[k] = (k <= c.K) ? exp(last_dot<WM>(wl, bias, row0 + k, a)) : 0.0;     // :173,189
+        for (int k = 0; k < KM + 1; ++k)
+          V[k] = (KEXACT || k <= c.K) ? nis_exp(last_dot<WM>(wl, bias, row0 + k, a), etab) : 0.0;                   // :173,189
+        const int Kq = KEXACT ? KM : c.K;
 #pragma unroll
-        for (int k = 0; k < KM; ++k) W[k] = (k < c.K) ? exp(last_dot<WM>(wl, bias, row0 + c.K + 1 + k, a)) : 0.0;  // :175,178
-        y = pwquad_column<KM>(xb, c.K, V, W, &jf, &bin);
+        for (int k = 0; k < KM; ++k)
+          W[k] = (KEXACT || k < c.K) ? nis_exp(last_dot<WM>(wl, bias, row0 + Kq + 1 + k, a), etab) : 0.0;             // :175,178
+        y = pwquad_column<KM, KEXACT>(xb, c.K, V, W, &jf, &bin);
       } else {
         // PWLin: equal-width bins -> the index is known before the heights (coupling_cells.py:126-133),
         // so the K heights are streamed: total, prefix below the bin, and the bin's own height.
@@ -357,7 +420,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
         bin = (int)bf;
         double tot = 0.0, below = 0.0, qb = 0.0;
         for (int k = 0; k < c.K; ++k) {
-          const double e = exp(last_dot<WM>(wl, bias, row0 + k, a));                 // :115
+          const double e = nis_exp(last_dot<WM>(wl, bias, row0 + k, a), etab);                 // :115
           if (k == bin) {
             below = tot;
             qb = e;
@@ -374,7 +437,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
       }
       if (fz.write_planes) col[i] = y;
       jprod *= jf;
-      if (bins_out) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
+      if (bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
       if (next) {
 #pragma unroll
         for (int f = 0; f < NF; ++f)
@@ -407,15 +470,15 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
     if (fuse) {
       double fv = 1.0;
       if (fz.kind == NIS_F_CAMEL) {                                                   // README.md:35-36
-        const double s2 = fz.p[2] * fz.p[2];
-        const double e1 = -((c0 - fz.p[0]) * (c0 - fz.p[0]) + (c1 - fz.p[0]) * (c1 - fz.p[0])) / s2;
-        const double e2 = -((c0 - fz.p[1]) * (c0 - fz.p[1]) + (c1 - fz.p[1]) * (c1 - fz.p[1])) / s2;
-        fv = exp(e1) + exp(e2);
+        const double is2 = fz.p[3];                                                   // host: 1 / s^2
+        const double e1 = -((c0 - fz.p[0]) * (c0 - fz.p[0]) + (c1 - fz.p[0]) * (c1 - fz.p[0])) * is2;
+        const double e2 = -((c0 - fz.p[1]) * (c0 - fz.p[1]) + (c1 - fz.p[1]) * (c1 - fz.p[1])) * is2;
+        fv = nis_exp(e1, etab) + nis_exp(e2, etab);
       } else if (fz.kind == NIS_F_NORMAL) {                                           // manager.py:39-40
-        fv = exp(-nsum) / (fz.p[1] * sqrt(pow(2 * M_PI, (double)c.d)));
+        fv = nis_exp(-nsum, etab) / (fz.p[1] * sqrt(pow(2 * M_PI, (double)c.d)));
       }
       const double v = fv * jout;
-      if (fz.fres) fz.fres[i] = v;
+      if (fz.fres) fz.fres[(size_t)g * fz.fres_gs + i] = v;
       if (firstit) fshift = wave_first(v);
       const double t = v - fshift;
       fS1 += t;
@@ -425,19 +488,38 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
     cnt += 1.0;
     firstit = false;
   }
-  if (next) emit_records<NF, NW>(nS1, nS2, cnt, wshift, wmom, c.next_P, c.next_partials + (size_t)blockIdx.x * c.next_wm * 3);
-  if (fuse) block_record<NW>(fshift, fS1, fS2, cnt, fmax_, fmom, fz.partials + (size_t)blockIdx.x * 4);
+  if (next)
+    emit_records<NF, NW>(nS1, nS2, cnt, wshift, wmom, c.next_P, c.next_partials + ((size_t)g * c.maxb + blockIdx.x) * c.next_wm * 3);
+  if (fuse) block_record<NW>(fshift, fS1, fS2, cnt, fmax_, fmom, fz.partials + ((size_t)g * fz.maxb + blockIdx.x) * 4);
 }
 
-// Host-side launchers, instantiated once per WM in flow_wm.hip.
+// Host-side launchers, instantiated once per WM in flow_wm.hip.  `grid` is the x extent; y = c.G batches.
+// *_blocks_per_cu: resident workgroups per CU of the kernel (occupancy query, cached) -> grids are sized to ONE
+// resident wave of workgroups so that every thread amortises the prologue / epilogue over many samples.
+template <int WM>
+int stats_blocks_per_cu();
+template <int WM>
+int apply_blocks_per_cu(int kind, int km);
 template <int WM>
 hipError_t launch_stats(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s);
+template <int WM>
+hipError_t launch_finalize(const CellK& c, int layer, hipStream_t s);
+template <int WM>
+hipError_t launch_running_update(const CellK& c, hipStream_t s);
 template <int WM>
 hipError_t launch_apply(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz, int grid,
                         hipStream_t s);
 #define NIS_DECL_WM(W)                                                                                                      \
   template <>                                                                                                               \
+  int stats_blocks_per_cu<W>();                                                                                             \
+  template <>                                                                                                               \
+  int apply_blocks_per_cu<W>(int kind, int km);                                                                             \
+  template <>                                                                                                               \
   hipError_t launch_stats<W>(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s);    \
+  template <>                                                                                                               \
+  hipError_t launch_finalize<W>(const CellK& c, int layer, hipStream_t s);                                                  \
+  template <>                                                                                                               \
+  hipError_t launch_running_update<W>(const CellK& c, hipStream_t s);                                                       \
   template <>                                                                                                               \
   hipError_t launch_apply<W>(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz, \
                              int grid, hipStream_t s);

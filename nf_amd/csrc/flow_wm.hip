@@ -10,24 +10,95 @@
 template <>
 hipError_t launch_stats<NIS_WM>(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s) {
   constexpr int TPB = nis_stats_tpb(NIS_WM);
-  hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB>), dim3(grid), dim3(TPB), 0, s, c, planes, ld, N, layer);
+  hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N, layer);
   return hipGetLastError();
 }
 
-#define NIS_APPLY(KIND, KMV) \
-  hipLaunchKernelGGL((k_cell_apply<KIND, NIS_WM, KMV>), dim3(grid), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
+template <>
+hipError_t launch_finalize<NIS_WM>(const CellK& c, int layer, hipStream_t s) {
+  hipLaunchKernelGGL((k_bn_finalize<NIS_WM>), dim3(c.G), dim3(1024), 0, s, c, layer);
+  return hipGetLastError();
+}
 
+template <>
+hipError_t launch_running_update<NIS_WM>(const CellK& c, hipStream_t s) {
+  hipLaunchKernelGGL((k_running_update<NIS_WM>), dim3(c.L + 1), dim3(NIS_WM), 0, s, c);
+  return hipGetLastError();
+}
+
+template <>
+int stats_blocks_per_cu<NIS_WM>() {
+  static int v = -1;
+  if (v < 0) {
+    constexpr int TPB = nis_stats_tpb(NIS_WM);
+    hipFuncAttributes at;
+    int n = 1;
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(k_bn_stats<NIS_WM, TPB>)) == hipSuccess && at.numRegs > 0) {
+      const int alloc = (at.numRegs + 7) / 8 * 8;
+      int waves = 512 / alloc;
+      waves = waves < 1 ? 1 : waves > 8 ? 8 : waves;
+      n = waves * 4 * 64 / TPB;                 // waves/SIMD * 4 SIMDs * 64 lanes / workgroup size
+      if (n < 1) n = 1;
+    }
+    v = n;
+  }
+  return v;
+}
+
+// resident 256-thread workgroups per CU from the kernel's register allocation (the occupancy API
+// under-reports these kernels: measured optimum 5/CU where it answers 3): 512 VGPRs per SIMD lane, granule 8.
+template <typename K>
+static int occ_of(K kern) {
+  hipFuncAttributes at;
+  if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(kern)) != hipSuccess || at.numRegs < 1) return 4;
+  const int alloc = (at.numRegs + 7) / 8 * 8;
+  int waves = 512 / alloc;                       // waves per SIMD; a 256-thread workgroup puts one wave on each SIMD
+  waves = waves < 1 ? 1 : waves > 8 ? 8 : waves;
+  int by_lds = at.sharedSizeBytes > 0 ? (int)(160 * 1024 / at.sharedSizeBytes) : 8;
+  return waves < by_lds ? waves : (by_lds < 1 ? 1 : by_lds);
+}
+
+template <>
+int apply_blocks_per_cu<NIS_WM>(int kind, int km) {
+  static int cache[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+  const bool exact = km < 0;
+  const int kk = exact ? -km : km;
+  const int slot = kind == NIS_PWLIN ? 0 : (kk == 4 ? 1 : kk == 8 ? 2 : kk == 16 ? 3 : 4) + (exact ? 4 : 0);
+  if (cache[slot] < 0) {
+    switch (slot) {
+      case 0: cache[slot] = occ_of(k_cell_apply<NIS_PWLIN, NIS_WM, 4, false>); break;
+      case 1: cache[slot] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 4, false>); break;
+      case 2: cache[slot] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 8, false>); break;
+      case 3: cache[slot] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 16, false>); break;
+      case 4: cache[slot] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 32, false>); break;
+      case 5: cache[slot] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 4, true>); break;
+      case 6: cache[slot] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 8, true>); break;
+      case 7: cache[slot] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 16, true>); break;
+      default: cache[slot] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 32, true>); break;
+    }
+  }
+  return cache[slot];
+}
+
+#define NIS_APPLY(KIND, KMV, EX) \
+  hipLaunchKernelGGL((k_cell_apply<KIND, NIS_WM, KMV, EX>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
+
+// km < 0 selects the K == KM specialisation (no per-bin guards)
 template <>
 hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz,
                                 int grid, hipStream_t s) {
   if (c.kind == NIS_PWLIN) {
-    NIS_APPLY(NIS_PWLIN, 4);
+    NIS_APPLY(NIS_PWLIN, 4, false);
   } else {
     switch (km) {
-      case 4: NIS_APPLY(NIS_PWQUAD, 4); break;
-      case 8: NIS_APPLY(NIS_PWQUAD, 8); break;
-      case 16: NIS_APPLY(NIS_PWQUAD, 16); break;
-      case 32: NIS_APPLY(NIS_PWQUAD, 32); break;
+      case 4: NIS_APPLY(NIS_PWQUAD, 4, false); break;
+      case 8: NIS_APPLY(NIS_PWQUAD, 8, false); break;
+      case 16: NIS_APPLY(NIS_PWQUAD, 16, false); break;
+      case 32: NIS_APPLY(NIS_PWQUAD, 32, false); break;
+      case -4: NIS_APPLY(NIS_PWQUAD, 4, true); break;
+      case -8: NIS_APPLY(NIS_PWQUAD, 8, true); break;
+      case -16: NIS_APPLY(NIS_PWQUAD, 16, true); break;
+      case -32: NIS_APPLY(NIS_PWQUAD, 32, true); break;
       default: return hipErrorInvalidValue;
     }
   }

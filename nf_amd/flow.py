@@ -120,6 +120,11 @@ class FlowEngine:
         self._token = 0
         self._stats_epoch = 0
 
+    def fusable(self):
+        """The built-in-integrand rider lives in the narrow (register width <= 8) apply kernels."""
+        last = self.cells[-1]
+        return max([last.pass_through_size] + list(last.hidden_widths)) <= 8
+
     # ---- per-call plumbing
     def _pointers(self, dev):
         n = len(self.cells)
@@ -129,8 +134,8 @@ class FlowEngine:
             pp[i], rp[i], tp[i] = c._flat.data_ptr(), c._running.data_ptr(), c._tracked.data_ptr()
         return pp, rp, tp
 
-    def _workspace(self, dev):
-        wsb = self.L.nis_flow_workspace_bytes(self.handle, 1)
+    def _workspace(self, dev, G=1):
+        wsb = self.L.nis_flow_workspace_bytes(self.handle, G)
         if self._ws is None or self._ws.device != dev or self._ws.numel() < wsb:
             self._ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             self._sig = None
@@ -178,28 +183,37 @@ class FlowEngine:
             self._stats_epoch += 1
         return dict(planes=planes, xj=xj, bins=bins, status=ws[:4].view(torch.int32), ws=ws)
 
-    def integrate_step(self, w, train, f_kind, f_params, out4, planes=None, token=None, want_fres=False):
-        """One integrate() iteration in ONE library call: flow forward + built-in integrand + moments -> out4
-        (a 4-element float64 device tensor/view).  X and J are not stored unless `planes` is wanted back."""
-        w = self._check_input(w, self.d, train)
-        N, dev = w.shape[0], w.device
+    def integrate_steps(self, w, train, f_kind, f_params, out4, planes=None, token=None, want_fres=False):
+        """G iterations of integrate()'s loop body in ONE library call.  w: (G, N, d) (or (N, d) for G = 1),
+        out4: (G, 4) float64 device tensor/view receiving {count, mean, M2, max} per iteration.  The iterations
+        run as the y dimension of every launch (each is its own train-mode BatchNorm batch); X and J are not
+        stored unless `planes` ((G, d+1, N)) is passed."""
+        if w.dim() == 2:
+            w = w.unsqueeze(0)
+        G, N = w.shape[0], w.shape[1]
+        w2 = self._check_input(w.reshape(G * N, w.shape[2]), self.d, train)
+        if train and N < 2:
+            raise ValueError("Expected more than 1 value per channel when training")
+        dev = w2.device
         pp, rp, tp = self._pointers(dev)
-        ws, wsb = self._workspace(dev)
+        ws, wsb = self._workspace(dev, G)
         if token is None:
             token = self.pack_token()
         keep = planes is not None
         if planes is None:
-            planes = torch.empty((self.d + 1, N), dtype=torch.double, device=dev)
-        fres = torch.empty(N, dtype=torch.double, device=dev) if want_fres else None
+            planes = torch.empty((G, self.d + 1, N), dtype=torch.double, device=dev)
+        fres = torch.empty((G, N), dtype=torch.double, device=dev) if want_fres else None
         fp = (C.c_double * 4)(*(list(f_params) + [0.0] * 4)[:4])
-        rc = self.L.nis_integrate_step(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
-                                       N, pp, rp, tp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL, token, f_kind, fp,
-                                       planes.data_ptr(), N, 1 if keep else 0, fres.data_ptr() if want_fres else None,
-                                       out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr())
-        _lib.check(rc, "nis_integrate_step")
+        rc = self.L.nis_integrate_steps(self.handle, w2.data_ptr(), _lib.NIS_F32 if w2.dtype == torch.float32 else _lib.NIS_F64,
+                                        G, N, pp, rp, tp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL, token, f_kind, fp,
+                                        planes.data_ptr(), N, 1 if keep else 0, fres.data_ptr() if want_fres else None,
+                                        out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr())
+        _lib.check(rc, "nis_integrate_steps")
         if train:
             self._stats_epoch += 1
         return fres
+
+    integrate_step = integrate_steps
 
 
 def moments_of(planes, d, out_col, f_kind, f_params, want_fres=False):

@@ -315,21 +315,29 @@ class BasicManager(ModelAPI):
         p = next(self.best_model.parameters())
         return p.device if p.is_cuda else torch.device("cuda:0")
 
+    batch_iterations = 16      # integrate(): iterations fused into one launch set (independent BN batches)
+
     def moments_batches(self, f, nitn, neval, dev):
         """(count, mean, M2, max) of f(X)*J for nitn fresh batches; stays on the device."""
         model = self.best_model
         model.to(dev)
         out = torch.empty((nitn, 4), dtype=torch.double, device=dev)
-        fused = hasattr(f, "nis_kind") and isinstance(model, FlowSequential)
-        eng = model.engine() if fused else None
+        fused = hasattr(f, "nis_kind") and isinstance(model, FlowSequential) and model.engine().fusable()
+        if fused:                           # G iterations per library call, X / J never stored
+            eng = model.engine()
+            G = max(1, min(int(self.batch_iterations), nitn, max(1, (1 << 28) // max(1, neval * (self.n_flow + 1)))))
+            i = 0
+            while i < nitn:
+                g = min(G, nitn - i)
+                w = torch.stack([self._uniform(neval, dev, torch.float32, "integrate") for _ in range(g)])
+                eng.integrate_steps(w, model.training, f.nis_kind, f.nis_params, out[i:i + g])
+                i += g
+            return out
         for i in range(nitn):
             w = self._uniform(neval, dev, torch.float32, "integrate")
-            if fused:                       # one library call per iteration, X / J never stored
-                eng.integrate_step(w, model.training, f.nis_kind, f.nis_params, out[i])
-            else:
-                with torch.no_grad():
-                    XJ = model(self.format_input(w, dev)).detach()
-                    out[i] = hip_moments(f(XJ[:, :-1]), XJ[:, -1])
+            with torch.no_grad():
+                XJ = model(self.format_input(w, dev)).detach()
+                out[i] = hip_moments(f(XJ[:, :-1]), XJ[:, -1])
         return out
 
 
