@@ -199,6 +199,7 @@ def main():
     if ws != args.gpus and ws > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}")
     _lib.require_gpu()
+    local = local % max(1, torch.cuda.device_count())      # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
