@@ -156,7 +156,8 @@ typedef struct nis_rambo_desc {
   double  final_masses[NIS_MAX_LEGS];
   double  E_cm;
   double  pT_mincut, delR_mincut, rap_maxcut;
-  int32_t bisect_levels;           /* lattice bisection depth (reference executes 120-180)   */
+  int32_t bisect_levels;           /* 0: Newton solver for the intermediate-mass equation; > 0: the
+                                      reference's lattice bisection with this many levels (it runs 120-180) */
   int32_t reserved;
 } nis_rambo_desc;
 enum { NIS_RAMBO_PDF_ACTIVE = 1, NIS_RAMBO_TAU = 2, NIS_RAMBO_LAB_BOOST = 4 };

@@ -42,7 +42,8 @@ class FlatInvertiblePhasespace(VirtualPhaseSpaceGenerator):
 
     epsilon_border = 1e-10
     absolute_Ecm_min = 1.
-    bisect_levels = 120        # lattice-bisection depth; the reference executes 120-180 levels (batch dependent)
+    bisect_levels = 0          # 0: monotone Newton solver (default); > 0: the reference's lattice bisection with that many
+                               # levels per sample (the reference executes a batch-dependent 120-180)
 
     def __init__(self, *args, **opts):
         super().__init__(*args, **opts)

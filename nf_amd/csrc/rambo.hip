@@ -39,6 +39,42 @@ __device__ __forceinline__ double rb_ipow(double x, int e) {
   return p;
 }
 
+// Root of g(u) = (e+1) u^e - e u^(e+1) = v on (0,1) (the equation bisect_vec_batch solves, :313-359) by Newton's
+// method started on the side from which it converges monotonically: g is increasing, convex left of its inflection
+// u_i = (e-1)/e and concave right of it, so start right of the root in the convex part (u_s/(1-u_s) >= root, u_s the
+// leading-order root) and left of it in the concave part.  8 steps reach the fixed point of the double evaluation
+// (<= few ulp from the lattice bisection's limit; identical conditioning: both stall where g' ~ 0 at v -> 1).
+__device__ __forceinline__ double rb_solve(double v, int e) {
+  if (e == 1) return v / (1.0 + sqrt(1.0 - v));                  // 2u - u^2 = v
+  const double ui = (double)(e - 1) / (double)e;
+  const double vi = rb_ipow(ui, e) * ((double)(e + 1) - (double)e * ui);
+  const bool convex = v < vi;
+  double u;
+  if (convex) {
+    const double us = pow(v / (double)(e + 1), 1.0 / (double)e);
+    double c0 = us / (1.0 - fmin(us, 0.9));
+    c0 = fmin(c0, ui);
+    const double g0 = rb_ipow(c0, e) * ((double)(e + 1) - (double)e * c0);
+    u = (g0 >= v) ? c0 : ui;
+  } else {
+    const double ub = 1.0 - sqrt(2.0 * (1.0 - v) / (double)(e * (e + 1)));
+    u = fmax(ui, ub);
+  }
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    const double um1 = rb_ipow(u, e - 1);
+    const double g = um1 * u * ((double)(e + 1) - (double)e * u) - v;
+    const double gp = (double)(e * (e + 1)) * um1 * (1.0 - u);
+    double un = u - g / gp;
+    un = convex ? fmin(fmax(un, 0.0), ui) : fmin(fmax(un, ui), 1.0);
+    un = (gp > 0.0) ? un : u;
+    const bool moved = fabs(un - u) > 4e-16 * un;       // the iteration is monotone: no movement = fixed point
+    u = un;
+    if (!__any(moved)) break;                           // wave-uniform exit (typically after 4-5 steps)
+  }
+  return u;
+}
+
 struct V4 {
   double e, x, y, z;
 };
@@ -72,26 +108,50 @@ __device__ __forceinline__ double rb_delphi(const V4& a, const V4& b) {         
   return r;
 }
 
+#define RB_TPB 128      // threads (= samples) per tile: bounds the LDS staging area to 128*(4(n+2)+1)*8 B
+
+// Row-major I/O goes through LDS: a tile's (RB_TPB x ncol) inputs are copied with contiguous 8-byte-per-lane
+// loads, each thread then reads its own row; the (RB_TPB x 4(n+2)) momenta are written to a padded LDS image and
+// stored as contiguous 16-byte-per-lane streams.  Without staging every lane touches its own cache line per
+// instruction (row stride 64-256 B).
 template <int NF>
-__global__ __launch_bounds__(NIS_TPB) void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict__ momenta,
-                                                   double* __restrict__ weight, int* __restrict__ status) {
-  const long stride = (long)gridDim.x * NIS_TPB;
+__global__ __launch_bounds__(RB_TPB) void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict__ momenta,
+                                                  double* __restrict__ weight, int* __restrict__ status) {
+  extern __shared__ double rb_lds[];
+  constexpr int LM = 4 * (NF + 2);                   // doubles of one sample's momenta
+  const int tid = threadIdx.x;
   const bool pdf_active = k.d.flags & NIS_RAMBO_PDF_ACTIVE;
   const bool use_tau = k.d.flags & NIS_RAMBO_TAU;
   const bool lab_boost = k.d.flags & NIS_RAMBO_LAB_BOOST;
   constexpr int NPS = 3 * NF - 4;                    // phase-space columns; +2 (tau, ycm | x2, x1) with PDFs
-  for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < N; i += stride) {
+  const long ntiles = (N + RB_TPB - 1) / RB_TPB;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long i0 = tile * RB_TPB;
+    const int ns = (int)min((long)RB_TPB, N - i0);
+    const long i = i0 + tid;
+    const bool live = tid < ns;
     double rv[NPS + 2];
     bool nan_in = false;
-#pragma unroll
-    for (int c = 0; c < NPS + 2; ++c) {
-      rv[c] = 0.5;
-      if (c < k.ncol) {
-        rv[c] = k.col_major ? r[(size_t)k.cols[c] * k.r_ld + i] : r[(size_t)i * k.r_ld + c];
-        nan_in |= (rv[c] != rv[c]);
+    if (!k.col_major) {
+      if (k.r_ld == k.ncol) {                         // contiguous rows: one flat copy of the tile
+        const int tot = ns * k.ncol;
+        const double* src = r + (size_t)i0 * k.ncol;
+        for (int e = tid; e < tot; e += RB_TPB) rb_lds[e] = src[e];
+      } else {
+        for (int s_ = 0; s_ < ns; ++s_)
+          for (int c = tid; c < k.ncol; c += RB_TPB) rb_lds[s_ * k.ncol + c] = r[(size_t)(i0 + s_) * k.r_ld + c];
       }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < NPS + 2; ++c) rv[c] = (live && c < k.ncol) ? rb_lds[tid * k.ncol + c] : 0.5;
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int c = 0; c < NPS + 2; ++c) rv[c] = (live && c < k.ncol) ? r[(size_t)k.cols[c] * k.r_ld + i] : 0.5;
     }
-    if (nan_in) atomicOr(status, 2);                  // the reference raises PhaseSpaceGeneratorError (:147-149)
+#pragma unroll
+    for (int c = 0; c < NPS + 2; ++c) nan_in |= (rv[c] != rv[c]);
+    if (nan_in && live) atomicOr(status, 2);                  // the reference raises PhaseSpaceGeneratorError (:147-149)
 
     // ---- PDFs: tau / y_cm sampling (:157-187)
     double wgt = 1.0, x1 = 1.0, x2 = 1.0, E = k.d.E_cm;
@@ -119,18 +179,27 @@ __global__ __launch_bounds__(NIS_TPB) void k_rambo(RamboK k, const double* __res
     M[0] = E - k.mtot;
 #pragma unroll
     for (int c = 0; c < NF - 2; ++c) {
+      constexpr int dummy = 0;
+      (void)dummy;
       const int e = NF - 2 - c;
       const double v = rv[c];
-      double left = 0.0, right = 1.0, scale = 0.5, u = -1.0;
-      for (int level = 0; level < k.d.bisect_levels; ++level) {
-        u = (left + right) * scale;
-        const double chk = rb_ipow(u, e) * ((double)(e + 1) - (double)e * u);      // massless_map :101-103
-        left *= 2.;
-        right *= 2.;
-        const double adder = (v <= chk) ? -0.5 : 0.5;
-        left += adder + 0.5;
-        right += adder - 0.5;
-        scale *= 0.5;
+      double u;
+      if (k.d.bisect_levels > 0) {
+        // the reference's integer-lattice bisection, fixed depth (bit-compatible path, ~14 VALU per level)
+        double left = 0.0, right = 1.0, scale = 0.5;
+        u = -1.0;
+        for (int level = 0; level < k.d.bisect_levels; ++level) {
+          u = (left + right) * scale;
+          const double chk = rb_ipow(u, e) * ((double)(e + 1) - (double)e * u);      // massless_map :101-103
+          left *= 2.;
+          right *= 2.;
+          const double adder = (v <= chk) ? -0.5 : 0.5;
+          left += adder + 0.5;
+          right += adder - 0.5;
+          scale *= 0.5;
+        }
+      } else {
+        u = rb_solve(v, e);
       }
       M[c + 1] = sqrt(u * (M[c] * M[c]));                                           // :370
     }
@@ -160,7 +229,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_rambo(RamboK k, const double* __res
       const double cos_t = 2. * rv[NF - 2 + 2 * c] - 1.;
       const double sin_t = sqrt(1. - cos_t * cos_t);
       const double phi = 2 * M_PI * rv[NF - 2 + 2 * c + 1];
-      const double cos_p = cos(phi);
+      const double cos_p = cospi(2.0 * rv[NF - 2 + 2 * c + 1]);   // = cos(2 pi r) without the large-argument reduction path
       const double sq = sqrt(1. - cos_p * cos_p);
       const double sin_p = phi > M_PI ? -sq : sq;                                   // :241-243
       V4 p = {0., q * sin_t * cos_p, q * sin_t * sin_p, q * cos_t};
@@ -177,7 +246,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_rambo(RamboK k, const double* __res
       rb_set_square(Q, M[c + 1] * M[c + 1]);
     }
     mom[NF + 1] = Q;
-    if (bad_boost) atomicOr(status, 8);
+    if (bad_boost && live) atomicOr(status, 8);
 
     // ---- initial state (:408-441)
     if (k.d.initial_masses[0] == 0. || k.d.initial_masses[1] == 0.) {
@@ -192,19 +261,29 @@ __global__ __launch_bounds__(NIS_TPB) void k_rambo(RamboK k, const double* __res
       mom[1] = {E2 / 2.0, 0., 0., -(Z / 2.0)};
     }
     if (momenta) {                                   // COM-frame copy is what the reference returns (:282,308)
-      double* o = momenta + (size_t)i * (NF + 2) * 4;
+      double* row = rb_lds + tid * (LM + 1);         // +1: odd row stride -> conflict-free column writes
 #pragma unroll
       for (int l = 0; l < NF + 2; ++l) {
-        reinterpret_cast<double2*>(o)[2 * l] = make_double2(mom[l].e, mom[l].x);
-        reinterpret_cast<double2*>(o)[2 * l + 1] = make_double2(mom[l].y, mom[l].z);
+        row[4 * l + 0] = mom[l].e;
+        row[4 * l + 1] = mom[l].x;
+        row[4 * l + 2] = mom[l].y;
+        row[4 * l + 3] = mom[l].z;
       }
+      __syncthreads();
+      double* dst = momenta + (size_t)i0 * LM;
+      const int tot = ns * LM;
+      for (int e = tid; e < tot; e += RB_TPB) {
+        const int s_ = e / LM, q = e - s_ * LM;      // LM is a compile-time constant
+        dst[e] = rb_lds[s_ * (LM + 1) + q];
+      }
+      __syncthreads();
     }
 
     // ---- lab frame (utils.py:134-146); the batch-global "any zero reference" test is the caller's
     if (lab_boost) {
       const double rx = mom[0].x * x1 + mom[1].x * x2, ry = mom[0].y * x1 + mom[1].y * x2, rz = mom[0].z * x1 + mom[1].z * x2;
       const double re = mom[0].e * x1 + mom[1].e * x2;
-      if (rx * rx + ry * ry + rz * rz == 0.) atomicOr(status, 4);
+      if (live && rx * rx + ry * ry + rz * rz == 0.) atomicOr(status, 4);
       const double bx = rx / re, by = ry / re, bz = rz / re;
 #pragma unroll
       for (int l = 0; l < NF + 2; ++l) rb_boost(mom[l], bx, by, bz);
@@ -238,7 +317,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_rambo(RamboK k, const double* __res
     }
     wtot *= factor;
     const double shat = x1 * x2 * (k.d.E_cm * k.d.E_cm);
-    weight[i] = wtot / (2 * shat);
+    if (live) weight[i] = wtot / (2 * shat);
   }
 }
 
@@ -257,7 +336,6 @@ extern "C" int nis_rambo_forward(const nis_rambo_desc* dh, const double* r, int6
   RamboK k;
   memset(&k, 0, sizeof(k));
   k.d = *dh;
-  if (k.d.bisect_levels <= 0) k.d.bisect_levels = 120;
   const bool pdf_active = dh->flags & NIS_RAMBO_PDF_ACTIVE;
   k.ncol = 3 * n - 4 + (pdf_active ? 2 : 0);
   k.r_ld = r_ld;
@@ -279,10 +357,13 @@ extern "C" int nis_rambo_forward(const nis_rambo_desc* dh, const double* r, int6
   const double base = (tot > 1.0 ? tot : 1.0) / dh->E_cm;   // absolute_Ecm_min = 1 (:68,:164-165)
   k.tau_min = base * base;
   hipStream_t s = (hipStream_t)stream;
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (N + NIS_TPB - 1) / NIS_TPB));
+  const int LMh = 4 * (n + 2);
+  const size_t lds_bytes = (size_t)RB_TPB * std::max(LMh + 1, k.ncol) * sizeof(double);
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * 256 * 2, (N + RB_TPB - 1) / RB_TPB));
 #define RB_CASE(NFV)                                                                                              \
   case NFV:                                                                                                       \
-    hipLaunchKernelGGL(k_rambo<NFV>, dim3(grid), dim3(NIS_TPB), 0, s, k, r, (long)N, momenta, weight, (int*)status); \
+    hipLaunchKernelGGL(k_rambo<NFV>, dim3(grid), dim3(RB_TPB), lds_bytes, s, k, r, (long)N, momenta, weight, (int*)status); \
     break;
   NisProfScope ps(NIS_K_RAMBO, s);
   switch (n) {

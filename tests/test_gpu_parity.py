@@ -240,10 +240,12 @@ def make_ps(m):
     return FlatInvertiblePhasespace(m["initial"], m["final"], pdf=None, pdf_active=m["pdf_active"], tau=m["tau"])
 
 
+@pytest.mark.parametrize("levels", [0, 120])        # 0: Newton solver (default), 120: the reference's lattice bisection
 @pytest.mark.parametrize("case", golden("rambo.npz").cases())
-def test_rambo_vs_reference_golden(case, g_rambo):
+def test_rambo_vs_reference_golden(case, levels, g_rambo):
     m = g_rambo.meta[case]
     gen = make_ps(m)
+    gen.bisect_levels = levels
     r = torch.as_tensor(g_rambo.get(case, "r")).to(dev())
     mom, wgt = gen.generateKinematics_batch(m["E_cm"], r, pT_mincut=m["cuts"][0], delR_mincut=m["cuts"][1],
                                             rap_maxcut=m["cuts"][2], pdgs=[2, -1])
