@@ -42,6 +42,16 @@ BATCH = 1_000_000
 K_CLASS = {"apply": 0, "stats": 1, "ingest": 2, "integrand": 3, "rambo": 4}
 
 
+def measured_traffic(kernel, steps_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_hbm_traffic.json: FETCH_SIZE x 2 +
+    WRITE_SIZE, gfx950 correction calibrated there), rescaled to this run's steps per launch; None if not profiled."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))[kernel]
+        return t["bytes_per_launch"] * steps_per_launch / t["steps_per_launch"]
+    except Exception:
+        return None
+
+
 def barrier_sync(ws):
     if ws > 1:
         dist.barrier()
@@ -125,7 +135,9 @@ def bench_flow(args, rank, ws, dev):
         roof = {"kernel": {"apply": "k_cell_apply", "stats": "k_bn_stats", "ingest": "k_ingest",
                            "integrand": "k_integrand_moments"}[args.roofline_kernel],
                 "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": measured_traffic({"apply": "k_cell_apply", "stats": "k_bn_stats", "ingest": "k_ingest"}.get(
+                    args.roofline_kernel, ""), gmean),
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches": kern_n, "steps_per_launch": gmean,
                 "algorithmic_bytes_per_launch": per_launch}
     return dict(dt=dt, samples=BATCH * args.steps * ws, sig=sig, sig_err=sig_err, roofline=roof, NF=NF)
@@ -158,7 +170,7 @@ def bench_rambo(args, rank, ws, dev):
     return {"metric": "2->4 massive RAMBO samples/sec at batch 1e6", "value": BATCH * args.steps * ws / dt,
             "unit": "samples/s", "ms_per_step": dt / args.steps * 1e3, "mean_weight": float(wgt.mean()),
             "roofline": {"kernel": "k_rambo<4>", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic("k_rambo<4>", 1),
                          "avg_launch_us": round(avg_s * 1e6, 2), "launches": kern_n,
                          "algorithmic_bytes_per_launch": per_launch}}
 
