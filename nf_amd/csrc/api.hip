@@ -107,6 +107,8 @@ extern "C" size_t nis_cell_running_count(const nis_cell_desc* c) {
 struct CellLayout {
   int WM, KM;
   size_t off_wp, off_wlast, off_bias, off_gb, off_coef, off_part, off_gstat;   // in doubles from the workspace body
+  size_t off_wm, off_wmlast, off_biaspad;                                      // matrix-core fragment images (WM >= 16)
+  int RT;                                                                      // row tiles of the last layer
 };
 
 struct nis_flow {
@@ -145,6 +147,13 @@ static size_t flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay
     L.off_coef = off;    off += (size_t)G * (nl + 1) * 2 * WM;
     L.off_gstat = off;   off += (size_t)G * (nl + 1) * 2 * WM;
     L.off_part = off;    off += (nl + 1) * (size_t)G * NIS_MAXB * WM * 3;
+    L.RT = (int)((R + 15) / 16);
+    L.off_wm = L.off_wmlast = L.off_biaspad = 0;
+    if (WM >= 16) {
+      L.off_wm = off;      off += nl * WM * WM;
+      L.off_wmlast = off;  off += (size_t)L.RT * 16 * WM;
+      L.off_biaspad = off; off += (size_t)L.RT * 16;
+    }
     if (lay) lay->push_back(L);
   }
   if (off_fpart) *off_fpart = off;
@@ -248,6 +257,33 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double*
     off += 2 * (size_t)F + (size_t)O * F;
     roff += 2 * F;
   }
+}
+
+// k_pack_mfma: padded row-major images -> per-(row tile, k-step) fragments of 64 contiguous doubles, lane l holding
+// W[16 jt + (l & 15)][4 q + (l >> 4)]  (the A operand of v_mfma_f64_16x16x4_f64).
+__global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int RT, const double* __restrict__ wp,
+                                                       const double* __restrict__ wlast, const double* __restrict__ bias,
+                                                       double* __restrict__ wm_all, double* __restrict__ wm_last,
+                                                       double* __restrict__ bias_pad) {
+  const size_t tid = (size_t)blockIdx.x * NIS_TPB + threadIdx.x, nth = (size_t)gridDim.x * NIS_TPB;
+  const int JT = WM / 16, KQ = WM / 4;
+  const size_t nh = (size_t)L * WM * WM;
+  for (size_t e = tid; e < nh; e += nth) {
+    const int lane = (int)(e & 63);
+    const size_t frag = e >> 6;
+    const int q = (int)(frag % KQ), jt = (int)((frag / KQ) % JT), l = (int)(frag / ((size_t)KQ * JT));
+    const int j = 16 * jt + (lane & 15), k = 4 * q + (lane >> 4);
+    wm_all[e] = wp[(size_t)l * WM * WM + (size_t)j * WM + k];
+  }
+  const size_t nl = (size_t)RT * KQ * 64;
+  for (size_t e = tid; e < nl; e += nth) {
+    const int lane = (int)(e & 63);
+    const size_t frag = e >> 6;
+    const int q = (int)(frag % KQ), jt = (int)(frag / KQ);
+    const int j = 16 * jt + (lane & 15), k = 4 * q + (lane >> 4);
+    wm_last[e] = j < R ? wlast[(size_t)j * WM + k] : 0.0;
+  }
+  for (size_t e = tid; e < (size_t)RT * 16; e += nth) bias_pad[e] = e < (size_t)R ? bias[e] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -577,9 +613,14 @@ struct RunOpts {
   int keep_planes = 1;             // 0 with f_kind >= 0: X / J are not stored
 };
 
+static bool use_mfma() {
+  static const int off = env_int("NIS_NO_MFMA", 0);
+  return !off;
+}
+
 template <int WM>
-static int run_cell(const CellK& c, double* planes, long ld, long N, int bn_mode, int km, int* bins, const FuseF& fz, bool need_stats0,
-                    int grid_stats, int grid_apply, hipStream_t s) {
+static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, long ld, long N, int bn_mode, int km, int* bins,
+                    const FuseF& fz, bool need_stats0, int grid_stats, int grid_apply, int grid_mf, hipStream_t s) {
   if (bn_mode == NIS_BN_TRAIN) {
     if (need_stats0) {
       NisProfScope ps(NIS_K_STATS, s);
@@ -589,17 +630,31 @@ static int run_cell(const CellK& c, double* planes, long ld, long N, int bn_mode
     for (int l = 1; l <= c.L; ++l) {
       {
         NisProfScope ps(NIS_K_STATS, s);
-        HIP_OK(launch_stats<WM>(c, planes, ld, N, l, grid_stats, s));
+        if (mfma)
+          HIP_OK(launch_stats_mfma<WM>(c, mw, planes, ld, N, l, grid_mf, s));
+        else
+          HIP_OK(launch_stats<WM>(c, planes, ld, N, l, grid_stats, s));
       }
       if (c.G > 1) HIP_OK(launch_finalize<WM>(c, l, s));
     }
   }
   {
     NisProfScope ps(NIS_K_APPLY, s);
-    HIP_OK(launch_apply<WM>(c, planes, ld, N, bn_mode == NIS_BN_TRAIN ? 1 : 0, km, bins, fz, grid_apply, s));
+    if (mfma)
+      HIP_OK(launch_apply_mfma<WM>(c, mw, planes, ld, N, bn_mode == NIS_BN_TRAIN ? 1 : 0, km, bins, grid_mf, s));
+    else
+      HIP_OK(launch_apply<WM>(c, planes, ld, N, bn_mode == NIS_BN_TRAIN ? 1 : 0, km, bins, fz, grid_apply, s));
   }
   if (bn_mode == NIS_BN_TRAIN && c.G > 1) HIP_OK(launch_running_update<WM>(c, s));
   return NIS_OK;
+}
+
+template <int WM>
+static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid) {
+  *ok = WM >= 16 && use_mfma() && mfma_supported<WM>(c);
+  // one wave owns 64 (WM <= 32) or 32 samples per pass; 4 waves per workgroup
+  const int per_wg = 4 * 16 * (WM <= 32 ? 4 : 2);
+  *grid = *ok ? grid_for(mfma_blocks_per_cu<WM>(c), G, N, per_wg) : 1;
 }
 
 static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, const double* const* params, double* const* running,
@@ -680,8 +735,21 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     for (int j = 0; j < d; ++j) c.in_plane[j] = cd.in_col[j];
     c.jplane = d;
     c.first = (ci == 0 && !o.w_has_jac) ? 1 : 0;
+    c.R = cell_R(cd);
+    c.out = cell_out(cd);
+    c.kind = cd.kind;
+    c.K = cd.K;
+    c.G = G;
+    bool mfma = false;
+    int grid_mf = 1;
+    switch (L.WM) {
+      case 16: mfma_plan<16>(c, G, N, &mfma, &grid_mf); break;
+      case 32: mfma_plan<32>(c, G, N, &mfma, &grid_mf); break;
+      case 64: mfma_plan<64>(c, G, N, &mfma, &grid_mf); break;
+      default: break;
+    }
     c.nparts[0] = have_stats0 ? prev_records : grid_stats;
-    for (int l = 1; l <= cd.n_hidden; ++l) c.nparts[l] = grid_stats;
+    for (int l = 1; l <= cd.n_hidden; ++l) c.nparts[l] = mfma ? grid_mf : grid_stats;
     c.maxb = NIS_MAXB;
     c.bins_row = f->bins_row[ci];
     c.wp = body + L.off_wp;
@@ -743,15 +811,25 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       hipLaunchKernelGGL(k_pack, dim3(std::max(1, pgrid)), dim3(NIS_TPB), 0, s, c, L.WM, params[ci], (const double*)running[ci],
                          train ? 0 : 1, body + L.off_wp, body + L.off_wlast, body + L.off_bias, body + L.off_gb);
       HIP_OK(hipGetLastError());
+      if (mfma) {
+        hipLaunchKernelGGL(k_pack_mfma, dim3(std::max(1, pgrid)), dim3(NIS_TPB), 0, s, L.WM, c.L, c.R, L.RT,
+                           (const double*)(body + L.off_wp), (const double*)(body + L.off_wlast), (const double*)(body + L.off_bias),
+                           body + L.off_wm, body + L.off_wmlast, body + L.off_biaspad);
+        HIP_OK(hipGetLastError());
+      }
     }
+    MfmaW mw;
+    mw.wm_all = body + L.off_wm;
+    mw.wm_last = body + L.off_wmlast;
+    mw.bias_pad = body + L.off_biaspad;
     int rc;
     const bool need0 = !have_stats0;
     switch (L.WM) {
-      case 4: rc = run_cell<4>(c, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, s); break;
-      case 8: rc = run_cell<8>(c, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, s); break;
-      case 16: rc = run_cell<16>(c, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, s); break;
-      case 32: rc = run_cell<32>(c, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, s); break;
-      case 64: rc = run_cell<64>(c, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, s); break;
+      case 4: rc = run_cell<4>(c, mw, false, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, s); break;
+      case 8: rc = run_cell<8>(c, mw, false, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, s); break;
+      case 16: rc = run_cell<16>(c, mw, mfma, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, s); break;
+      case 32: rc = run_cell<32>(c, mw, mfma, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, s); break;
+      case 64: rc = run_cell<64>(c, mw, mfma, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, s); break;
       default: rc = NIS_E_UNSUPPORTED;
     }
     if (rc != NIS_OK) return rc;

@@ -509,6 +509,21 @@ hipError_t launch_running_update(const CellK& c, hipStream_t s);
 template <int WM>
 hipError_t launch_apply(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz, int grid,
                         hipStream_t s);
+// matrix-core path (WM >= 16): weight fragments pre-packed per (row tile, k-step) as 64 contiguous doubles
+struct MfmaW {
+  const double* wm_all;      // L x (WM/16) x (WM/4) x 64
+  const double* wm_last;     // RT x (WM/4) x 64,  RT = ceil(R/16)
+  const double* bias_pad;    // RT x 16
+};
+template <int WM>
+bool mfma_supported(const CellK& c);                        // LDS image of one column batch fits
+template <int WM>
+int mfma_blocks_per_cu(const CellK& c);
+template <int WM>
+hipError_t launch_stats_mfma(const CellK& c, const MfmaW& w, const double* planes, long ld, long N, int layer, int grid, hipStream_t s);
+template <int WM>
+hipError_t launch_apply_mfma(const CellK& c, const MfmaW& w, double* planes, long ld, long N, int bn_train, int km, int* bins, int grid,
+                             hipStream_t s);
 #define NIS_DECL_WM(W)                                                                                                      \
   template <>                                                                                                               \
   int stats_blocks_per_cu<W>();                                                                                             \
@@ -522,7 +537,17 @@ hipError_t launch_apply(const CellK& c, double* planes, long ld, long N, int bn_
   hipError_t launch_running_update<W>(const CellK& c, hipStream_t s);                                                       \
   template <>                                                                                                               \
   hipError_t launch_apply<W>(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz, \
-                             int grid, hipStream_t s);
+                             int grid, hipStream_t s);                                                                      \
+  template <>                                                                                                               \
+  bool mfma_supported<W>(const CellK& c);                                                                                   \
+  template <>                                                                                                               \
+  int mfma_blocks_per_cu<W>(const CellK& c);                                                                                \
+  template <>                                                                                                               \
+  hipError_t launch_stats_mfma<W>(const CellK& c, const MfmaW& w, const double* planes, long ld, long N, int layer, int grid, \
+                                  hipStream_t s);                                                                           \
+  template <>                                                                                                               \
+  hipError_t launch_apply_mfma<W>(const CellK& c, const MfmaW& w, double* planes, long ld, long N, int bn_train, int km, int* bins, \
+                                  int grid, hipStream_t s);
 NIS_DECL_WM(4)
 NIS_DECL_WM(8)
 NIS_DECL_WM(16)

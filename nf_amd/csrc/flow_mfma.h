@@ -1,0 +1,301 @@
+// Wide conditioners (register width WM >= 16) on the f64 matrix cores: v_mfma_f64_16x16x4_f64.
+//
+// Orientation: C[j][s] = sum_k W[j][k] * H[k][s]  (rows = output features, columns = 16 samples), i.e.
+//   A operand = weights, lane l holds W[16*jt + (l&15)][4*q + (l>>4)]      (pre-packed per (jt,q) as 64 contiguous doubles)
+//   B operand = activations, lane l holds H[4*q + (l>>4)][sample l&15]
+//   C/D: lane l holds rows (l>>4) + 4*r (r = 0..3) of column l&15    (probed on gfx950: tools/probe/mfma_f64_layout.hip)
+// so accumulator register r of output tile jt IS the B operand of k-step q = 4*jt + r of the next layer: the hidden
+// stack runs register-to-register with no LDS and no cross-lane traffic.  BN + ReLU are applied to the accumulators
+// (per-lane feature index -> coefficient read from LDS).  A wave owns ST tiles of 16 samples, so every weight
+// fragment feeds ST MFMAs.
+//
+// The last layer is produced in column batches (NCB transformed columns = NCB*out rows at a time): its exp() values
+// go through a per-wave LDS image [row][16 samples] and are read back one (sample, column) per lane, where the SAME
+// pwquad_column<> / streamed PWLin code as the narrow kernels finishes the cell (bit-identical bin selection).
+#pragma once
+#include "flow_kernels.h"
+
+typedef double nis_d4 __attribute__((ext_vector_type(4)));
+
+#define NIS_MF_TPB 256                 // 4 waves, one per SIMD
+#define NIS_MF_NCB 4                   // transformed columns per bijector batch (4 x 16 samples = 64 lanes)
+
+template <int WM>
+struct MfCfg {
+  static constexpr int ST = WM <= 32 ? 4 : 2;      // sample tiles (of 16) per wave
+  static constexpr int JT = WM / 16;               // output row tiles of a hidden layer
+  static constexpr int KQ = WM / 4;                // k-steps of a hidden layer
+};
+
+// Load the pass-through block as B operands and apply BN_0:  H[q][st] = sc0[k]*x[k][s] + sh0[k],  k = 4q + (lane>>4).
+template <int WM>
+__device__ __forceinline__ void mf_load_input(const CellK& c, const double* planes, long ld, long N, long base, const int* lds_plane,
+                                              const double* lds_coef, double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST]) {
+  constexpr int ST = MfCfg<WM>::ST, KQ = MfCfg<WM>::KQ;
+  const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = 4 * q + g;
+    const bool kv = k < c.P;
+    const size_t pl = kv ? (size_t)lds_plane[k] * ld : 0;
+    const double sc = kv ? lds_coef[k] : 0.0, sh = kv ? lds_coef[WM + k] : 0.0;
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+      const long i = base + 16 * st + s;
+      const double x = (kv && i < N && 4 * q < c.P) ? planes[pl + i] : 0.0;
+      H[q][st] = kv ? fma(x, sc, sh) : 0.0;
+    }
+  }
+}
+
+// One hidden Linear on the matrix cores: acc[jt][st] = sum_q Wm[jt][q] (x) H[q][st];  nq = k-steps actually populated.
+template <int WM>
+__device__ __forceinline__ void mf_dense(const double* __restrict__ wm, int nq, const double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST],
+                                         nis_d4 (&acc)[MfCfg<WM>::JT][MfCfg<WM>::ST]) {
+  constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+    for (int st = 0; st < ST; ++st) acc[jt][st] = nis_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      if (q < nq) {
+        const double a = wm[((size_t)jt * KQ + q) * 64 + lane];
+#pragma unroll
+        for (int st = 0; st < ST; ++st) acc[jt][st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, H[q][st], acc[jt][st], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// BN_l + ReLU on the accumulators -> B operands of the next layer (feature j = 16 jt + (lane>>4) + 4 r  ->  k-step 4 jt + r).
+template <int WM>
+__device__ __forceinline__ void mf_bn_relu(const double* lds_coef_l, const nis_d4 (&acc)[MfCfg<WM>::JT][MfCfg<WM>::ST],
+                                           double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST]) {
+  constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT;
+  const int g = (threadIdx.x & 63) >> 4;
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * jt + g + 4 * r;
+      const double sc = lds_coef_l[j], sh = lds_coef_l[WM + j];
+#pragma unroll
+      for (int st = 0; st < ST; ++st) H[4 * jt + r][st] = fmax(fma(acc[jt][st][r], sc, sh), 0.0);
+    }
+}
+
+// Hidden stack up to (excluding) BN layer `upto` (1..L): leaves the pre-BN accumulators of that layer in acc.
+template <int WM>
+__device__ __forceinline__ void mf_hidden(const CellK& c, const double* wm_all, const double* lds_coef, int upto,
+                                          double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST], nis_d4 (&acc)[MfCfg<WM>::JT][MfCfg<WM>::ST]) {
+  for (int l = 0; l < upto; ++l) {
+    const int nq = l == 0 ? (c.P + 3) / 4 : MfCfg<WM>::KQ;
+    mf_dense<WM>(wm_all + (size_t)l * WM * WM, nq, H, acc);
+    if (l + 1 < upto) mf_bn_relu<WM>(lds_coef + (size_t)(l + 1) * 2 * WM, acc, H);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batch statistics of BN layer `layer` >= 1 (pre-BN accumulators of Linear_{layer-1}).
+template <int WM>
+__global__ __launch_bounds__(NIS_MF_TPB) void k_bn_stats_mfma(CellK c, const double* __restrict__ planes, long ld, long N, int layer,
+                                                              const double* __restrict__ wm_all) {
+  constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ, NW = NIS_MF_TPB / 64;
+  __shared__ double lds_coef[NIS_MAX_HIDDEN * 2 * WM];
+  __shared__ double red[3 * NIS_MF_TPB];
+  __shared__ int lds_plane[NIS_MAX_DIM];
+  __shared__ double wmom[NW][WM][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
+  const int g = blockIdx.y;
+  planes += (size_t)g * c.plane_gs;
+  if (tid < NIS_MAX_DIM) lds_plane[tid] = c.in_plane[tid];
+  load_coefs<WM, NIS_MF_TPB>(c, g, layer, c.G == 1 ? layer - 1 : -1, blockIdx.x == 0, lds_coef, red);
+
+  double S1[JT][4], S2[JT][4], shf[JT][4];
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S1[jt][r] = S2[jt][r] = shf[jt][r] = 0.0;
+  double cnt = 0.0;
+  bool first = true;
+  const long wstride = (long)gridDim.x * NW * 16 * ST;
+  for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
+    double H[KQ][ST];
+    nis_d4 acc[JT][ST];
+    mf_load_input<WM>(c, planes, ld, N, base, lds_plane, lds_coef, H);
+    mf_hidden<WM>(c, wm_all, lds_coef, layer, H, acc);
+    if (first) {                       // shift = value of the wave's first sample (lane with s == 0 of each row group)
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) shf[jt][r] = __shfl(acc[jt][0][r], lane & 48, 64);
+      first = false;
+    }
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+      const bool ok = base + 16 * st + s < N;
+      if (gq == 0 && ok) cnt += 1.0;
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double t = ok ? acc[jt][st][r] - shf[jt][r] : 0.0;
+          S1[jt][r] += t;
+          S2[jt][r] = fma(t, t, S2[jt][r]);
+        }
+    }
+  }
+  // reduce over the 16 samples of a row group (lanes with equal lane>>4), then over the count (held by group 0)
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        S1[jt][r] += __shfl_xor(S1[jt][r], o, 64);
+        S2[jt][r] += __shfl_xor(S2[jt][r], o, 64);
+      }
+  }
+  const double nw = __shfl(cnt, 0, 64);
+  if (s == 0) {
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jt + gq + 4 * r;
+        const bool any = nw > 0.0;
+        wmom[wave][j][0] = nw;
+        wmom[wave][j][1] = any ? shf[jt][r] + S1[jt][r] / nw : 0.0;
+        wmom[wave][j][2] = any ? fmax(S2[jt][r] - S1[jt][r] * S1[jt][r] / nw, 0.0) : 0.0;
+      }
+  }
+  __syncthreads();
+  if (tid < WM) {
+    Mom t = {0.0, 0.0, 0.0};
+    for (int w = 0; w < NW; ++w) {
+      Mom m = {wmom[w][tid][0], wmom[w][tid][1], wmom[w][tid][2]};
+      t = mom_merge(t, m);
+    }
+    double* out = c.partials + ((((size_t)layer * c.G + g) * c.maxb + blockIdx.x) * WM + tid) * 3;
+    out[0] = t.n;
+    out[1] = t.mean;
+    out[2] = t.m2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Full cell with the conditioner on the matrix cores.
+template <int KIND, int WM, int KM, bool KEXACT>
+__global__ __launch_bounds__(NIS_MF_TPB) void k_cell_apply_mfma(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
+                                                                int* __restrict__ bins_out, const double* __restrict__ wm_all,
+                                                                const double* __restrict__ wm_last, const double* __restrict__ bias_pad) {
+  constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ, NW = NIS_MF_TPB / 64, NCB = NIS_MF_NCB;
+  extern __shared__ double mf_dyn[];                 // per wave: [NCB*out rows][16 samples]
+  __shared__ double lds_coef[(NIS_MAX_HIDDEN + 1) * 2 * WM];
+  __shared__ double red[3 * NIS_MF_TPB];
+  __shared__ int lds_plane[NIS_MAX_DIM];
+  __shared__ double etab[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
+  const int g = blockIdx.y;
+  planes += (size_t)g * c.plane_gs;
+  if (tid < NIS_MAX_DIM) lds_plane[tid] = c.in_plane[tid];
+  nis_exp_init(etab);
+  load_coefs<WM, NIS_MF_TPB>(c, g, c.L + 1, (bn_train && c.G == 1) ? c.L : -1, blockIdx.x == 0, lds_coef, red);
+  const int out = c.out;
+  double* ring = mf_dyn + (size_t)wave * NCB * out * 16;
+  const int Kq = KEXACT ? KM : c.K;
+  const long wstride = (long)gridDim.x * NW * 16 * ST;
+  for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
+    double H[KQ][ST];
+    {
+      nis_d4 acc[JT][ST];
+      mf_load_input<WM>(c, planes, ld, N, base, lds_plane, lds_coef, H);
+      mf_hidden<WM>(c, wm_all, lds_coef, c.L, H, acc);
+      mf_bn_relu<WM>(lds_coef + (size_t)c.L * 2 * WM, acc, H);
+    }
+    // ---- last layer + bijector, one tile of 16 samples and NCB columns at a time
+#pragma unroll 1
+    for (int st = 0; st < ST; ++st) {
+      double jprod = 1.0;                            // this lane's columns (t = NCB*cb + gq) of sample s
+#pragma unroll 1
+      for (int cb = 0; cb * NCB < c.T; ++cb) {
+        const int r0 = cb * NCB * out;
+        const int r1 = min(c.R, r0 + NCB * out);
+        for (int jt = r0 / 16; jt * 16 < r1; ++jt) {
+          nis_d4 z;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z[r] = bias_pad[16 * jt + gq + 4 * r];
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) {
+            const double a = wm_last[((size_t)jt * KQ + q) * 64 + lane];
+            // sample tile st is a runtime index: select the operand with a uniform switch (registers stay static)
+            double hb = H[q][0];
+#pragma unroll
+            for (int u = 1; u < ST; ++u) hb = (st == u) ? H[q][u] : hb;
+            z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, hb, z, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + gq + 4 * r - r0;
+            if (j >= 0 && j < NCB * out && 16 * jt + gq + 4 * r < c.R) ring[j * 16 + s] = nis_exp(z[r], etab);
+          }
+        }
+        // (sample s, column t) per lane.  A wave executes in lock step and its LDS operations complete in order:
+        // the image written above is complete; the wave barriers only pin the compiler's schedule.
+        __builtin_amdgcn_wave_barrier();
+        const int t = cb * NCB + gq;
+        const long i = base + 16 * st + s;
+        if (t < c.T && i < N) {
+          double* col = planes + (size_t)lds_plane[c.P + t] * ld;
+          const double xb = col[i];
+          const double* zr = ring + (size_t)gq * out * 16 + s;
+          double y, jf;
+          int bin;
+          if (KIND == NIS_PWQUAD) {
+            double V[KM + 1], W[KM];
+#pragma unroll
+            for (int k = 0; k < KM + 1; ++k) V[k] = (KEXACT || k <= c.K) ? zr[k * 16] : 0.0;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) W[k] = (KEXACT || k < c.K) ? zr[(Kq + 1 + k) * 16] : 0.0;
+            y = pwquad_column<KM, KEXACT>(xb, c.K, V, W, &jf, &bin);
+          } else {
+            const double ak = xb * c.K;
+            const double bf = floor(ak);
+            const double alpha = (ak - bf) / c.K;
+            bin = (int)bf;
+            double tot = 0.0, below = 0.0, qb = 0.0;
+            for (int k = 0; k < c.K; ++k) {
+              const double e = zr[k * 16];
+              const bool hit = k == bin;
+              below = hit ? tot : below;
+              qb = hit ? e : qb;
+              tot += e;
+            }
+            if (bin < 0 || bin >= c.K) {
+              if (c.status) atomicOr(c.status, 1);
+              qb = __builtin_nan("");
+            }
+            const double qn = qb / (tot / c.K);
+            y = qn * alpha + below / tot;
+            jf = qn;
+          }
+          col[i] = y;
+          jprod *= jf;
+          if (bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      // product over this sample's columns: 4 lanes (row groups) share a sample
+      jprod *= __shfl_xor(jprod, 16, 64);
+      jprod *= __shfl_xor(jprod, 32, 64);
+      const long i = base + 16 * st + s;
+      if (gq == 0 && i < N) {
+        double* jp = planes + (size_t)c.jplane * ld;
+        jp[i] = (c.first ? 1.0 : jp[i]) * jprod;
+      }
+    }
+  }
+}

@@ -104,3 +104,67 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
   }
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// matrix-core (MFMA f64) variants for wide conditioners
+#if NIS_WM >= 16
+#include "flow_mfma.h"
+
+static size_t mf_ring_bytes(const CellK& c) { return (size_t)(NIS_MF_TPB / 64) * NIS_MF_NCB * c.out * 16 * sizeof(double); }
+
+template <>
+bool mfma_supported<NIS_WM>(const CellK& c) {
+  return mf_ring_bytes(c) + 24 * 1024 <= 160 * 1024 && (c.kind == NIS_PWLIN || c.K <= 32);
+}
+
+template <>
+int mfma_blocks_per_cu<NIS_WM>(const CellK& c) {
+  (void)c;
+  return 1;                                        // ~300 VGPR+AGPR per lane: one wave per SIMD
+}
+
+template <>
+hipError_t launch_stats_mfma<NIS_WM>(const CellK& c, const MfmaW& w, const double* planes, long ld, long N, int layer, int grid,
+                                     hipStream_t s) {
+  hipLaunchKernelGGL((k_bn_stats_mfma<NIS_WM>), dim3(grid, c.G), dim3(NIS_MF_TPB), 0, s, c, planes, ld, N, layer, w.wm_all);
+  return hipGetLastError();
+}
+
+#define NIS_APPLY_MF(KIND, KMV, EX)                                                                                               \
+  hipLaunchKernelGGL((k_cell_apply_mfma<KIND, NIS_WM, KMV, EX>), dim3(grid, c.G), dim3(NIS_MF_TPB), mf_ring_bytes(c), s, c, planes, ld, \
+                     N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad)
+
+template <>
+hipError_t launch_apply_mfma<NIS_WM>(const CellK& c, const MfmaW& w, double* planes, long ld, long N, int bn_train, int km, int* bins,
+                                     int grid, hipStream_t s) {
+  if (c.kind == NIS_PWLIN) {
+    NIS_APPLY_MF(NIS_PWLIN, 4, false);
+  } else {
+    switch (km) {
+      case 4: NIS_APPLY_MF(NIS_PWQUAD, 4, false); break;
+      case 8: NIS_APPLY_MF(NIS_PWQUAD, 8, false); break;
+      case 16: NIS_APPLY_MF(NIS_PWQUAD, 16, false); break;
+      case 32: NIS_APPLY_MF(NIS_PWQUAD, 32, false); break;
+      case -4: NIS_APPLY_MF(NIS_PWQUAD, 4, true); break;
+      case -8: NIS_APPLY_MF(NIS_PWQUAD, 8, true); break;
+      case -16: NIS_APPLY_MF(NIS_PWQUAD, 16, true); break;
+      case -32: NIS_APPLY_MF(NIS_PWQUAD, 32, true); break;
+      default: return hipErrorInvalidValue;
+    }
+  }
+  return hipGetLastError();
+}
+#else
+template <>
+bool mfma_supported<NIS_WM>(const CellK&) { return false; }
+template <>
+int mfma_blocks_per_cu<NIS_WM>(const CellK&) { return 1; }
+template <>
+hipError_t launch_stats_mfma<NIS_WM>(const CellK&, const MfmaW&, const double*, long, long, int, int, hipStream_t) {
+  return hipErrorInvalidValue;
+}
+template <>
+hipError_t launch_apply_mfma<NIS_WM>(const CellK&, const MfmaW&, double*, long, long, int, int, int*, int, hipStream_t) {
+  return hipErrorInvalidValue;
+}
+#endif
