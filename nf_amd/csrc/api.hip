@@ -652,8 +652,8 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
 template <int WM>
 static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid) {
   *ok = WM >= 16 && use_mfma() && mfma_supported<WM>(c);
-  // one wave owns 64 (WM <= 32) or 32 samples per pass; 4 waves per workgroup
-  const int per_wg = 4 * 16 * (WM <= 32 ? 4 : 2);
+  // one wave owns 2 tiles of 16 samples per pass; 4 waves per workgroup
+  const int per_wg = 4 * 16 * 2;
   *grid = *ok ? grid_for(mfma_blocks_per_cu<WM>(c), G, N, per_wg) : 1;
 }
 

@@ -22,7 +22,8 @@ typedef double nis_d4 __attribute__((ext_vector_type(4)));
 
 template <int WM>
 struct MfCfg {
-  static constexpr int ST = WM <= 32 ? 4 : 2;      // sample tiles (of 16) per wave
+  static constexpr int ST = 2;                     // sample tiles (of 16) per wave: keeps VGPR+AGPR <= 256 -> 2 waves/SIMD,
+                                                   // so one wave's MFMA phase overlaps the other's VALU (exp / bijector) phase
   static constexpr int JT = WM / 16;               // output row tiles of a hidden layer
   static constexpr int KQ = WM / 4;                // k-steps of a hidden layer
 };
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(NIS_MF_TPB) void k_bn_stats_mfma(CellK c, const dou
 // ---------------------------------------------------------------------------------------------
 // Full cell with the conditioner on the matrix cores.
 template <int KIND, int WM, int KM, bool KEXACT>
-__global__ __launch_bounds__(NIS_MF_TPB) void k_cell_apply_mfma(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
+__global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfma(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                                 int* __restrict__ bins_out, const double* __restrict__ wm_all,
                                                                 const double* __restrict__ wm_last, const double* __restrict__ bias_pad) {
   constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ, NW = NIS_MF_TPB / 64, NCB = NIS_MF_NCB;
@@ -220,6 +221,13 @@ __global__ __launch_bounds__(NIS_MF_TPB) void k_cell_apply_mfma(CellK c, double*
 #pragma unroll 1
     for (int st = 0; st < ST; ++st) {
       double jprod = 1.0;                            // this lane's columns (t = NCB*cb + gq) of sample s
+      double Hs[KQ];                                 // B operands of this sample tile (st is a runtime index: select once)
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        Hs[q] = H[q][0];
+#pragma unroll
+        for (int u = 1; u < ST; ++u) Hs[q] = (st == u) ? H[q][u] : Hs[q];
+      }
 #pragma unroll 1
       for (int cb = 0; cb * NCB < c.T; ++cb) {
         const int r0 = cb * NCB * out;
@@ -231,11 +239,7 @@ __global__ __launch_bounds__(NIS_MF_TPB) void k_cell_apply_mfma(CellK c, double*
 #pragma unroll
           for (int q = 0; q < KQ; ++q) {
             const double a = wm_last[((size_t)jt * KQ + q) * 64 + lane];
-            // sample tile st is a runtime index: select the operand with a uniform switch (registers stay static)
-            double hb = H[q][0];
-#pragma unroll
-            for (int u = 1; u < ST; ++u) hb = (st == u) ? H[q][u] : hb;
-            z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, hb, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Hs[q], z, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

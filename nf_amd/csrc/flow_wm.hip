@@ -119,8 +119,9 @@ bool mfma_supported<NIS_WM>(const CellK& c) {
 
 template <>
 int mfma_blocks_per_cu<NIS_WM>(const CellK& c) {
-  (void)c;
-  return 1;                                        // ~300 VGPR+AGPR per lane: one wave per SIMD
+  const size_t lds = mf_ring_bytes(c) + 12 * 1024;
+  int n = (int)(160 * 1024 / lds);
+  return n < 1 ? 1 : n > 2 ? 2 : n;               // <= 256 VGPR+AGPR per lane: two waves per SIMD when the LDS images fit
 }
 
 template <>
