@@ -129,6 +129,25 @@ int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_b
                         double* planes, int64_t ld, int32_t keep_planes, double* fres_out, double* out4,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* Training forward + hand-written adjoint (replaces loss.backward() through the flow, manager.py:275-278, for the
+ * cell class the adjoint kernels cover: register width 4, one transformed column, PWQuad n_bins <= 4 / PWLin
+ * n_bins <= 12 -- README / C1 / C2 models; nis_flow_backward_supported tells).
+ *   nis_flow_forward_train: train-mode forward that keeps every cell's input: planes_hist holds n_cells+1 plane
+ *     sets of (d+1, ld) doubles (set c = input of cell c, last set = model output); bnsave
+ *     (nis_flow_bnsave_count doubles) receives scale | shift | batch mean | rstd of every BN layer.
+ *   nis_flow_backward: gxj = dL/dXJ (N, d+1) row-major in output column order -> gparams[c] = dL/d(parameter
+ *     blob of cell c) (same layout as params[c], overwritten) and optionally gx_out = dL/d(input) (N, d+1). */
+int nis_flow_backward_supported(const nis_flow* f);
+size_t nis_flow_bnsave_count(const nis_flow* f);
+int nis_flow_forward_train(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N,
+                           const double* const* params, double* const* running, long long* const* tracked,
+                           int64_t pack_token, double* planes_hist, int64_t ld, double* bnsave, double* xj_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+size_t nis_flow_backward_workspace_bytes(const nis_flow* f, int64_t N);
+int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
+                      const double* const* params, const double* bnsave, const double* gxj,
+                      double* const* gparams, double* gx_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* f(X)*J for a built-in integrand straight from the planes + streaming moments of the result:
  * out4 = {count, mean, M2 = sum (v-mean)^2, max}   (torch.mean/var/max at manager.py:399-400,
  * :241-249).  fres_out (N) optional.  workspace >= nis_moments_workspace_bytes(). */

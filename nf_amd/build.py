@@ -17,7 +17,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
-UNITS = [("api", "api.hip", []), ("rambo", "rambo.hip", [])] + \
+UNITS = [("api", "api.hip", []), ("rambo", "rambo.hip", []), ("flow_bwd", "flow_bwd.hip", [])] + \
         [(f"flow_wm{w}", "flow_wm.hip", [f"-DNIS_WM={w}"]) for w in (4, 8, 16, 32, 64)]
 
 

@@ -359,6 +359,27 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest(const TIN* __restrict__ w, l
   if (st.P > 0) emit_records<NF, NW>(S1, S2, cnt, wshift, wmom, st.P, st.partials + ((size_t)g * st.maxb + blockIdx.x) * st.wm * 3);
 }
 
+// inverse of k_emit: column c of the row-major (N, cols) matrix goes to plane m.col[c]
+__global__ __launch_bounds__(NIS_TPB) void k_scatter_rows(const double* __restrict__ src, long N, int cols, ColMap m,
+                                                          double* __restrict__ planes, long ld) {
+  extern __shared__ double tile[];
+  const long nblk = (N + NIS_TPB - 1) / NIS_TPB;
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long i0 = blk * NIS_TPB;
+    const int ns = (int)min((long)NIS_TPB, N - i0);
+    const int tot = ns * cols;
+    for (int e = threadIdx.x; e < tot; e += NIS_TPB) {
+      const int r = e / cols, cidx = e - r * cols;
+      tile[r * cols + cidx + r / 32] = src[i0 * cols + e];
+    }
+    __syncthreads();
+    const int s = threadIdx.x;
+    if (s < ns)
+      for (int cidx = 0; cidx < cols; ++cidx) planes[(size_t)m.col[cidx] * ld + i0 + s] = tile[s * cols + cidx + s / 32];
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(NIS_TPB) void k_emit(const double* __restrict__ planes, long ld, long N, int d, ColMap m,
                                                   double* __restrict__ xj) {
   extern __shared__ double tile[];
@@ -611,7 +632,15 @@ struct RunOpts {
   double* fres_out = nullptr;
   double* out4 = nullptr;
   int keep_planes = 1;             // 0 with f_kind >= 0: X / J are not stored
+  int hist = 0;                    // 1: `planes` holds n_cells+1 plane sets; cell c reads set c and writes set c+1
+  double* bnsave = nullptr;        // hist: per cell (L+1) x 4 x WM saved BN scale | shift | mean | rstd
 };
+
+// declared in flow_bwd.hip
+bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm);
+size_t nis_bwd_cell_workspace_doubles(int L, int64_t N);
+int nis_bwd_cell_run(const CellK& c, const double* x, const double* xo, double* g, const double* bnsave, long ld, long N, double* ws,
+                     double* gparams, hipStream_t s);
 
 static bool use_mfma() {
   static const int off = env_int("NIS_NO_MFMA", 0);
@@ -664,7 +693,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   if (w_dtype != NIS_F64 && w_dtype != NIS_F32) return NIS_E_ARG;
   const int G = o.G;
   if (G < 1 || G > 65535) return NIS_E_ARG;
-  if (G > 1 && (o.xj_out || o.bins_out || o.w_has_jac)) return NIS_E_UNSUPPORTED;
+  if (G > 1 && (o.xj_out || o.bins_out || o.w_has_jac || o.hist)) return NIS_E_UNSUPPORTED;
   if (!workspace || workspace_bytes < nis_flow_workspace_bytes(f, G)) return NIS_E_WORKSPACE;
   std::vector<CellLayout> lay;
   size_t off_fpart = 0;
@@ -709,9 +738,12 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
 
   int prev_records = tgrid;           // records of BN_0 of the current cell written by the previous launch
   bool have_stats0 = ingest_stats;
+  double* const planes0 = planes;
+  size_t bn_off = 0;
   for (int ci = 0; ci < f->n_cells; ++ci) {
     const nis_cell_desc& cd = f->cells[ci];
     const CellLayout& L = lay[ci];
+    if (o.hist) planes = planes0 + (size_t)ci * plane_gs;
     if (!params[ci] || !running[ci]) return NIS_E_ARG;
     int grid_stats = 1, grid_apply = 1;
     switch (L.WM) {
@@ -765,6 +797,9 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     c.G = G;
     c.coef_gs = train ? (cd.n_hidden + 1) * 2 * L.WM : 0;     // eval: every batch shares the running-stat coefficients
     c.plane_gs = plane_gs;
+    c.out_off = o.hist ? plane_gs : 0;
+    c.bnsave = (o.hist && o.bnsave && train) ? o.bnsave + bn_off : nullptr;
+    bn_off += (size_t)(cd.n_hidden + 1) * 4 * L.WM;
     // rider 1: BN_0 records of the next cell (every state column is in this thread's registers)
     bool next_rider = false;
     if (train && ci + 1 < f->n_cells && L.WM <= 8 && f->cells[ci + 1].P <= (L.WM <= 4 ? 4 : NIS_PMAX_FUSED)) {
@@ -853,6 +888,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   f->packed_ws = workspace;
   f->packed_G = G;
   for (int ci = 0; ci < f->n_cells; ++ci) f->packed_params[ci] = params[ci];
+  if (o.hist) planes = planes0 + (size_t)f->n_cells * plane_gs;      // the final state lives in the last plane set
   if (o.xj_out) {
     ColMap m;
     for (int j = 0; j < d; ++j) m.col[j] = f->out_col[j];
@@ -895,4 +931,134 @@ extern "C" int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, 
   o.out4 = out4;
   o.keep_planes = keep_planes;
   return flow_run(f, w, w_dtype, N, params, running, planes, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// training forward with history + hand-written adjoint
+static int cell_wm(const nis_cell_desc& c) {
+  int m = c.P;
+  for (int l = 0; l < c.n_hidden; ++l) m = std::max(m, c.width[l]);
+  return nis_pick_wm(m);
+}
+
+extern "C" int nis_flow_backward_supported(const nis_flow* f) {
+  if (!f) return 0;
+  for (int ci = 0; ci < f->n_cells; ++ci)
+    if (!nis_bwd_cell_supported(f->cells[ci], cell_wm(f->cells[ci]))) return 0;
+  return 1;
+}
+
+extern "C" size_t nis_flow_bnsave_count(const nis_flow* f) {
+  size_t n = 0;
+  for (int ci = 0; ci < f->n_cells; ++ci) n += (size_t)(f->cells[ci].n_hidden + 1) * 4 * cell_wm(f->cells[ci]);
+  return n;
+}
+
+extern "C" int nis_flow_forward_train(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N,
+                                      const double* const* params, double* const* running, long long* const* tracked,
+                                      int64_t pack_token, double* planes_hist, int64_t ld, double* bnsave, double* xj_out,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!planes_hist || !bnsave) return NIS_E_ARG;
+  RunOpts o;
+  o.w_has_jac = w_has_jac;
+  o.bn_mode = NIS_BN_TRAIN;
+  o.pack_token = pack_token;
+  o.tracked = tracked;
+  o.xj_out = xj_out;
+  o.hist = 1;
+  o.bnsave = bnsave;
+  return flow_run(f, w, w_dtype, N, params, running, planes_hist, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
+}
+
+extern "C" size_t nis_flow_backward_workspace_bytes(const nis_flow* f, int64_t N) {
+  size_t cellws = 0, pk = 0;
+  std::vector<CellLayout> lay;
+  flow_layout(f, 1, &lay, nullptr);
+  for (int ci = 0; ci < f->n_cells; ++ci) {
+    cellws = std::max(cellws, nis_bwd_cell_workspace_doubles(f->cells[ci].n_hidden, N));
+    const size_t WM = lay[ci].WM, R = cell_R(f->cells[ci]), nl = f->cells[ci].n_hidden;
+    pk = std::max(pk, nl * WM * WM + R * WM + (R + 7) / 8 * 8 + 2 * (nl + 1) * 2 * WM);
+  }
+  return ((size_t)(f->d + 1) * N + cellws + pk + 64) * sizeof(double);
+}
+
+extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
+                                 const double* const* params, const double* bnsave, const double* gxj, double* const* gparams,
+                                 double* gx_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!f || !planes_hist || !params || !bnsave || !gxj || !gparams || N < 1 || ld < N) return NIS_E_ARG;
+  if (!nis_flow_backward_supported(f)) return NIS_E_UNSUPPORTED;
+  if (!workspace || workspace_bytes < nis_flow_backward_workspace_bytes(f, N)) return NIS_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int d = f->d;
+  const long set = (long)(d + 1) * ld;
+  double* g = (double*)workspace;                       // gradient planes (d+1, ld)
+  double* cellws = g + (size_t)(d + 1) * N;
+  size_t cw = 0;
+  for (int ci = 0; ci < f->n_cells; ++ci) cw = std::max(cw, nis_bwd_cell_workspace_doubles(f->cells[ci].n_hidden, N));
+  double* pk = cellws + cw;
+  std::vector<CellLayout> lay;
+  flow_layout(f, 1, &lay, nullptr);
+  const int tgrid = grid_for(8, 1, N, NIS_TPB);
+  const size_t tile_bytes = ((size_t)NIS_TPB * (d + 1) + 16) * sizeof(double);
+  // dL/dXJ (N, d+1) row-major in the model's OUTPUT column order -> gradient planes in plane order
+  {
+    IngestStats ist;
+    memset(&ist, 0, sizeof(ist));
+    ist.plane_gs = set;
+    // logical output column c lives in plane out_col[c]: ingest writes plane index = input column index, so permute
+    // by ingesting into a scratch set and renaming is avoided: k_ingest_perm below handles the map.
+    (void)ist;
+  }
+  {
+    ColMap m;
+    for (int j = 0; j < d; ++j) m.col[j] = f->out_col[j];
+    m.col[d] = d;
+    hipLaunchKernelGGL(k_scatter_rows, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, gxj, (long)N, d + 1, m, g, (long)N);
+    HIP_OK(hipGetLastError());
+  }
+  size_t bn_total = nis_flow_bnsave_count(f);
+  size_t bn_off = bn_total;
+  for (int ci = f->n_cells - 1; ci >= 0; --ci) {
+    const nis_cell_desc& cd = f->cells[ci];
+    const CellLayout& L = lay[ci];
+    bn_off -= (size_t)(cd.n_hidden + 1) * 4 * L.WM;
+    CellK c;
+    memset(&c, 0, sizeof(c));
+    c.kind = cd.kind;
+    c.d = d;
+    c.P = cd.P;
+    c.T = d - cd.P;
+    c.K = cd.K;
+    c.L = cd.n_hidden;
+    c.out = cell_out(cd);
+    c.R = cell_R(cd);
+    for (int l = 0; l < cd.n_hidden; ++l) c.width[l] = cd.width[l];
+    for (int j = 0; j < d; ++j) c.in_plane[j] = cd.in_col[j];
+    c.jplane = d;
+    c.first = (ci == 0 && !w_has_jac) ? 1 : 0;
+    c.G = 1;
+    const size_t WM = L.WM, R = c.R, nl = c.L;
+    double* wp = pk;
+    double* wlast = wp + nl * WM * WM;
+    double* bias = wlast + R * WM;
+    double* gb = bias + (R + 7) / 8 * 8;
+    double* coef = gb + (nl + 1) * 2 * WM;
+    c.wp = wp;
+    c.wlast = wlast;
+    c.bias = bias;
+    c.gb = gb;
+    c.coef = coef;
+    hipLaunchKernelGGL(k_pack, dim3(1), dim3(NIS_TPB), 0, s, c, (int)WM, params[ci], (const double*)nullptr, 0, wp, wlast, bias, gb);
+    HIP_OK(hipGetLastError());
+    int rc = nis_bwd_cell_run(c, planes_hist + (size_t)ci * set, planes_hist + (size_t)(ci + 1) * set, g, bnsave + bn_off, (long)ld,
+                              (long)N, cellws, gparams[ci], s);
+    if (rc != NIS_OK) return rc;
+  }
+  if (gx_out) {
+    ColMap m;
+    for (int j = 0; j <= d; ++j) m.col[j] = j;
+    hipLaunchKernelGGL(k_emit, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const double*)g, (long)N, (long)N, d, m, gx_out);
+    HIP_OK(hipGetLastError());
+  }
+  return NIS_OK;
 }

@@ -85,6 +85,17 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
       if (writer) {
         coef_g[(fresh * 2 + 0) * WM + j] = scale;
         coef_g[(fresh * 2 + 1) * WM + j] = shift;
+        if (c.bnsave && c.G == 1) {
+          double mean_s = 0.0, rstd_s = 0.0;
+          if (j < F) {
+            mean_s = ref + s1 / n;
+            rstd_s = 1.0 / sqrt(fmax(s2 - s1 * s1 / n, 0.0) / n + NIS_BN_EPS);
+          }
+          c.bnsave[(fresh * 4 + 0) * WM + j] = scale;
+          c.bnsave[(fresh * 4 + 1) * WM + j] = shift;
+          c.bnsave[(fresh * 4 + 2) * WM + j] = mean_s;
+          c.bnsave[(fresh * 4 + 3) * WM + j] = rstd_s;
+        }
       }
     }
   }
@@ -372,6 +383,11 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   for (long i = (long)blockIdx.x * NIS_TPB + tid; i < N; i += stride) {
     double a[WM];
     load_passthrough<WM>(c, planes, ld, i, a);
+    if (c.out_off != 0) {                             // history mode: the next plane set gets the pass-through block too
+#pragma unroll
+      for (int p = 0; p < (WM < NIS_MAX_DIM ? WM : NIS_MAX_DIM); ++p)
+        if (p < c.P) planes[(size_t)c.in_plane[p] * ld + c.out_off + i] = a[p];
+    }
     double nv[NF];
     double c0 = 0.0, c1 = 0.0, nsum = 0.0;
     // riders read pass-through columns straight from their planes (uniform plane index, L1 hit: the line was
@@ -435,7 +451,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
         y = qn * alpha + below / tot;                                                 // :123,136-139
         jf = qn;                                                                      // :141
       }
-      if (fz.write_planes) col[i] = y;
+      if (fz.write_planes) col[c.out_off + i] = y;
       jprod *= jf;
       if (bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
       if (next) {
@@ -451,7 +467,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
     }
     double* jp = planes + (size_t)c.jplane * ld;
     const double jout = (c.first ? 1.0 : jp[i]) * jprod;
-    if (fz.write_planes) jp[i] = jout;
+    if (fz.write_planes) jp[c.out_off + i] = jout;
     if (next) {
       if (firstit) {
 #pragma unroll

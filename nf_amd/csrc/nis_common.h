@@ -131,6 +131,9 @@ struct CellK {
   int coef_gs;                           // doubles between the coefficient sets of consecutive g: (L+1)*2*WM
   long plane_gs;                         // doubles between the plane sets of consecutive g: (d+1)*ld
   double* gstat;                         // G > 1: (L+1) x G x 2 x WM  batch mean | unbiased var for k_running_update
+  // ---- training history (for the adjoint kernels): outputs go to the NEXT plane set, BN statistics are kept
+  long out_off;                          // doubles from a cell's input planes to its output planes (0: in place)
+  double* bnsave;                        // (L+1) x 4 x WM: scale | shift | batch mean | 1/sqrt(var+eps)  (may be null)
 };
 
 __host__ __device__ static inline int cellk_feat(const CellK& c, int l) { return l == 0 ? c.P : c.width[l - 1]; }

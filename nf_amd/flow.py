@@ -183,6 +183,44 @@ class FlowEngine:
             self._stats_epoch += 1
         return dict(planes=planes, xj=xj, bins=bins, status=ws[:4].view(torch.int32), ws=ws)
 
+    # ---- training: forward with history + hand-written adjoint
+    def backward_supported(self):
+        """True when every cell is in the class the adjoint kernels cover (include/nis_hip.h)."""
+        return bool(self.L.nis_flow_backward_supported(self.handle))
+
+    def forward_train(self, w, has_jac):
+        """Train-mode forward that keeps what the adjoint needs.  Returns (xj, saved)."""
+        w = self._check_input(w, self.d + (1 if has_jac else 0), True)
+        N, dev = w.shape[0], w.device
+        pp, rp, tp = self._pointers(dev)
+        ws, wsb = self._workspace(dev)
+        hist = torch.empty((len(self.cells) + 1, self.d + 1, N), dtype=torch.double, device=dev)
+        bnsave = torch.empty(self.L.nis_flow_bnsave_count(self.handle), dtype=torch.double, device=dev)
+        xj = torch.empty((N, self.d + 1), dtype=torch.double, device=dev)
+        rc = self.L.nis_flow_forward_train(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
+                                           1 if has_jac else 0, N, pp, rp, tp, self.pack_token(), hist.data_ptr(), N,
+                                           bnsave.data_ptr(), xj.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr())
+        _lib.check(rc, "nis_flow_forward_train")
+        self._stats_epoch += 1
+        return xj, (hist, bnsave, has_jac)
+
+    def backward(self, saved, gxj, want_gx):
+        """dL/dXJ (N, d+1) -> ([flat parameter-gradient blob per cell], dL/dx or None)."""
+        hist, bnsave, has_jac = saved
+        N, dev = hist.shape[2], hist.device
+        pp, _, _ = self._pointers(dev)
+        n = len(self.cells)
+        gflat = [torch.empty_like(c._flat) for c in self.cells]
+        gp = (C.c_void_p * n)(*[g.data_ptr() for g in gflat])
+        wsb = self.L.nis_flow_backward_workspace_bytes(self.handle, N)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        gx = torch.empty((N, self.d + 1), dtype=torch.double, device=dev) if want_gx else None
+        gxj = gxj.to(torch.double).contiguous()
+        rc = self.L.nis_flow_backward(self.handle, hist.data_ptr(), N, N, 1 if has_jac else 0, pp, bnsave.data_ptr(), gxj.data_ptr(),
+                                      gp, gx.data_ptr() if want_gx else None, ws.data_ptr(), wsb, _lib.stream_ptr())
+        _lib.check(rc, "nis_flow_backward")
+        return gflat, gx
+
     def integrate_steps(self, w, train, f_kind, f_params, out4, planes=None, token=None, want_fres=False):
         """G iterations of integrate()'s loop body in ONE library call.  w: (G, N, d) (or (N, d) for G = 1),
         out4: (G, 4) float64 device tensor/view receiving {count, mean, M2, max} per iteration.  The iterations

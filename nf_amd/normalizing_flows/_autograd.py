@@ -1,12 +1,16 @@
 """Autograd glue for the HIP flow.
 
 Forward values ALWAYS come from the HIP kernels.  Gradients (needed only by
-`_train_variance_forward_seq`, /root/reference/nisrep/normalizing_flows/manager.py:275-280) are, in this
-round, obtained by re-evaluating the same cells with stock PyTorch-ROCm ops on the GPU inside
-`backward` and differentiating that graph (the hand-written adjoint kernels are
-the next row).  The recomputation below is a device-side adjoint helper, not a fallback: it never
-produces a forward result and refuses to run without a GPU.
+`_train_variance_forward_seq`, /root/reference/nisrep/normalizing_flows/manager.py:275-280):
+  * models whose cells are all in the class the adjoint kernels cover (nf_amd/csrc/flow_bwd.hip: register width 4, one
+    transformed column, PWQuad n_bins <= 4 / PWLin n_bins <= 12 -- the README / C1 / C2 models) use the hand-written HIP
+    backward (`nis_flow_forward_train` + `nis_flow_backward`);
+  * every other model re-evaluates the same cells with stock PyTorch-ROCm ops on the GPU inside `backward` and
+    differentiates that graph (widening the adjoint kernels is the next row).  That
+    recomputation is a device-side adjoint helper, not a fallback: it never produces a forward result and refuses to run
+    without a GPU.  NF_AMD_TORCH_ADJOINT=1 forces it everywhere (A/B checks).
 """
+import os
 import torch
 import torch.nn.functional as F
 
@@ -86,6 +90,34 @@ def modules_torch(modules, x, train):
     return x
 
 
+class _HipFlowFn(torch.autograd.Function):
+    """Forward AND backward in libnis_hip.so."""
+
+    @staticmethod
+    def forward(ctx, engine, train, has_jac, x, *params):
+        xj, saved = engine.forward_train(x.detach(), has_jac)
+        ctx.engine, ctx.saved = engine, saved
+        ctx.sizes = [[p.numel() for p in c.parameters()] for c in engine.cells]
+        ctx.shapes = [[p.shape for p in c.parameters()] for c in engine.cells]
+        ctx.x_dtype = x.dtype
+        return xj
+
+    @staticmethod
+    def backward(ctx, gout):
+        gflat, gx = ctx.engine.backward(ctx.saved, gout, ctx.needs_input_grad[3])
+        grads = []
+        for gf, sizes, shapes in zip(gflat, ctx.sizes, ctx.shapes):
+            off = 0
+            for n, sh in zip(sizes, shapes):
+                grads.append(gf[off:off + n].view(sh))
+                off += n
+        if gx is not None:
+            if not ctx.saved[2]:
+                gx = gx[:, :-1]
+            gx = gx.to(ctx.x_dtype)
+        return (None, None, None, gx) + tuple(grads)
+
+
 class _FlowFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, modules, has_jac, train, x, *params):
@@ -127,4 +159,7 @@ def run_flow(engine, modules, x, has_jac, train):
     for c in cells:
         ensure_flat(c, x.device)        # before autograd captures the parameter tensors
     params = [p for c in cells for p in c.parameters()]
+    if train and engine.backward_supported() and not os.environ.get("NF_AMD_TORCH_ADJOINT") \
+            and all(p.requires_grad for p in params):
+        return _HipFlowFn.apply(engine, train, has_jac, x, *params)
     return _FlowFn.apply(engine, modules, has_jac, train, x, *params)
