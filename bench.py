@@ -32,7 +32,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from nf_amd import _lib, integrands                                            # noqa: E402
-from nf_amd.flow import moments_of                                             # noqa: E402
 from nf_amd.normalizing_flows.manager import PWQuadManager                     # noqa: E402
 from nf_amd.parallel import allreduce_moments, init_from_env                   # noqa: E402
 from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace   # noqa: E402

@@ -1000,15 +1000,7 @@ extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t
   flow_layout(f, 1, &lay, nullptr);
   const int tgrid = grid_for(8, 1, N, NIS_TPB);
   const size_t tile_bytes = ((size_t)NIS_TPB * (d + 1) + 16) * sizeof(double);
-  // dL/dXJ (N, d+1) row-major in the model's OUTPUT column order -> gradient planes in plane order
-  {
-    IngestStats ist;
-    memset(&ist, 0, sizeof(ist));
-    ist.plane_gs = set;
-    // logical output column c lives in plane out_col[c]: ingest writes plane index = input column index, so permute
-    // by ingesting into a scratch set and renaming is avoided: k_ingest_perm below handles the map.
-    (void)ist;
-  }
+  // dL/dXJ (N, d+1) row-major in the model's OUTPUT column order -> gradient planes (output column c lives in plane out_col[c])
   {
     ColMap m;
     for (int j = 0; j < d; ++j) m.col[j] = f->out_col[j];

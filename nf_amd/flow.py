@@ -181,7 +181,15 @@ class FlowEngine:
         _lib.check(rc, "nis_flow_forward")
         if train:
             self._stats_epoch += 1
-        return dict(planes=planes, xj=xj, bins=bins, status=ws[:4].view(torch.int32), ws=ws)
+        status = ws[:4].view(torch.int32)
+        self._raise_on_status(status)
+        return dict(planes=planes, xj=xj, bins=bins, status=status, ws=ws)
+
+    def _raise_on_status(self, status):
+        """PWLin with x == 1.0 indexes bin n_bins: the reference's torch.gather raises (coupling_cells.py:136); the kernel
+        flags it instead.  Only models with a PWLin cell pay the device->host read of the status word."""
+        if any(c.KIND == _lib.NIS_PWLIN for c in self.cells) and int(status[0].item()) & 1:
+            raise IndexError("index out of range in PWLin bin lookup (an input coordinate equals 1.0 or is negative)")
 
     # ---- training: forward with history + hand-written adjoint
     def backward_supported(self):
@@ -202,6 +210,7 @@ class FlowEngine:
                                            bnsave.data_ptr(), xj.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr())
         _lib.check(rc, "nis_flow_forward_train")
         self._stats_epoch += 1
+        self._raise_on_status(ws[:4].view(torch.int32))
         return xj, (hist, bnsave, has_jac)
 
     def backward(self, saved, gxj, want_gx):
@@ -249,6 +258,7 @@ class FlowEngine:
         _lib.check(rc, "nis_integrate_steps")
         if train:
             self._stats_epoch += 1
+        self._raise_on_status(ws[:4].view(torch.int32))
         return fres
 
     integrate_step = integrate_steps

@@ -405,3 +405,62 @@ def test_c2_full_batch_properties():
     # camel integral over the unit square (truncated Gaussians) = 0.2323 within MC error
     mean, var = merged[1], merged[2] / (merged[0] - 1)
     assert abs(mean - 0.23228) < 5 * np.sqrt(var / 1e6)
+
+
+# ------------------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("N", [2, 3, 63, 65, 257, 1025])
+def test_ragged_batch_sizes_vs_oracle(N):
+    """Batch sizes around wave / workgroup / tile boundaries (N = 2 is the smallest train-mode batch torch accepts)."""
+    torch.manual_seed(N)
+    NF = build_manager(dict(kind="pwquad", d=5, n_cells=2, K=6, NN=[8, 8]))
+    params = {k: t2n(v) for k, v in NF._model.state_dict().items()}
+    w = torch.rand(N, 5, dtype=torch.double)
+    steps = oflow.plan_pwquad(5, 2, 6)
+    for train in (True, False):
+        NF._model.train(train)
+        ref = oflow.model_forward(w.numpy(), params, steps, train)
+        got = NF._model.flow_forward(w.to(dev()), want_xj=True)["xj"]
+        np.testing.assert_allclose(t2n(got), ref, rtol=1e-8 if N < 4 else RTOL, atol=1e-11)
+        if train:                                   # running statistics moved: refresh the oracle's copy
+            params = {k: t2n(v) for k, v in NF._model.state_dict().items()}
+
+
+def test_single_sample_train_mode_raises_like_torch():
+    NF = build_manager(dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3]))
+    NF._model.train()
+    with pytest.raises(ValueError):
+        NF._model.flow_forward(torch.rand(1, 2, dtype=torch.double, device=dev()))
+    NF._model.eval()
+    out = NF._model.flow_forward(torch.rand(1, 2, dtype=torch.double, device=dev()), want_xj=True)["xj"]
+    assert out.shape == (1, 3) and torch.isfinite(out).all()
+
+
+def test_pwlin_input_one_raises_index_error():
+    """x == 1.0 selects bin n_bins: the reference's gather raises."""
+    from nf_amd.normalizing_flows.layers.coupling_cells import PWLin
+    cell = PWLin(3, 1, 8, [4, 4]).double().to(dev())
+    x = torch.rand(100, 4, dtype=torch.double, device=dev())
+    x[17, 2] = 1.0
+    with pytest.raises(IndexError):
+        cell(x)
+
+
+@pytest.mark.parametrize("G", [1, 3, 7])
+def test_batched_iterations_equal_one_by_one(G):
+    """nis_integrate_steps with G batches == G separate calls (records and running statistics), train mode."""
+    from nf_amd import integrands
+    f = integrands.Camel()
+    torch.manual_seed(4)
+    A = build_manager(dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3]))
+    sd = {k: v.clone() for k, v in A._model.state_dict().items()}
+    B = build_manager(dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3]))
+    B._model.load_state_dict(sd)
+    w = torch.rand(G, 50_001, 2, dtype=torch.float32, device=dev())
+    outA = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    A._model.engine().integrate_steps(w, True, f.nis_kind, f.nis_params, outA)
+    outB = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    for g in range(G):
+        B._model.engine().integrate_steps(w[g], True, f.nis_kind, f.nis_params, outB[g:g + 1])
+    np.testing.assert_allclose(t2n(outA), t2n(outB), rtol=1e-12)
+    for k in sd:
+        np.testing.assert_allclose(t2n(A._model.state_dict()[k]), t2n(B._model.state_dict()[k]), rtol=1e-12, atol=1e-15, err_msg=k)
