@@ -130,8 +130,8 @@ int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_b
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Training forward + hand-written adjoint (replaces loss.backward() through the flow, manager.py:275-278, for the
- * cell class the adjoint kernels cover: register width 4, one transformed column, PWQuad n_bins <= 4 / PWLin
- * n_bins <= 12 -- README / C1 / C2 models; nis_flow_backward_supported tells).
+ * cell class the adjoint kernels cover: conditioner widths and pass-through size <= 8, PWQuad n_bins <= 16, PWLin
+ * any n_bins, any number of transformed columns; nis_flow_backward_supported tells).
  *   nis_flow_forward_train: train-mode forward that keeps every cell's input: planes_hist holds n_cells+1 plane
  *     sets of (d+1, ld) doubles (set c = input of cell c, last set = model output); bnsave
  *     (nis_flow_bnsave_count doubles) receives scale | shift | batch mean | rstd of every BN layer.

@@ -638,9 +638,9 @@ struct RunOpts {
 
 // declared in flow_bwd.hip
 bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm);
-size_t nis_bwd_cell_workspace_doubles(int L, int64_t N);
-int nis_bwd_cell_run(const CellK& c, const double* x, const double* xo, double* g, const double* bnsave, long ld, long N, double* ws,
-                     double* gparams, hipStream_t s);
+size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N);
+int nis_bwd_cell_run(const CellK& c, int wm, const double* x, const double* xo, double* g, const double* bnsave, long ld, long N,
+                     double* ws, double* gparams, hipStream_t s);
 
 static bool use_mfma() {
   static const int off = env_int("NIS_NO_MFMA", 0);
@@ -975,7 +975,7 @@ extern "C" size_t nis_flow_backward_workspace_bytes(const nis_flow* f, int64_t N
   std::vector<CellLayout> lay;
   flow_layout(f, 1, &lay, nullptr);
   for (int ci = 0; ci < f->n_cells; ++ci) {
-    cellws = std::max(cellws, nis_bwd_cell_workspace_doubles(f->cells[ci].n_hidden, N));
+    cellws = std::max(cellws, nis_bwd_cell_workspace_doubles(f->cells[ci], lay[ci].WM, N));
     const size_t WM = lay[ci].WM, R = cell_R(f->cells[ci]), nl = f->cells[ci].n_hidden;
     pk = std::max(pk, nl * WM * WM + R * WM + (R + 7) / 8 * 8 + 2 * (nl + 1) * 2 * WM);
   }
@@ -994,10 +994,10 @@ extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t
   double* g = (double*)workspace;                       // gradient planes (d+1, ld)
   double* cellws = g + (size_t)(d + 1) * N;
   size_t cw = 0;
-  for (int ci = 0; ci < f->n_cells; ++ci) cw = std::max(cw, nis_bwd_cell_workspace_doubles(f->cells[ci].n_hidden, N));
-  double* pk = cellws + cw;
   std::vector<CellLayout> lay;
   flow_layout(f, 1, &lay, nullptr);
+  for (int ci = 0; ci < f->n_cells; ++ci) cw = std::max(cw, nis_bwd_cell_workspace_doubles(f->cells[ci], lay[ci].WM, N));
+  double* pk = cellws + cw;
   const int tgrid = grid_for(8, 1, N, NIS_TPB);
   const size_t tile_bytes = ((size_t)NIS_TPB * (d + 1) + 16) * sizeof(double);
   // dL/dXJ (N, d+1) row-major in the model's OUTPUT column order -> gradient planes (output column c lives in plane out_col[c])
@@ -1042,8 +1042,8 @@ extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t
     c.coef = coef;
     hipLaunchKernelGGL(k_pack, dim3(1), dim3(NIS_TPB), 0, s, c, (int)WM, params[ci], (const double*)nullptr, 0, wp, wlast, bias, gb);
     HIP_OK(hipGetLastError());
-    int rc = nis_bwd_cell_run(c, planes_hist + (size_t)ci * set, planes_hist + (size_t)(ci + 1) * set, g, bnsave + bn_off, (long)ld,
-                              (long)N, cellws, gparams[ci], s);
+    int rc = nis_bwd_cell_run(c, L.WM, planes_hist + (size_t)ci * set, planes_hist + (size_t)(ci + 1) * set, g, bnsave + bn_off,
+                              (long)ld, (long)N, cellws, gparams[ci], s);
     if (rc != NIS_OK) return rc;
   }
   if (gx_out) {

@@ -1,62 +1,65 @@
-// Hand-written adjoint (backward) of a coupling cell for the narrow conditioner class the headline
-// configurations use (register width WM = 4, one transformed column: d = P + 1; PWQuad n_bins <= 4 or PWLin
-// n_bins <= 12), train-mode BatchNorm.  Everything else keeps the stock-PyTorch adjoint (nf_amd/normalizing_flows/_autograd.py).
+// Hand-written adjoint (backward) of a coupling cell with a narrow conditioner (register width WM = 4 or 8, any
+// number of transformed columns, PWQuad n_bins <= 16, PWLin any n_bins), train-mode BatchNorm.  Wider conditioners keep
+// the stock-PyTorch adjoint (nf_amd/normalizing_flows/_autograd.py) until their weight-gradient GEMMs move to MFMA.
 //
 // Reverse of:  BN_0 -> Lin_0 -> [BN_l -> ReLU -> Lin_l]_{l=1..L} -> exp / normalise -> quadratic (linear) CDF, J *= dy/dx
 // (reference forward: normalizing_flows/layers/coupling_cells.py:107-142, :159-228, :236-254; the reference obtains these
 // gradients from torch.autograd at manager.py:275-278).
 //
 // Train-mode BatchNorm couples all samples, so the adjoint is again a chain of launches, one per BN layer, in reverse:
-//   head    : recompute the cell, bijector adjoint -> dZ -> dW_L, db_L, d a_L -> dy_L (grad at BN_L's output), sums of BN_L
+//   head    : recompute the cell; per transformed column the bijector adjoint -> dZ rows (stored as planes) -> d a_L;
+//             dy_L (grad at BN_L's output) + the two batch sums BN_L's backward needs
+//   wlast   : dW_L = dZ^T a_L, db_L = sum dZ  (rows in chunks of 8: a tall-skinny reduction over the samples)
 //   layer l : dh_l = scale_l (dy_l - mean(dy_l) - xhat_l mean(dy_l xhat_l)) -> dW_{l-1}, dy_{l-1}, sums of BN_{l-1}
-//   input   : BN_0 backward -> grad of the pass-through columns
+//   input   : BN_0 backward -> gradient of the pass-through columns
 // Per-thread partial sums (registers) -> per-workgroup records -> k_bwd_reduce (fixed order: bitwise reproducible).
 #include <algorithm>
 #include <cstring>
 
 #include "flow_kernels.h"
 
-#define BW 4                  // conditioner register width handled here
-#define BKM 4                 // max PWQuad bins
-#define BLK 12                // max PWLin bins
-#define BROWS 12              // max rows of the last layer (2*BKM+1 = 9, BLK = 12)
-#define BNACC 80              // record length: BROWS*BW + BROWS (dW_L, db_L) | BW*BW (dW_l) ; + 2*BW sums
+#define BNACC 80              // record length (>= WM*WM + 2*WM for WM = 8, >= BRC*(WM+1))
+#define BRC 8                 // rows of the last layer per wlast chunk
 #define BMAXB 1024            // max workgroups of an adjoint launch
+#define BKMAX 16              // max PWQuad bins handled here
 
 struct BwdK {
-  CellK c;                    // same per-cell view as the forward (in_plane, sizes, packed weights, coefficient pointers)
+  CellK c;                    // same per-cell view as the forward (in_plane, sizes, packed weights)
   const double* x;            // plane set of the cell's input  (d+1 planes, leading dimension ld)
   const double* xo;           // plane set of the cell's output (J_out lives in plane d)
   double* g;                  // gradient planes (d+1): in = dL/d(output set), out = dL/d(input set), in place
-  double* dyp;                // BW planes: dL/d(BN_l output) of the layer being processed
-  const double* bn;           // saved (L+1) x 4 x BW: scale | shift | mean | rstd
-  const double* gam;          // (L+1) x 2 x BW gamma | beta (padded image)
-  double* part;               // records of this launch: BMAXB x BNACC
+  double* dyp;                // WM planes: dL/d(BN_l output) of the layer being processed
+  double* alp;                // WM planes: a_L (input of the last Linear)
+  double* dzp;                // R planes: dL/dZ
+  const double* bn;           // saved (L+1) x 4 x WM: scale | shift | mean | rstd
+  double* part;               // records of this launch
   const double* sums;         // reduced record of the previous launch (BNACC)
   long ld, N;
 };
 
-__device__ __forceinline__ void bw_block_reduce(const double (&acc)[BNACC], int nacc, double* part) {
-  __shared__ double sm[NIS_TPB / 64][BNACC];
+template <int NACC>
+__device__ __forceinline__ void bw_block_reduce(const double (&acc)[NACC], double* part) {
+  __shared__ double sm[NIS_TPB / 64][NACC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int a = 0; a < BNACC; ++a) {
-    if (a < nacc) {
-      const double v = wave_sum(acc[a]);
-      if (lane == 0) sm[wave][a] = v;
-    }
+  for (int a = 0; a < NACC; ++a) {
+    const double v = wave_sum(acc[a]);
+    if (lane == 0) sm[wave][a] = v;
   }
   __syncthreads();
-  if ((int)threadIdx.x < nacc) {
+  if ((int)threadIdx.x < NACC) {
     double t = 0.0;
     for (int w = 0; w < NIS_TPB / 64; ++w) t += sm[w][threadIdx.x];
     part[(size_t)blockIdx.x * BNACC + threadIdx.x] = t;
   }
 }
 
-// records -> one summed record (one workgroup, fixed order)
-__global__ __launch_bounds__(NIS_TPB) void k_bwd_reduce(const double* __restrict__ part, int nparts, int nacc, double* __restrict__ out) {
+// records -> one summed record per y-slice (one workgroup each, fixed order)
+__global__ __launch_bounds__(NIS_TPB) void k_bwd_reduce(const double* __restrict__ part, int nparts, int nacc, double* __restrict__ out,
+                                                        long part_ystride) {
   __shared__ double sm[NIS_TPB];
+  part += (size_t)blockIdx.y * part_ystride;
+  out += (size_t)blockIdx.y * BNACC;
   for (int a = 0; a < nacc; ++a) {
     double t = 0.0;
     for (int b = threadIdx.x; b < nparts; b += NIS_TPB) t += part[(size_t)b * BNACC + a];
@@ -74,28 +77,29 @@ __global__ __launch_bounds__(NIS_TPB) void k_bwd_reduce(const double* __restrict
 // forward recompute of the hidden stack with the SAVED statistics; returns for layer `upto` (1..L):
 //   h[]   pre-BN activations of BN_upto        a_in[] input of Linear_{upto-1} (post-ReLU of BN_{upto-1}; BN_0 output if upto == 1)
 //   o_in[] BN_{upto-1} output before ReLU      xh_in[] normalised input of BN_{upto-1}
-__device__ __forceinline__ void bw_forward(const BwdK& k, long i, int upto, double (&h)[BW], double (&a_in)[BW], double (&o_in)[BW],
-                                           double (&xh_in)[BW]) {
+template <int WM>
+__device__ __forceinline__ void bw_forward(const BwdK& k, long i, int upto, double (&h)[WM], double (&a_in)[WM], double (&o_in)[WM],
+                                           double (&xh_in)[WM]) {
   nis_cptr wp = as_const(k.c.wp);
   nis_cptr bn = as_const(k.bn);
-  double cur[BW];
+  double cur[WM];
 #pragma unroll
-  for (int p = 0; p < BW; ++p) cur[p] = (p < k.c.P) ? k.x[(size_t)k.c.in_plane[p] * k.ld + i] : 0.0;
+  for (int p = 0; p < WM; ++p) cur[p] = (p < k.c.P) ? k.x[(size_t)k.c.in_plane[p] * k.ld + i] : 0.0;
   for (int l = 0; l < upto; ++l) {
 #pragma unroll
-    for (int j = 0; j < BW; ++j) {
-      xh_in[j] = (cur[j] - bn[(l * 4 + 2) * BW + j]) * bn[(l * 4 + 3) * BW + j];
-      o_in[j] = fma(cur[j], bn[(l * 4 + 0) * BW + j], bn[(l * 4 + 1) * BW + j]);
+    for (int j = 0; j < WM; ++j) {
+      xh_in[j] = (cur[j] - bn[(l * 4 + 2) * WM + j]) * bn[(l * 4 + 3) * WM + j];
+      o_in[j] = fma(cur[j], bn[(l * 4 + 0) * WM + j], bn[(l * 4 + 1) * WM + j]);
       a_in[j] = (l == 0) ? o_in[j] : fmax(o_in[j], 0.0);
     }
-    dense<BW>(wp + (size_t)l * BW * BW, a_in, cur);
+    dense<WM>(wp + (size_t)l * WM * WM, a_in, cur);
   }
 #pragma unroll
-  for (int j = 0; j < BW; ++j) h[j] = cur[j];
+  for (int j = 0; j < WM; ++j) h[j] = cur[j];
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int KIND>
+template <int KIND, int WM, int KM>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
   __shared__ double etab[64];
   nis_exp_init(etab);
@@ -105,232 +109,252 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
   nis_cptr bias = as_const(c.bias);
   nis_cptr bn = as_const(k.bn);
   const int L = c.L, K = c.K;
-  double acc[BNACC];
+  double acc[2 * WM];
 #pragma unroll
-  for (int a = 0; a < BNACC; ++a) acc[a] = 0.0;
+  for (int a = 0; a < 2 * WM; ++a) acc[a] = 0.0;
   const long stride = (long)gridDim.x * NIS_TPB;
   for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < k.N; i += stride) {
-    double h[BW], a_in[BW], o_in[BW], xh_in[BW];
-    bw_forward(k, i, L, h, a_in, o_in, xh_in);
-    double aL[BW], oL[BW], xhL[BW];
+    double h[WM], a_in[WM], o_in[WM], xh_in[WM];
+    bw_forward<WM>(k, i, L, h, a_in, o_in, xh_in);
+    double aL[WM], oL[WM], xhL[WM], da[WM];
 #pragma unroll
-    for (int j = 0; j < BW; ++j) {
-      xhL[j] = (h[j] - bn[(L * 4 + 2) * BW + j]) * bn[(L * 4 + 3) * BW + j];
-      oL[j] = fma(h[j], bn[(L * 4 + 0) * BW + j], bn[(L * 4 + 1) * BW + j]);
+    for (int j = 0; j < WM; ++j) {
+      xhL[j] = (h[j] - bn[(L * 4 + 2) * WM + j]) * bn[(L * 4 + 3) * WM + j];
+      oL[j] = fma(h[j], bn[(L * 4 + 0) * WM + j], bn[(L * 4 + 1) * WM + j]);
       aL[j] = fmax(oL[j], 0.0);
+      k.alp[(size_t)j * k.ld + i] = aL[j];
+      da[j] = 0.0;
     }
-    // ---- the single transformed column
-    const int colp = c.in_plane[c.P];
-    const double xraw = k.x[(size_t)colp * k.ld + i];
-    const double gy = k.g[(size_t)colp * k.ld + i];
     const double gJ = k.g[(size_t)c.jplane * k.ld + i];
     const double Jout = k.xo[(size_t)c.jplane * k.ld + i];
-    double dz[BROWS];
+    double jfprod = 1.0;
+    for (int t = 0; t < c.T; ++t) {
+      const int colp = c.in_plane[c.P + t];
+      const int row0 = t * c.out;
+      const double xraw = k.x[(size_t)colp * k.ld + i];
+      const double gy = k.g[(size_t)colp * k.ld + i];
+      double gx = 0.0, jf = 1.0;
+      if (KIND == NIS_PWQUAD) {
+        const bool clamped = xraw > 1.0 - 1e-6;
+        const double xb = clamped ? 1.0 - 1e-6 : xraw;
+        double V[KM + 1], W[KM];
 #pragma unroll
-    for (int r = 0; r < BROWS; ++r) dz[r] = 0.0;
-    double gx = 0.0, jf = 1.0;
-    if (KIND == NIS_PWQUAD) {
-      const bool clamped = xraw > 1.0 - 1e-6;
-      const double xb = clamped ? 1.0 - 1e-6 : xraw;
-      double V[BKM + 1], W[BKM];
+        for (int q = 0; q < KM + 1; ++q) V[q] = (q <= K) ? nis_exp(last_dot<WM>(wl, bias, row0 + q, aL), etab) : 0.0;
 #pragma unroll
-      for (int q = 0; q < BKM + 1; ++q) V[q] = (q <= K) ? nis_exp(last_dot<BW>(wl, bias, q, aL), etab) : 0.0;
+        for (int q = 0; q < KM; ++q) W[q] = (q < K) ? nis_exp(last_dot<WM>(wl, bias, row0 + K + 1 + q, aL), etab) : 0.0;
+        // forward quantities exactly as k_cell_apply forms them
+        double wn = 0.0;
 #pragma unroll
-      for (int q = 0; q < BKM; ++q) W[q] = (q < K) ? nis_exp(last_dot<BW>(wl, bias, K + 1 + q, aL), etab) : 0.0;
-      // forward quantities exactly as k_cell_apply forms them
-      double wn = 0.0;
+        for (int q = 0; q < KM; ++q)
+          if (q < K) wn += W[q];
+        double run = 0.0, best = 1e-30, left = 0.0;
+        int b = 0;
 #pragma unroll
-      for (int q = 0; q < BKM; ++q)
-        if (q < K) wn += W[q];
-      double run = 0.0, best = 1e-30, left = 0.0;
-      int b = 0;
+        for (int q = 0; q < KM; ++q)
+          if (q < K) {
+            run += W[q];
+            const double cs = run / wn;
+            const double v = (cs > xb) ? 0.0 : cs;
+            const bool up = v > best;
+            best = up ? v : best;
+            b = up ? q + 1 : b;
+            left = up ? cs : left;
+          }
+        b = (b > K - 1) ? K - 1 : b;
+        const double iwn = 1.0 / wn;
+        double area = 0.0;
 #pragma unroll
-      for (int q = 0; q < BKM; ++q)
-        if (q < K) {
-          run += W[q];
-          const double cs = run / wn;
-          const double v = (cs > xb) ? 0.0 : cs;
-          const bool up = v > best;
-          best = up ? v : best;
-          b = up ? q + 1 : b;
-          left = up ? cs : left;
+        for (int q = 0; q < KM; ++q)
+          if (q < K) {
+            W[q] = W[q] * iwn;
+            area += (V[q] + V[q + 1]) / 2 * W[q];
+          }
+        const double iarea = 1.0 / area;
+#pragma unroll
+        for (int q = 0; q < KM + 1; ++q)
+          if (q <= K) V[q] = V[q] * iarea;
+        double Wb = 1.0, Vb = 0.0, Vb1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < KM; ++q)
+          if (q < K) {
+            const bool hit = q == b;
+            Wb = hit ? W[q] : Wb;
+            Vb = hit ? V[q] : Vb;
+            Vb1 = hit ? V[q + 1] : Vb1;
+          }
+        const double alpha = (xb - left) / Wb;
+        const double D = Vb1 - Vb;
+        jf = lerp_torch(Vb, Vb1, alpha);
+        // ---- adjoint.  J_out = J_in * prod_t jf_t  ->  dL/d jf_t = gJ * J_out / jf_t
+        const double gjf = gJ * Jout / jf;
+        const double galpha = gy * jf * Wb + gjf * D;
+        gx = clamped ? 0.0 : galpha / Wb;
+        const double gleft = -galpha / Wb;
+        // gradients w.r.t. the normalised heights v (kept in gv) and widths w (in gw)
+        double gv[KM + 1], gw[KM];
+#pragma unroll
+        for (int q = 0; q < KM + 1; ++q) gv[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < KM; ++q) {
+          gw[q] = 0.0;
+          if (q < K) {
+            const bool below = q < b, hit = q == b;
+            // shift = sum_{q<b} (v_q + v_{q+1})/2 w_q ;  left = sum_{q<b} w_q
+            gw[q] += below ? gy * (V[q] + V[q + 1]) / 2 + gleft : 0.0;
+            gv[q] += below ? gy * W[q] / 2 : 0.0;
+            gv[q + 1] += below ? gy * W[q] / 2 : 0.0;
+            // the bin itself: y = a^2/2 D w_b + a v_b w_b + shift,  jf = v_b + a D,  a = (x - left)/w_b
+            gw[q] += hit ? gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb : 0.0;
+            gv[q] += hit ? gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha) : 0.0;
+            gv[q + 1] += hit ? gy * alpha * alpha / 2 * Wb + gjf * alpha : 0.0;
+          }
         }
-      b = (b > K - 1) ? K - 1 : b;
-      const double iwn = 1.0 / wn;
-      double area = 0.0;
+        // through v = eV/area(eV, w) and w = softmax(zW)
+        double S = 0.0;
 #pragma unroll
-      for (int q = 0; q < BKM; ++q)
-        if (q < K) {
-          W[q] = W[q] * iwn;
-          area += (V[q] + V[q + 1]) / 2 * W[q];
-        }
-      const double iarea = 1.0 / area;
+        for (int q = 0; q < KM + 1; ++q)
+          if (q <= K) S += gv[q] * V[q];
+        double Sw = 0.0;
 #pragma unroll
-      for (int q = 0; q < BKM + 1; ++q)
-        if (q <= K) V[q] = V[q] * iarea;
-      double Wb = 1.0, Vb = 0.0, Vb1 = 0.0;
+        for (int q = 0; q < KM; ++q)
+          if (q < K) {
+            gw[q] -= S * (V[q] + V[q + 1]) / 2;
+            Sw += gw[q] * W[q];
+          }
 #pragma unroll
-      for (int q = 0; q < BKM; ++q)
-        if (q < K) {
+        for (int q = 0; q < KM + 1; ++q)
+          if (q <= K) {
+            const double wl_ = (q >= 1) ? W[q >= 1 ? q - 1 : 0] : 0.0;
+            const double wr_ = (q < K && q < KM) ? W[q < KM ? q : 0] : 0.0;
+            const double dz = gv[q] * V[q] - S * V[q] * (wl_ + wr_) / 2;
+            k.dzp[(size_t)(row0 + q) * k.ld + i] = dz;
+#pragma unroll
+            for (int j = 0; j < WM; ++j) da[j] = fma(wl[(size_t)(row0 + q) * WM + j], dz, da[j]);
+          }
+#pragma unroll
+        for (int q = 0; q < KM; ++q)
+          if (q < K) {
+            const double dz = W[q] * (gw[q] - Sw);
+            k.dzp[(size_t)(row0 + K + 1 + q) * k.ld + i] = dz;
+#pragma unroll
+            for (int j = 0; j < WM; ++j) da[j] = fma(wl[(size_t)(row0 + K + 1 + q) * WM + j], dz, da[j]);
+          }
+      } else {
+        // PWLin: Q_q = K e_q / tot, y = Q_b alpha + sum_{q<b} e_q / tot, jf = Q_b, alpha = x - b/K  (two streamed passes)
+        const double ak = xraw * K;
+        const double bf = floor(ak);
+        const double alpha = (ak - bf) / K;
+        const int b = (int)bf;
+        double tot = 0.0, below = 0.0, eb = 0.0;
+        for (int q = 0; q < K; ++q) {
+          const double e = nis_exp(last_dot<WM>(wl, bias, row0 + q, aL), etab);
           const bool hit = q == b;
-          Wb = hit ? W[q] : Wb;
-          Vb = hit ? V[q] : Vb;
-          Vb1 = hit ? V[q + 1] : Vb1;
+          below = hit ? tot : below;
+          eb = hit ? e : eb;
+          tot += e;
         }
-      const double alpha = (xb - left) / Wb;
-      const double D = Vb1 - Vb;
-      jf = lerp_torch(Vb, Vb1, alpha);
-      // ---- adjoint.  J_out = J_in * jf  ->  dL/d jf = gJ * J_out / jf
-      const double gjf = gJ * Jout / jf;
-      const double galpha = gy * jf * Wb + gjf * D;
-      gx = clamped ? 0.0 : galpha / Wb;
-      const double gleft = -galpha / Wb;
-      double gv[BKM + 1], gw[BKM];
+        const double Qb = eb / (tot / K);
+        const double Qs = below / tot;
+        jf = Qb;
+        const double gjf = gJ * Jout / jf;
+        const double gQb = gy * alpha + gjf, gQs = gy;
+        gx = gy * Qb;
+        for (int q = 0; q < K; ++q) {
+          const double e = nis_exp(last_dot<WM>(wl, bias, row0 + q, aL), etab);
+          const double pq = e / tot;
+          const double dz = gQb * ((q == b ? Qb : 0.0) - Qb * pq) + gQs * ((q < b ? pq : 0.0) - Qs * pq);
+          k.dzp[(size_t)(row0 + q) * k.ld + i] = dz;
 #pragma unroll
-      for (int q = 0; q < BKM + 1; ++q) gv[q] = 0.0;
-#pragma unroll
-      for (int q = 0; q < BKM; ++q) gw[q] = 0.0;
-#pragma unroll
-      for (int q = 0; q < BKM; ++q)
-        if (q < K) {
-          const bool below = q < b, hit = q == b;
-          // shift = sum_{q<b} (v_q + v_{q+1})/2 w_q ;  left = sum_{q<b} w_q
-          gw[q] += below ? gy * (V[q] + V[q + 1]) / 2 + gleft : 0.0;
-          gv[q] += below ? gy * W[q] / 2 : 0.0;
-          gv[q + 1] += below ? gy * W[q] / 2 : 0.0;
-          // the bin itself: y = a^2/2 D w_b + a v_b w_b + shift,  jf = v_b + a D,  a = (x - left)/w_b
-          gw[q] += hit ? gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb : 0.0;
-          gv[q] += hit ? gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha) : 0.0;
-          gv[q + 1] += hit ? gy * alpha * alpha / 2 * Wb + gjf * alpha : 0.0;
+          for (int j = 0; j < WM; ++j) da[j] = fma(wl[(size_t)(row0 + q) * WM + j], dz, da[j]);
         }
-      // through v = eV/area(eV, w) and w = softmax(zW)
-      double S = 0.0;
-#pragma unroll
-      for (int q = 0; q < BKM + 1; ++q)
-        if (q <= K) S += gv[q] * V[q];
-#pragma unroll
-      for (int q = 0; q < BKM; ++q)
-        if (q < K) gw[q] -= S * (V[q] + V[q + 1]) / 2;
-      double Sw = 0.0;
-#pragma unroll
-      for (int q = 0; q < BKM; ++q)
-        if (q < K) Sw += gw[q] * W[q];
-#pragma unroll
-      for (int q = 0; q < BKM + 1; ++q)
-        if (q <= K) {
-          const double wl_ = (q >= 1) ? W[q - 1 < BKM ? (q - 1 >= 0 ? q - 1 : 0) : 0] : 0.0;
-          const double wr_ = (q < K) ? W[q < BKM ? q : 0] : 0.0;
-          dz[q] = gv[q] * V[q] - S * V[q] * (wl_ + wr_) / 2;
-        }
-#pragma unroll
-      for (int q = 0; q < BKM; ++q)
-        if (q < K) {
-          const double val = W[q] * (gw[q] - Sw);
-          // row K+1+q: place with a select chain (K is a run-time value)
-#pragma unroll
-          for (int r = 0; r < BROWS; ++r) dz[r] = (r == K + 1 + q) ? val : dz[r];
-        }
-    } else {
-      // PWLin: Q_q = K e_q / tot, y = Q_b alpha + sum_{q<b} e_q / tot, jf = Q_b, alpha = x - b/K
-      const double ak = xraw * K;
-      const double bf = floor(ak);
-      const double alpha = (ak - bf) / K;
-      const int b = (int)bf;
-      double e[BLK];
-      double tot = 0.0, below = 0.0, eb = 0.0;
-#pragma unroll
-      for (int q = 0; q < BLK; ++q) {
-        e[q] = (q < K) ? nis_exp(last_dot<BW>(wl, bias, q, aL), etab) : 0.0;
-        const bool hit = q == b;
-        below = hit ? tot : below;
-        eb = hit ? e[q] : eb;
-        tot += e[q];
       }
-      const double Qb = eb / (tot / K);
-      const double Qs = below / tot;
-      jf = Qb;
-      const double gjf = gJ * Jout / jf;
-      const double gQb = gy * alpha + gjf, gQs = gy;
-      gx = gy * Qb;
-#pragma unroll
-      for (int q = 0; q < BLK; ++q)
-        if (q < K) {
-          const double pq = e[q] / tot;
-          dz[q] = gQb * ((q == b ? Qb : 0.0) - Qb * pq) + gQs * ((q < b ? pq : 0.0) - Qs * pq);
-        }
+      k.g[(size_t)colp * k.ld + i] = gx;
+      jfprod *= jf;
     }
-    k.g[(size_t)colp * k.ld + i] = gx;
-    k.g[(size_t)c.jplane * k.ld + i] = gJ * jf;                 // dL/dJ_in = dL/dJ_out * dy/dx   (T == 1)
-    // ---- last Linear: dW_L[r][i] += dz_r a_i ; db_L[r] += dz_r ; da_i = sum_r W[r][i] dz_r
-    double da[BW];
-#pragma unroll
-    for (int j = 0; j < BW; ++j) da[j] = 0.0;
-#pragma unroll
-    for (int r = 0; r < BROWS; ++r)
-      if (r < c.R) {
-#pragma unroll
-        for (int j = 0; j < BW; ++j) {
-          acc[r * BW + j] = fma(dz[r], aL[j], acc[r * BW + j]);
-          da[j] = fma(wl[r * BW + j], dz[r], da[j]);
-        }
-        acc[BROWS * BW + r] += dz[r];
-      }
+    k.g[(size_t)c.jplane * k.ld + i] = gJ * jfprod;              // dL/dJ_in = dL/dJ_out * prod_t dy_t/dx_t
     // ---- through ReLU to BN_L's output; sums for BN_L
 #pragma unroll
-    for (int j = 0; j < BW; ++j) {
+    for (int j = 0; j < WM; ++j) {
       const double dy = (oL[j] > 0.0) ? da[j] : 0.0;
       k.dyp[(size_t)j * k.ld + i] = dy;
-      acc[BROWS * BW + BROWS + j] += dy;
-      acc[BROWS * BW + BROWS + BW + j] = fma(dy, xhL[j], acc[BROWS * BW + BROWS + BW + j]);
+      acc[j] += dy;
+      acc[WM + j] = fma(dy, xhL[j], acc[WM + j]);
     }
   }
-  bw_block_reduce(acc, BROWS * BW + BROWS + 2 * BW, k.part);
+  bw_block_reduce<2 * WM>(acc, k.part);
+}
+
+// dW_L[r][j] = sum_s dZ[r][s] a_L[j][s],  db_L[r] = sum_s dZ[r][s]   for the BRC rows of chunk blockIdx.y
+template <int WM>
+__global__ __launch_bounds__(NIS_TPB) void k_bwd_wlast(BwdK k) {
+  const int r0 = blockIdx.y * BRC;
+  const int nr = min(BRC, k.c.R - r0);
+  double acc[BRC * (WM + 1)];
+#pragma unroll
+  for (int a = 0; a < BRC * (WM + 1); ++a) acc[a] = 0.0;
+  const long stride = (long)gridDim.x * NIS_TPB;
+  for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < k.N; i += stride) {
+    double a[WM];
+#pragma unroll
+    for (int j = 0; j < WM; ++j) a[j] = k.alp[(size_t)j * k.ld + i];
+#pragma unroll
+    for (int r = 0; r < BRC; ++r)
+      if (r < nr) {
+        const double dz = k.dzp[(size_t)(r0 + r) * k.ld + i];
+#pragma unroll
+        for (int j = 0; j < WM; ++j) acc[r * (WM + 1) + j] = fma(dz, a[j], acc[r * (WM + 1) + j]);
+        acc[r * (WM + 1) + WM] += dz;
+      }
+  }
+  bw_block_reduce<BRC*(WM + 1)>(acc, k.part + (size_t)blockIdx.y * BMAXB * BNACC);
 }
 
 // BN_l backward (l >= 1) -> Linear_{l-1} backward -> dy_{l-1}
+template <int WM>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_layer(BwdK k, int l, int sums_off) {
   const CellK& c = k.c;
   nis_cptr wp = as_const(c.wp);
   nis_cptr bn = as_const(k.bn);
   nis_cptr sm = as_const(k.sums);
   const double invN = 1.0 / (double)k.N;
-  double acc[BNACC];
+  double acc[WM * WM + 2 * WM];
 #pragma unroll
-  for (int a = 0; a < BNACC; ++a) acc[a] = 0.0;
+  for (int a = 0; a < WM * WM + 2 * WM; ++a) acc[a] = 0.0;
   const long stride = (long)gridDim.x * NIS_TPB;
   for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < k.N; i += stride) {
-    double h[BW], a_in[BW], o_in[BW], xh_in[BW];
-    bw_forward(k, i, l, h, a_in, o_in, xh_in);
-    double dh[BW];
+    double h[WM], a_in[WM], o_in[WM], xh_in[WM];
+    bw_forward<WM>(k, i, l, h, a_in, o_in, xh_in);
+    double dh[WM];
 #pragma unroll
-    for (int j = 0; j < BW; ++j) {
-      const double xh = (h[j] - bn[(l * 4 + 2) * BW + j]) * bn[(l * 4 + 3) * BW + j];
+    for (int j = 0; j < WM; ++j) {
+      const double xh = (h[j] - bn[(l * 4 + 2) * WM + j]) * bn[(l * 4 + 3) * WM + j];
       const double dy = k.dyp[(size_t)j * k.ld + i];
-      const double m1 = sm[sums_off + j] * invN, m2 = sm[sums_off + BW + j] * invN;
-      dh[j] = bn[(l * 4 + 0) * BW + j] * (dy - m1 - xh * m2);       // scale_l = gamma_l * rstd_l
+      const double m1 = sm[sums_off + j] * invN, m2 = sm[sums_off + WM + j] * invN;
+      dh[j] = bn[(l * 4 + 0) * WM + j] * (dy - m1 - xh * m2);       // scale_l = gamma_l * rstd_l
     }
-    double da[BW];
+    double da[WM];
 #pragma unroll
-    for (int q = 0; q < BW; ++q) da[q] = 0.0;
+    for (int q = 0; q < WM; ++q) da[q] = 0.0;
 #pragma unroll
-    for (int j = 0; j < BW; ++j)
+    for (int j = 0; j < WM; ++j)
 #pragma unroll
-      for (int q = 0; q < BW; ++q) {
-        acc[j * BW + q] = fma(dh[j], a_in[q], acc[j * BW + q]);      // dW_{l-1}[j][q]
-        da[q] = fma(wp[(size_t)(l - 1) * BW * BW + j * BW + q], dh[j], da[q]);
+      for (int q = 0; q < WM; ++q) {
+        acc[j * WM + q] = fma(dh[j], a_in[q], acc[j * WM + q]);      // dW_{l-1}[j][q]
+        da[q] = fma(wp[(size_t)(l - 1) * WM * WM + j * WM + q], dh[j], da[q]);
       }
 #pragma unroll
-    for (int q = 0; q < BW; ++q) {
+    for (int q = 0; q < WM; ++q) {
       const double dy = (l - 1 == 0 || o_in[q] > 0.0) ? da[q] : 0.0;   // BN_0 has no ReLU behind it
       k.dyp[(size_t)q * k.ld + i] = dy;
-      acc[BW * BW + q] += dy;
-      acc[BW * BW + BW + q] = fma(dy, xh_in[q], acc[BW * BW + BW + q]);
+      acc[WM * WM + q] += dy;
+      acc[WM * WM + WM + q] = fma(dy, xh_in[q], acc[WM * WM + WM + q]);
     }
   }
-  bw_block_reduce(acc, BW * BW + 2 * BW, k.part);
+  bw_block_reduce<WM * WM + 2 * WM>(acc, k.part);
 }
 
 // BN_0 backward: gradient of the pass-through columns
+template <int WM>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_input(BwdK k, int sums_off) {
   const CellK& c = k.c;
   nis_cptr bn = as_const(k.bn);
@@ -339,92 +363,122 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_input(BwdK k, int sums_off
   const long stride = (long)gridDim.x * NIS_TPB;
   for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < k.N; i += stride) {
 #pragma unroll
-    for (int p = 0; p < BW; ++p)
+    for (int p = 0; p < WM; ++p)
       if (p < c.P) {
         const size_t at = (size_t)c.in_plane[p] * k.ld + i;
-        const double xh = (k.x[at] - bn[2 * BW + p]) * bn[3 * BW + p];
+        const double xh = (k.x[at] - bn[2 * WM + p]) * bn[3 * WM + p];
         const double dy = k.dyp[(size_t)p * k.ld + i];
-        const double m1 = sm[sums_off + p] * invN, m2 = sm[sums_off + BW + p] * invN;
+        const double m1 = sm[sums_off + p] * invN, m2 = sm[sums_off + WM + p] * invN;
         k.g[at] += bn[p] * (dy - m1 - xh * m2);
       }
   }
 }
 
 // Summed records -> gradient blob in the reference's parameter order (include/nis_hip.h).
-//   sums layout: [pass 0 = head | pass 1 = layer L | ... | pass L = layer 1], each BNACC doubles.
-__global__ void k_bwd_scatter(CellK c, const double* __restrict__ sums, double* __restrict__ gparams) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+//   sums: [pass 0 = head (BN_L sums) | pass 1 = layer L | ... | pass L = layer 1], each BNACC doubles;
+//   wsum: one BNACC record per chunk of BRC last-layer rows, [r][WM weights | bias].
+__global__ void k_bwd_scatter(CellK c, int WM, const double* __restrict__ sums, const double* __restrict__ wsum,
+                              double* __restrict__ gparams) {
   const int L = c.L;
   size_t off = 0;
+  const int tid = threadIdx.x, nth = blockDim.x;
   for (int l = 0; l <= L; ++l) {
     const int F = cellk_feat(c, l);
     const int O = l < L ? c.width[l] : c.R;
-    // d gamma_l = sum dy_l xhat_l, d beta_l = sum dy_l : emitted by the pass that produced dy_l
-    //   dy_L by the head (pass 0, offset BROWS*BW+BROWS); dy_l (l < L) by layer pass l+1 = pass index L-l, offset BW*BW
-    const double* s = (l == L) ? sums + BROWS * BW + BROWS : sums + (size_t)(L - l) * BNACC + BW * BW;
-    for (int j = 0; j < F; ++j) {
-      gparams[off + j] = s[BW + j];
+    // d gamma_l = sum dy_l xhat_l, d beta_l = sum dy_l: emitted by the pass that produced dy_l
+    //   dy_L by the head (pass 0, offset 0); dy_l (l < L) by layer pass l+1 = pass index L-l, offset WM*WM
+    const double* s = (l == L) ? sums : sums + (size_t)(L - l) * BNACC + WM * WM;
+    for (int j = tid; j < F; j += nth) {
+      gparams[off + j] = s[WM + j];
       gparams[off + F + j] = s[j];
     }
     off += 2 * (size_t)F;
     if (l < L) {                       // dW_l from layer pass l+1 (pass index L-l)
       const double* w = sums + (size_t)(L - l) * BNACC;
-      for (int j = 0; j < O; ++j)
-        for (int q = 0; q < F; ++q) gparams[off + (size_t)j * F + q] = w[j * BW + q];
+      for (int e = tid; e < O * F; e += nth) gparams[off + e] = w[(e / F) * WM + (e % F)];
     } else {
-      for (int r = 0; r < O; ++r)
-        for (int q = 0; q < F; ++q) gparams[off + (size_t)r * F + q] = sums[r * BW + q];
+      for (int e = tid; e < O * F; e += nth) {
+        const int r = e / F, q = e % F;
+        gparams[off + e] = wsum[(size_t)(r / BRC) * BNACC + (r % BRC) * (WM + 1) + q];
+      }
     }
     off += (size_t)O * F;
   }
-  for (int r = 0; r < c.R; ++r) gparams[off + r] = sums[BROWS * BW + r];
+  for (int r = tid; r < c.R; r += nth) gparams[off + r] = wsum[(size_t)(r / BRC) * BNACC + (r % BRC) * (WM + 1) + WM];
 }
 
 // ---------------------------------------------------------------------------------------------
 bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm) {
-  if (wm != BW || cd.d - cd.P != 1) return false;
-  if (cd.kind == NIS_PWQUAD) return cd.K <= BKM;
-  return cd.K <= BLK;
+  if (wm != 4 && wm != 8) return false;
+  if (cd.kind == NIS_PWQUAD) return cd.K <= BKMAX;
+  return cd.K <= NIS_MAX_BINS;
 }
 
-size_t nis_bwd_cell_workspace_doubles(int L, int64_t N) {
-  return (size_t)BW * N + (size_t)BMAXB * BNACC + (size_t)(L + 2) * BNACC;
+static size_t bwd_chunks(int R) { return (size_t)(R + BRC - 1) / BRC; }
+
+size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N) {
+  const int T = cd.d - cd.P;
+  const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.K);
+  const size_t nch = bwd_chunks(R);
+  return (size_t)(2 * wm + R) * N + std::max<size_t>(1, nch) * BMAXB * BNACC + (size_t)(cd.n_hidden + 2) * BNACC + nch * BNACC;
 }
 
-int nis_bwd_cell_run(const CellK& c, const double* x, const double* xo, double* g, const double* bnsave, long ld, long N, double* ws,
-                     double* gparams, hipStream_t s) {
+template <int WM>
+static int bwd_run(const CellK& c, BwdK k, double* ws, double* gparams, hipStream_t s) {
+  const long N = k.N;
+  k.dyp = ws;
+  k.alp = ws + (size_t)WM * N;
+  k.dzp = ws + (size_t)2 * WM * N;
+  const size_t nch = bwd_chunks(c.R);
+  double* part = ws + (size_t)(2 * WM + c.R) * N;
+  double* sums = part + std::max<size_t>(1, nch) * BMAXB * BNACC;
+  double* wsum = sums + (size_t)(c.L + 2) * BNACC;
+  k.part = part;
+  const int grid = (int)std::max<long>(1, std::min<long>(BMAXB, (N + NIS_TPB - 1) / NIS_TPB));
+  const int L = c.L;
+  const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : 16;
+  if (c.kind == NIS_PWLIN)
+    hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWLIN, WM, 4>), dim3(grid), dim3(NIS_TPB), 0, s, k);
+  else if (km == 4)
+    hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 4>), dim3(grid), dim3(NIS_TPB), 0, s, k);
+  else if (km == 8)
+    hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 8>), dim3(grid), dim3(NIS_TPB), 0, s, k);
+  else
+    hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 16>), dim3(grid), dim3(NIS_TPB), 0, s, k);
+  hipLaunchKernelGGL(k_bwd_reduce, dim3(1, 1), dim3(NIS_TPB), 0, s, (const double*)part, grid, 2 * WM, sums, 0L);
+  // last-layer weight / bias gradients (its own records, reduced per chunk)
+  {
+    const int gw = std::max(1, std::min(grid, 256));
+    hipLaunchKernelGGL((k_bwd_wlast<WM>), dim3(gw, (unsigned)nch), dim3(NIS_TPB), 0, s, k);
+    hipLaunchKernelGGL(k_bwd_reduce, dim3(1, (unsigned)nch), dim3(NIS_TPB), 0, s, (const double*)part, gw, BRC * (WM + 1), wsum,
+                       (long)BMAXB * BNACC);
+  }
+  for (int l = L; l >= 1; --l) {
+    const int pass = L - l + 1;                              // 1..L
+    k.sums = sums + (size_t)(pass - 1) * BNACC;
+    const int soff = (pass == 1) ? 0 : WM * WM;
+    hipLaunchKernelGGL((k_cell_bwd_layer<WM>), dim3(grid), dim3(NIS_TPB), 0, s, k, l, soff);
+    hipLaunchKernelGGL(k_bwd_reduce, dim3(1, 1), dim3(NIS_TPB), 0, s, (const double*)part, grid, WM * WM + 2 * WM,
+                       sums + (size_t)pass * BNACC, 0L);
+  }
+  k.sums = sums + (size_t)L * BNACC;
+  hipLaunchKernelGGL((k_cell_bwd_input<WM>), dim3(grid), dim3(NIS_TPB), 0, s, k, WM * WM);
+  hipLaunchKernelGGL(k_bwd_scatter, dim3(1), dim3(NIS_TPB), 0, s, c, WM, (const double*)sums, (const double*)wsum, gparams);
+  return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
+}
+
+int nis_bwd_cell_run(const CellK& c, int wm, const double* x, const double* xo, double* g, const double* bnsave, long ld, long N,
+                     double* ws, double* gparams, hipStream_t s) {
   BwdK k;
   memset(&k, 0, sizeof(k));
   k.c = c;
   k.x = x;
   k.xo = xo;
   k.g = g;
-  k.dyp = ws;
-  double* part = ws + (size_t)BW * N;
-  double* sums = part + (size_t)BMAXB * BNACC;
-  k.part = part;
   k.bn = bnsave;
-  k.gam = c.gb;
   k.ld = ld;
   k.N = N;
-  const int grid = (int)std::max<long>(1, std::min<long>(BMAXB, (N + NIS_TPB - 1) / NIS_TPB));
-  const int L = c.L;
-  if (c.kind == NIS_PWQUAD)
-    hipLaunchKernelGGL(k_cell_bwd_head<NIS_PWQUAD>, dim3(grid), dim3(NIS_TPB), 0, s, k);
-  else
-    hipLaunchKernelGGL(k_cell_bwd_head<NIS_PWLIN>, dim3(grid), dim3(NIS_TPB), 0, s, k);
-  hipLaunchKernelGGL(k_bwd_reduce, dim3(1), dim3(NIS_TPB), 0, s, (const double*)part, grid, BROWS * BW + BROWS + 2 * BW, sums);
-  for (int l = L; l >= 1; --l) {
-    const int pass = L - l + 1;                              // 1..L
-    const double* prev = sums + (size_t)(pass - 1) * BNACC;
-    k.sums = prev;
-    const int soff = (pass == 1) ? BROWS * BW + BROWS : BW * BW;
-    hipLaunchKernelGGL(k_cell_bwd_layer, dim3(grid), dim3(NIS_TPB), 0, s, k, l, soff);
-    hipLaunchKernelGGL(k_bwd_reduce, dim3(1), dim3(NIS_TPB), 0, s, (const double*)part, grid, BW * BW + 2 * BW,
-                       sums + (size_t)pass * BNACC);
-  }
-  k.sums = sums + (size_t)L * BNACC;
-  hipLaunchKernelGGL(k_cell_bwd_input, dim3(grid), dim3(NIS_TPB), 0, s, k, L == 0 ? BROWS * BW + BROWS : BW * BW);
-  hipLaunchKernelGGL(k_bwd_scatter, dim3(1), dim3(64), 0, s, c, (const double*)sums, gparams);
-  return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
+  if (wm == 4) return bwd_run<4>(c, k, ws, gparams, s);
+  if (wm == 8) return bwd_run<8>(c, k, ws, gparams, s);
+  return NIS_E_UNSUPPORTED;
 }

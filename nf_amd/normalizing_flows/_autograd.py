@@ -2,9 +2,9 @@
 
 Forward values ALWAYS come from the HIP kernels.  Gradients (needed only by
 `_train_variance_forward_seq`, /root/reference/nisrep/normalizing_flows/manager.py:275-280):
-  * models whose cells are all in the class the adjoint kernels cover (nf_amd/csrc/flow_bwd.hip: register width 4, one
-    transformed column, PWQuad n_bins <= 4 / PWLin n_bins <= 12 -- the README / C1 / C2 models) use the hand-written HIP
-    backward (`nis_flow_forward_train` + `nis_flow_backward`);
+  * models whose cells are all in the class the adjoint kernels cover (nf_amd/csrc/flow_bwd.hip: conditioner widths and
+    pass-through size <= 8, PWQuad n_bins <= 16, PWLin any n_bins) use the hand-written HIP backward
+    (`nis_flow_forward_train` + `nis_flow_backward`);
   * every other model re-evaluates the same cells with stock PyTorch-ROCm ops on the GPU inside `backward` and
     differentiates that graph (widening the adjoint kernels is the next row).  That
     recomputation is a device-side adjoint helper, not a fallback: it never produces a forward result and refuses to run

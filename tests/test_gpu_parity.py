@@ -126,6 +126,49 @@ def test_cell_module_call_is_differentiable():
     assert abs(float(fd) - float(p.grad[0, 0])) < 1e-4 * max(1.0, abs(float(fd)))
 
 
+def test_hip_backward_general_narrow_models(monkeypatch):
+    """Adjoint kernels on manager-built models with several transformed columns, masks, width-8 conditioners."""
+    from nf_amd.normalizing_flows.manager import PWLinManager, PWQuadManager
+    cases = [("pwquad", dict(d=5, n_cells=2, K=6, NN=[8, 8])), ("pwquad", dict(d=7, n_cells=3, K=16, NN=[6])),
+             ("pwquad", dict(d=9, n_cells=4, K=5, NN=[7, 4])), ("pwlin", dict(d=3, P=1, n_cells=3, K=33, NN=[5, 5], roll=1)),
+             ("pwlin", dict(d=6, P=4, n_cells=2, K=128, NN=[8], roll=2))]
+    for kind, c in cases:
+        torch.manual_seed(c["d"])
+        if kind == "pwquad":
+            NF = PWQuadManager(n_flow=c["d"])
+            NF.create_model(c["n_cells"], c["K"], list(c["NN"]))
+        else:
+            NF = PWLinManager(n_flow=c["d"])
+            NF.create_model(c["P"], c["n_cells"], c["K"], list(c["NN"]), c["roll"])
+        model = NF._model.train()
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.1 * torch.randn_like(p))
+        assert model.engine().backward_supported(), c
+        N, d = 2049, c["d"]
+        x0 = torch.rand(N, d + 1, dtype=torch.double, device=dev()) * (1 - 1e-9)
+        R = torch.randn(N, d + 1, dtype=torch.double, device=dev())
+
+        def grads(force_torch):
+            if force_torch:
+                monkeypatch.setenv("NF_AMD_TORCH_ADJOINT", "1")
+            else:
+                monkeypatch.delenv("NF_AMD_TORCH_ADJOINT", raising=False)
+            for p in model.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            out = model(x)
+            (out * R).sum().backward()
+            return x.grad.clone(), [p.grad.clone() for p in model.parameters()]
+
+        gx_h, gp_h = grads(False)
+        gx_t, gp_t = grads(True)
+        np.testing.assert_allclose(t2n(gx_h), t2n(gx_t), rtol=1e-6, atol=1e-9 * float(gx_t.abs().max()), err_msg=str(c))
+        for (name, _), a, b in zip(model.named_parameters(), gp_h, gp_t):
+            np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-6, atol=1e-9 * max(1.0, float(b.abs().max())),
+                                       err_msg=f"{c} {name}")
+
+
 @pytest.mark.parametrize("kind,K,NN,n_cells", [("pwquad", 4, [3, 3, 3], 2), ("pwquad", 3, [4], 3), ("pwquad", 2, [2, 3], 2),
                                                ("pwlin", 7, [3, 3], 3), ("pwlin", 12, [4, 4, 4], 2)])
 def test_hip_backward_matches_torch_adjoint(kind, K, NN, n_cells, monkeypatch):
