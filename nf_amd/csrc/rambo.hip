@@ -51,7 +51,8 @@ __device__ __forceinline__ double rb_solve(double v, int e) {
   const bool convex = v < vi;
   double u;
   if (convex) {
-    const double us = pow(v / (double)(e + 1), 1.0 / (double)e);
+    const double vr = v / (double)(e + 1);
+    const double us = e == 2 ? sqrt(vr) : e == 3 ? cbrt(vr) : e == 4 ? sqrt(sqrt(vr)) : pow(vr, 1.0 / (double)e);
     double c0 = us / (1.0 - fmin(us, 0.9));
     c0 = fmin(c0, ui);
     const double g0 = rb_ipow(c0, e) * ((double)(e + 1) - (double)e * c0);
@@ -115,7 +116,12 @@ __device__ __forceinline__ double rb_delphi(const V4& a, const V4& b) {         
 // stored as contiguous 16-byte-per-lane streams.  Without staging every lane touches its own cache line per
 // instruction (row stride 64-256 B).
 template <int NF>
-__global__ __launch_bounds__(RB_TPB) void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict__ momenta,
+#ifdef RB_WAVES
+__global__ __launch_bounds__(RB_TPB, RB_WAVES)
+#else
+__global__ __launch_bounds__(RB_TPB)
+#endif
+void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict__ momenta,
                                                   double* __restrict__ weight, int* __restrict__ status) {
   extern __shared__ double rb_lds[];
   constexpr int LM = 4 * (NF + 2);                   // doubles of one sample's momenta
@@ -236,7 +242,8 @@ __global__ __launch_bounds__(RB_TPB) void k_rambo(RamboK k, const double* __rest
       const double m2 = k.d.final_masses[c] * k.d.final_masses[c];
       rb_set_square(p, m2);
       bad_boost |= (Q.e <= 0.) || ((Q.e * Q.e - Q.x * Q.x - Q.y * Q.y - Q.z * Q.z) < 0.);   // utils.py:33
-      rb_boost(p, Q.x / Q.e, Q.y / Q.e, Q.z / Q.e);
+      const double iQe = 1.0 / Q.e;                                                 // boostVector_t: Q_space / Q_0 (utils.py:36)
+      rb_boost(p, Q.x * iQe, Q.y * iQe, Q.z * iQe);
       rb_set_square(p, m2);
       mom[2 + c] = p;
       Q.e -= p.e;
@@ -290,10 +297,13 @@ __global__ __launch_bounds__(RB_TPB) void k_rambo(RamboK k, const double* __rest
     }
 
     // ---- cuts (:285-301)
-    double ptmin = RB_HUGE;
+    double factor = 1.0;
+    if (k.d.pT_mincut > 0.) {                         // min pT >= 0 can never be below a cut <= 0 (:285-288)
+      double ptmin = RB_HUGE;
 #pragma unroll
-    for (int l = 0; l < NF; ++l) ptmin = fmin(ptmin, fabs(sqrt(mom[2 + l].x * mom[2 + l].x + mom[2 + l].y * mom[2 + l].y)));
-    double factor = (ptmin < k.d.pT_mincut) ? 0.0 : 1.0;
+      for (int l = 0; l < NF; ++l) ptmin = fmin(ptmin, fabs(sqrt(mom[2 + l].x * mom[2 + l].x + mom[2 + l].y * mom[2 + l].y)));
+      factor = (ptmin < k.d.pT_mincut) ? 0.0 : 1.0;
+    }
     const bool need_eta = (k.d.delR_mincut > 0.) || (k.d.rap_maxcut > 0.);
     if (need_eta) {
       double eta[NF];
