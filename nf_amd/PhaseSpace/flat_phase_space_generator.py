@@ -123,6 +123,9 @@ class FlatInvertiblePhasespace(VirtualPhaseSpaceGenerator):
     def weights_from_planes(self, E_cm, planes, cols, N, pT_mincut=-1, delR_mincut=-1, rap_maxcut=-1):
         """Weight only, reading the random numbers from column planes (the flow's internal layout):
         the integrand side of a fused flow -> RAMBO evaluation.  No momenta are written."""
+        _lib.require_gpu()
+        ncol = self.nDimPhaseSpace() + (2 if self.pdf_active else 0)
+        assert len(cols) == ncol, f"the flow has {len(cols)} columns, the phase space needs {ncol}"
         weight = torch.empty(N, dtype=torch.double, device=planes.device)
         status = torch.zeros(1, dtype=torch.int32, device=planes.device)
         self.collider_energy = E_cm

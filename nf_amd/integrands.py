@@ -41,3 +41,23 @@ class One:
 
     def __call__(self, x):
         return torch.ones_like(x[:, 0])
+
+
+class RamboWeight:
+    """Phase-space integrand: f(x) = weight of `FlatInvertiblePhasespace.generateKinematics_batch(E_cm, x, cuts)` (unit
+    matrix element), i.e. how the reference's experiment driver feeds RAMBO to the flow.
+    Callable on a (N, d) CUDA tensor like any user integrand; `from_planes` lets `integrate` evaluate it straight from the
+    flow's column planes (no (N, d) matrix, no momenta written)."""
+
+    def __init__(self, generator, E_cm, pT_mincut=-1, delR_mincut=-1, rap_maxcut=-1, pdgs=(0, 0)):
+        self.gen, self.E_cm = generator, E_cm
+        self.cuts = (pT_mincut, delR_mincut, rap_maxcut)
+        self.pdgs = list(pdgs)
+
+    def __call__(self, x):
+        _, wgt = self.gen.generateKinematics_batch(self.E_cm, x, self.cuts[0], self.cuts[1], self.cuts[2], self.pdgs)
+        return wgt
+
+    def from_planes(self, planes, out_col, N):
+        wgt, status = self.gen.weights_from_planes(self.E_cm, planes, out_col, N, *self.cuts)
+        return wgt

@@ -333,8 +333,14 @@ class BasicManager(ModelAPI):
                 eng.integrate_steps(w, model.training, f.nis_kind, f.nis_params, out[i:i + g])
                 i += g
             return out
+        planar = hasattr(f, "from_planes") and isinstance(model, FlowSequential)
         for i in range(nitn):
             w = self._uniform(neval, dev, torch.float32, "integrate")
+            if planar:                      # e.g. RAMBO weight: reads the flow's column planes, X is never assembled
+                res = model.flow_forward(w)
+                eng = model.engine()
+                out[i] = hip_moments(f.from_planes(res["planes"], eng.out_col, neval), res["planes"][eng.d])
+                continue
             with torch.no_grad():
                 XJ = model(self.format_input(w, dev)).detach()
                 out[i] = hip_moments(f(XJ[:, :-1]), XJ[:, -1])

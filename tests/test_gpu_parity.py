@@ -507,3 +507,34 @@ def test_batched_iterations_equal_one_by_one(G):
     np.testing.assert_allclose(t2n(outA), t2n(outB), rtol=1e-12)
     for k in sd:
         np.testing.assert_allclose(t2n(A._model.state_dict()[k]), t2n(B._model.state_dict()[k]), rtol=1e-12, atol=1e-15, err_msg=k)
+
+
+@pytest.mark.parametrize("cfg", ["massive8", "tau10"])
+def test_flow_into_rambo_integrand_vs_oracle(cfg):
+    """C4-style pipeline: flow output -> RAMBO weight * J -> moments, planar (fused) path == materialised path == oracle."""
+    from nf_amd import integrands
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    if cfg == "massive8":
+        d, init, final, pdf, E, cuts = 8, [100., 100.], [100.] * 4, False, 1000., (0, 0, -1)
+    else:
+        d, init, final, pdf, E, cuts = 10, [0., 0.], [100.] * 4, True, 13000., (10., 0.4, 4.0)
+    torch.manual_seed(d)
+    NF = build_manager(dict(kind="pwquad", d=d, n_cells=2, K=8, NN=[16, 16]))
+    gen = FlatInvertiblePhasespace(init, final, pdf=None, pdf_active=pdf, tau=True)
+    f = integrands.RamboWeight(gen, E, *cuts)
+    N = 6001
+    w = torch.rand(1, N, d, dtype=torch.float32)
+    params = {k: t2n(v) for k, v in NF._model.state_dict().items()}
+    steps = oflow.plan_pwquad(d, 2, 8)
+    XJ = oflow.model_forward(w[0].numpy().astype(np.float64), params, steps, True)
+    _, wref = orambo.generate_kinematics(init, final, E, XJ[:, :d], *cuts, pdf_active=pdf, tau=True)
+    n, m, v, mx = oflow.moments(wref * XJ[:, d])
+    NF.sample_hook = Replay([w[0].numpy()])
+    mom_planar = t2n(NF.moments_batches(f, 1, N, dev()))[0]
+    NF2 = build_manager(dict(kind="pwquad", d=d, n_cells=2, K=8, NN=[16, 16]), params)
+    NF2.sample_hook = Replay([w[0].numpy()])
+    mom_plain = t2n(NF2.moments_batches(lambda x: f(x), 1, N, dev()))[0]
+    for got in (mom_planar, mom_plain):
+        assert got[0] == N
+        np.testing.assert_allclose(got[1], m, rtol=1e-8)
+        np.testing.assert_allclose(got[2] / (N - 1), v, rtol=1e-7)
