@@ -147,20 +147,9 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
 #pragma unroll
         for (int q = 0; q < KM; ++q)
           if (q < K) wn += W[q];
-        double run = 0.0, best = 1e-30, left = 0.0;
-        int b = 0;
-#pragma unroll
-        for (int q = 0; q < KM; ++q)
-          if (q < K) {
-            run += W[q];
-            const double cs = run / wn;
-            const double v = (cs > xb) ? 0.0 : cs;
-            const bool up = v > best;
-            best = up ? v : best;
-            b = up ? q + 1 : b;
-            left = up ? cs : left;
-          }
-        b = (b > K - 1) ? K - 1 : b;
+        int b;
+        double left;
+        pwquad_bin<KM, false>(xb, K, W, wn, &b, &left);
         const double iwn = 1.0 / wn;
         double area = 0.0;
 #pragma unroll

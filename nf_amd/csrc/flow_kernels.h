@@ -291,11 +291,60 @@ __device__ __forceinline__ double lerp_torch(double a, double b, double w) {
   return (w < 0.5) ? lo : hi;
 }
 
+// Bin of x among the normalised cumulative widths, with the reference's semantics (coupling_cells.py:198-202):
+//   index = argmax([1e-30, c_0, .., c_{K-1}]) (first maximum),  c_k = Wsum_k if Wsum_k <= x else 0,  Wsum_k = fl(run_k / wn),
+// run_k the sequential cumsum of the raw widths.  Wsum is non-decreasing, so the kept values form a prefix and the
+// maximum is its last element.  "Wsum_k <= x" is decided WITHOUT a division whenever run_k is outside a 2^-50 relative
+// band around fl(x * wn) (then the correctly rounded quotient provably falls on the same side of x); inside the band
+// -- probability ~1e-15 per bin -- the true division decides.  One division yields the selected left edge.
+// Ties (equal Wsum for consecutive bins, i.e. widths that vanish in the cumsum) resolve to the first bin, as argmax does.
+template <int KM, bool KEXACT>
+__device__ __forceinline__ void pwquad_bin(double xb, int Krt, const double (&W)[KM], double wn, int* idx_out, double* left_out) {
+  const int K = KEXACT ? KM : Krt;
+  const double q = xb * wn;
+  const double qlo = q * (1.0 - 0x1p-50), qhi = q * (1.0 + 0x1p-50);
+  double run = 0.0, bestrun = 0.0;
+  int idx = 0;
+  bool ambany = false;
+#pragma unroll
+  for (int k = 0; k < KM; ++k)
+    if (KEXACT || k < K) {
+      run += W[k];
+      const bool le = run <= qlo;
+      ambany |= (run > qlo) && (run < qhi);
+      const bool up = le && (run > bestrun);
+      bestrun = up ? run : bestrun;
+      idx = up ? k + 1 : idx;
+    }
+  if (__any(ambany)) {                                   // one wave-uniform test per column; practically never taken
+    run = 0.0;
+    bestrun = 0.0;
+    idx = 0;
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+      double wk = W[0];
+#pragma unroll
+      for (int u = 1; u < KM; ++u) wk = (u == k) ? W[u] : wk;
+      run += wk;
+      const bool le = !((run / wn) > xb);                // the reference's comparison, verbatim
+      const bool up = le && (run > bestrun);
+      bestrun = up ? run : bestrun;
+      idx = up ? k + 1 : idx;
+    }
+  }
+  double left = bestrun / wn;                            // Wsum2[idx]  (:186, :198)
+  const bool none = !(left > 1e-30);                     // the 1e-30 sentinel wins: bin 0, left edge 0
+  idx = none ? 0 : idx;
+  left = none ? 0.0 : left;
+  idx = (idx > K - 1) ? K - 1 : idx;
+  *idx_out = idx;
+  *left_out = left;
+}
+
 // Piecewise-quadratic transform of one column (coupling_cells.py:167-225).  V: K+1 vertex heights
 // (raw exp), W: K bin widths (raw exp).  Returns y; *jf = d y / d x; *bin = bin index.
-// The cumulative widths that decide the bin are formed exactly as the reference does (cumsum of the raw
-// exponentials, then a true division by the total), so the selected bin is bit-identical for identical
-// conditioner outputs; the remaining normalisations multiply by a reciprocal (<= 1 ulp from a division).
+// The bin is selected with the reference's exact semantics (pwquad_bin); the remaining normalisations multiply by a
+// reciprocal (<= 1 ulp from a division).
 template <int KM, bool KEXACT>
 __device__ __forceinline__ double pwquad_column(double xb, int Krt, double (&V)[KM + 1], double (&W)[KM], double* jf, int* bin) {
   const int K = KEXACT ? KM : Krt;
@@ -304,21 +353,9 @@ __device__ __forceinline__ double pwquad_column(double xb, int Krt, double (&V)[
 #pragma unroll
   for (int k = 0; k < KM; ++k)
     if (k < K) wn += W[k];                                        // Wsum[-1]  :180-182
-  // bin search on the normalised cumulative widths, "first maximum of [1e-30, Wsum_k*(Wsum_k<=x)]"  :198-202
-  double run = 0.0, best = 1e-30, left = 0.0;
-  int idx = 0;
-#pragma unroll
-  for (int k = 0; k < KM; ++k)
-    if (k < K) {
-      run += W[k];
-      const double cs = run / wn;                                 // Wsum/Wnorms :186
-      const double v = (cs > xb) ? 0.0 : cs;
-      const bool up = v > best;                                   // selects only (no divergent branch)
-      best = up ? v : best;
-      idx = up ? k + 1 : idx;
-      left = up ? cs : left;                                      // Wsum2[idx]
-    }
-  idx = (idx > K - 1) ? K - 1 : idx;
+  int idx;
+  double left;
+  pwquad_bin<KM, KEXACT>(xb, Krt, W, wn, &idx, &left);
   const double iwn = 1.0 / wn;
   double area = 0.0;
 #pragma unroll
