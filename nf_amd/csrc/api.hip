@@ -657,6 +657,7 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
     }
     if (c.G > 1) HIP_OK(launch_finalize<WM>(c, 0, s));
     for (int l = 1; l <= c.L; ++l) {
+      if (l == 1 && c.derive1) continue;                       // BN_1 was derived from BN_0 (single pass-through column)
       {
         NisProfScope ps(NIS_K_STATS, s);
         if (mfma)
@@ -797,6 +798,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     c.G = G;
     c.coef_gs = train ? (cd.n_hidden + 1) * 2 * L.WM : 0;     // eval: every batch shares the running-stat coefficients
     c.plane_gs = plane_gs;
+    c.derive1 = (train && cd.P == 1 && !env_int("NIS_NO_DERIVE1", 0)) ? 1 : 0;
     c.out_off = o.hist ? plane_gs : 0;
     c.bnsave = (o.hist && o.bnsave && train) ? o.bnsave + bn_off : nullptr;
     bn_off += (size_t)(cd.n_hidden + 1) * 4 * L.WM;

@@ -27,7 +27,7 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
   double* coef_g = c.coef + (size_t)g * c.coef_gs;
   for (int idx = tid; idx < upto * 2 * WM; idx += TPB) {
     const int l = idx / (2 * WM);
-    if (l != fresh) lds_coef[idx] = coef_g[idx];
+    if (l != fresh && !(fresh == 0 && c.derive1 && l == 1)) lds_coef[idx] = coef_g[idx];
   }
   if (fresh >= 0 && fresh < upto) {
     constexpr int S = TPB / WM;              // slices of partial records per feature (power of two)
@@ -95,6 +95,57 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
           c.bnsave[(fresh * 4 + 1) * WM + j] = shift;
           c.bnsave[(fresh * 4 + 2) * WM + j] = mean_s;
           c.bnsave[(fresh * 4 + 3) * WM + j] = rstd_s;
+        }
+      }
+      if (fresh == 0 && c.derive1 && j == 0) {       // hand BN_0's statistics to the BN_1 derivation below
+        const double mean = ref + s1 / n;
+        red[3 * TPB - 4] = n;
+        red[3 * TPB - 3] = mean;
+        red[3 * TPB - 2] = fmax(s2 - s1 * s1 / n, 0.0) / n;
+        red[3 * TPB - 1] = scale;
+      }
+    }
+    if (fresh == 0 && c.derive1 && upto >= 1) {
+      // P == 1: the pre-BN_1 activation h1_j = W0[j][0] * (scale0 * x + shift0) is affine in x, hence
+      //   mean(h1_j) = W0[j][0] * (scale0 * mean0 + shift0),   var_b(h1_j) = (W0[j][0] * scale0)^2 * var_b(x)
+      __syncthreads();
+      if (tid < WM) {
+        const double n = red[3 * TPB - 4], mean0 = red[3 * TPB - 3], var0 = red[3 * TPB - 2], scale0 = red[3 * TPB - 1];
+        const double shift0 = c.gb[1 * WM + 0] - mean0 * scale0;
+        const int F1 = cellk_feat(c, 1);
+        double scale = 0.0, shift = 0.0, mean1 = 0.0, var1 = 0.0;
+        if (tid < F1) {
+          const double a = c.wp[(size_t)tid * WM + 0];
+          mean1 = a * fma(scale0, mean0, shift0);
+          const double as = a * scale0;
+          var1 = as * as * var0;
+          const double gam = c.gb[(1 * 2 + 0) * WM + tid], be = c.gb[(1 * 2 + 1) * WM + tid];
+          scale = gam / sqrt(var1 + NIS_BN_EPS);
+          shift = be - mean1 * scale;
+          if (writer) {
+            const double unb = n > 1.0 ? var1 * (n / (n - 1.0)) : var1;
+            if (c.G == 1) {
+              double* run = c.running + cellk_running_off(c, 1);
+              run[tid] = (1.0 - NIS_BN_MOM) * run[tid] + NIS_BN_MOM * mean1;
+              run[F1 + tid] = (1.0 - NIS_BN_MOM) * run[F1 + tid] + NIS_BN_MOM * unb;
+              if (tid == 0 && c.tracked) c.tracked[1] += 1;
+            } else {
+              c.gstat[(((size_t)1 * c.G + g) * 2 + 0) * WM + tid] = mean1;
+              c.gstat[(((size_t)1 * c.G + g) * 2 + 1) * WM + tid] = unb;
+            }
+          }
+        }
+        lds_coef[(1 * 2 + 0) * WM + tid] = scale;
+        lds_coef[(1 * 2 + 1) * WM + tid] = shift;
+        if (writer) {
+          coef_g[(1 * 2 + 0) * WM + tid] = scale;
+          coef_g[(1 * 2 + 1) * WM + tid] = shift;
+          if (c.bnsave && c.G == 1) {
+            c.bnsave[(1 * 4 + 0) * WM + tid] = scale;
+            c.bnsave[(1 * 4 + 1) * WM + tid] = shift;
+            c.bnsave[(1 * 4 + 2) * WM + tid] = mean1;
+            c.bnsave[(1 * 4 + 3) * WM + tid] = tid < F1 ? 1.0 / sqrt(var1 + NIS_BN_EPS) : 0.0;
+          }
         }
       }
     }
@@ -193,7 +244,7 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
   const int g = blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   // G == 1: the previous layer's records are merged here; G > 1: k_bn_finalize already published the coefficients
-  load_coefs<WM, TPB>(c, g, layer, c.G == 1 ? layer - 1 : -1, blockIdx.x == 0, lds_coef, red);
+  load_coefs<WM, TPB>(c, g, layer, c.G == 1 ? cellk_fresh(c, layer) : -1, blockIdx.x == 0, lds_coef, red);
 
   double S1[WM], S2[WM];
 #pragma unroll
@@ -405,7 +456,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   const int g = blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   nis_exp_init(etab);
-  load_coefs<WM, NIS_TPB>(c, g, c.L + 1, (bn_train && c.G == 1) ? c.L : -1, blockIdx.x == 0, lds_coef, red);
+  load_coefs<WM, NIS_TPB>(c, g, c.L + 1, (bn_train && c.G == 1) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red);
   nis_cptr wl = as_const(c.wlast);
   nis_cptr bias = as_const(c.bias);
   constexpr bool RIDERS = WM <= 8;          // wide conditioners keep their registers for the GEMV

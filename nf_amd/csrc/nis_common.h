@@ -132,11 +132,16 @@ struct CellK {
   long plane_gs;                         // doubles between the plane sets of consecutive g: (d+1)*ld
   double* gstat;                         // G > 1: (L+1) x G x 2 x WM  batch mean | unbiased var for k_running_update
   // ---- training history (for the adjoint kernels): outputs go to the NEXT plane set, BN statistics are kept
+  int derive1;                           // 1 (P == 1): BN_1's batch statistics follow analytically from BN_0's
+                                         //   (h1_j = W0_j0 * BN_0(x) is affine in the single pass-through column),
+                                         //   so the layer-1 statistics launch is skipped
   long out_off;                          // doubles from a cell's input planes to its output planes (0: in place)
   double* bnsave;                        // (L+1) x 4 x WM: scale | shift | batch mean | 1/sqrt(var+eps)  (may be null)
 };
 
 __host__ __device__ static inline int cellk_feat(const CellK& c, int l) { return l == 0 ? c.P : c.width[l - 1]; }
+// BN layer whose records the prologue of a launch that needs the coefficients of layers < upto has to merge (G == 1)
+__host__ __device__ static inline int cellk_fresh(const CellK& c, int upto) { return (c.derive1 && upto == 2) ? 0 : upto - 1; }
 // offset (in doubles) of BN layer l inside the reference-order running-stat blob
 __host__ __device__ static inline int cellk_running_off(const CellK& c, int l) {
   int o = 0;
