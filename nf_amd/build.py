@@ -1,6 +1,6 @@
 """Build libnis_hip.so (gfx950) in-tree with hipcc.  `python -m nf_amd.build [--force]`.
 
-The five conditioner-width translation units compile in parallel; objects go to nf_amd/csrc/build/,
+The per-conditioner-width translation units (forward: 5, wide adjoint: 3) compile in parallel; objects go to nf_amd/csrc/build/,
 the shared library to nf_amd/lib/libnis_hip.so (git-ignored, travels to the GPU box with the snapshot).
 """
 import os
@@ -18,7 +18,8 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 UNITS = [("api", "api.hip", []), ("rambo", "rambo.hip", []), ("flow_bwd", "flow_bwd.hip", [])] + \
-        [(f"flow_wm{w}", "flow_wm.hip", [f"-DNIS_WM={w}"]) for w in (4, 8, 16, 32, 64)]
+        [(f"flow_wm{w}", "flow_wm.hip", [f"-DNIS_WM={w}"]) for w in (4, 8, 16, 32, 64)] + \
+        [(f"flow_bwd_wm{w}", "flow_bwd_wm.hip", [f"-DNIS_WM={w}"]) for w in (16, 32, 64)]
 
 
 def _sources():

@@ -640,7 +640,7 @@ struct RunOpts {
 bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm);
 size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N);
 int nis_bwd_cell_run(const CellK& c, int wm, const double* x, const double* xo, double* g, const double* bnsave, long ld, long N,
-                     double* ws, double* gparams, hipStream_t s);
+                     double* ws, double* gparams, const MfmaW& mw, hipStream_t s);
 
 static bool use_mfma() {
   static const int off = env_int("NIS_NO_MFMA", 0);
@@ -972,14 +972,21 @@ extern "C" int nis_flow_forward_train(nis_flow* f, const void* w, int32_t w_dtyp
   return flow_run(f, w, w_dtype, N, params, running, planes_hist, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
 }
 
+// doubles of the packed parameter image a cell's adjoint works from (row-major images + MFMA fragments when wide)
+static size_t bwd_pack_doubles(const nis_cell_desc& cd, size_t WM) {
+  const size_t R = cell_R(cd), nl = cd.n_hidden, RT = (R + 15) / 16;
+  size_t n = nl * WM * WM + R * WM + (R + 7) / 8 * 8 + 2 * (nl + 1) * 2 * WM;
+  if (WM >= 16) n += nl * WM * WM + RT * 16 * WM + RT * 16;
+  return n;
+}
+
 extern "C" size_t nis_flow_backward_workspace_bytes(const nis_flow* f, int64_t N) {
   size_t cellws = 0, pk = 0;
   std::vector<CellLayout> lay;
   flow_layout(f, 1, &lay, nullptr);
   for (int ci = 0; ci < f->n_cells; ++ci) {
     cellws = std::max(cellws, nis_bwd_cell_workspace_doubles(f->cells[ci], lay[ci].WM, N));
-    const size_t WM = lay[ci].WM, R = cell_R(f->cells[ci]), nl = f->cells[ci].n_hidden;
-    pk = std::max(pk, nl * WM * WM + R * WM + (R + 7) / 8 * 8 + 2 * (nl + 1) * 2 * WM);
+    pk = std::max(pk, bwd_pack_doubles(f->cells[ci], lay[ci].WM));
   }
   return ((size_t)(f->d + 1) * N + cellws + pk + 64) * sizeof(double);
 }
@@ -1042,10 +1049,25 @@ extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t
     c.bias = bias;
     c.gb = gb;
     c.coef = coef;
-    hipLaunchKernelGGL(k_pack, dim3(1), dim3(NIS_TPB), 0, s, c, (int)WM, params[ci], (const double*)nullptr, 0, wp, wlast, bias, gb);
+    hipLaunchKernelGGL(k_pack, dim3(WM >= 16 ? 32 : 1), dim3(NIS_TPB), 0, s, c, (int)WM, params[ci], (const double*)nullptr, 0, wp, wlast,
+                       bias, gb);
     HIP_OK(hipGetLastError());
+    MfmaW mw;
+    mw.wm_all = mw.wm_last = mw.bias_pad = nullptr;
+    if (WM >= 16) {
+      const size_t RT = (R + 15) / 16;
+      double* wm_all = coef + (nl + 1) * 2 * WM;
+      double* wm_last = wm_all + nl * WM * WM;
+      double* bias_pad = wm_last + RT * 16 * WM;
+      hipLaunchKernelGGL(k_pack_mfma, dim3(32), dim3(NIS_TPB), 0, s, (int)WM, c.L, c.R, (int)RT, (const double*)wp, (const double*)wlast,
+                         (const double*)bias, wm_all, wm_last, bias_pad);
+      HIP_OK(hipGetLastError());
+      mw.wm_all = wm_all;
+      mw.wm_last = wm_last;
+      mw.bias_pad = bias_pad;
+    }
     int rc = nis_bwd_cell_run(c, L.WM, planes_hist + (size_t)ci * set, planes_hist + (size_t)(ci + 1) * set, g, bnsave + bn_off,
-                              (long)ld, (long)N, cellws, gparams[ci], s);
+                              (long)ld, (long)N, cellws, gparams[ci], mw, s);
     if (rc != NIS_OK) return rc;
   }
   if (gx_out) {

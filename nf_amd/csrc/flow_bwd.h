@@ -1,0 +1,42 @@
+// Shared declarations of the adjoint kernels: flow_bwd.hip (narrow conditioners, fp64 VALU) and
+// flow_bwd_wm.hip (wide conditioners, v_mfma_f64_16x16x4_f64).
+#pragma once
+#include "flow_kernels.h"
+
+#define BNACC 80              // record length (>= WM*WM + 2*WM for WM = 8, >= BRC*(WM+1))
+#define BRC 8                 // rows of the last layer per wlast chunk
+#define BMAXB 1024            // max workgroups of an adjoint launch
+#define BKMAX 16              // max PWQuad bins handled here
+
+struct BwdK {
+  CellK c;                    // same per-cell view as the forward (in_plane, sizes, packed weights)
+  const double* x;            // plane set of the cell's input  (d+1 planes, leading dimension ld)
+  const double* xo;           // plane set of the cell's output (J_out lives in plane d)
+  double* g;                  // gradient planes (d+1): in = dL/d(output set), out = dL/d(input set), in place
+  double* dyp;                // WM planes: dL/d(BN_l output) of the layer being processed
+  double* alp;                // WM planes: a_L (input of the last Linear)
+  double* dzp;                // R planes: dL/dZ
+  const double* bn;           // saved (L+1) x 4 x WM: scale | shift | mean | rstd
+  double* part;               // records of this launch
+  const double* sums;         // reduced record of the previous launch (BNACC)
+  long ld, N;
+};
+
+// ---- wide conditioners (register width 16 / 32 / 64), one translation unit per width
+template <int WM>
+bool bwd_wide_supported(const nis_cell_desc& cd);
+template <int WM>
+size_t bwd_wide_workspace_doubles(const nis_cell_desc& cd, int64_t N);
+template <int WM>
+int bwd_wide_run(const CellK& c, BwdK k, const MfmaW& mw, double* ws, double* gparams, hipStream_t s);
+#define NIS_DECL_BWD_WM(W)                                                                            \
+  template <>                                                                                         \
+  bool bwd_wide_supported<W>(const nis_cell_desc& cd);                                                \
+  template <>                                                                                         \
+  size_t bwd_wide_workspace_doubles<W>(const nis_cell_desc& cd, int64_t N);                           \
+  template <>                                                                                         \
+  int bwd_wide_run<W>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, double* gparams, hipStream_t s);
+NIS_DECL_BWD_WM(16)
+NIS_DECL_BWD_WM(32)
+NIS_DECL_BWD_WM(64)
+#undef NIS_DECL_BWD_WM

@@ -1,6 +1,6 @@
 // Hand-written adjoint (backward) of a coupling cell with a narrow conditioner (register width WM = 4 or 8, any
-// number of transformed columns, PWQuad n_bins <= 16, PWLin any n_bins), train-mode BatchNorm.  Wider conditioners keep
-// the stock-PyTorch adjoint (nf_amd/normalizing_flows/_autograd.py) until their weight-gradient GEMMs move to MFMA.
+// number of transformed columns, PWQuad n_bins <= 16, PWLin any n_bins), train-mode BatchNorm.  Wider conditioners
+// (WM = 16 / 32 / 64) run the same chain on the f64 matrix cores: flow_bwd_wm.hip.
 //
 // Reverse of:  BN_0 -> Lin_0 -> [BN_l -> ReLU -> Lin_l]_{l=1..L} -> exp / normalise -> quadratic (linear) CDF, J *= dy/dx
 // (reference forward: normalizing_flows/layers/coupling_cells.py:107-142, :159-228, :236-254; the reference obtains these
@@ -16,26 +16,7 @@
 #include <algorithm>
 #include <cstring>
 
-#include "flow_kernels.h"
-
-#define BNACC 80              // record length (>= WM*WM + 2*WM for WM = 8, >= BRC*(WM+1))
-#define BRC 8                 // rows of the last layer per wlast chunk
-#define BMAXB 1024            // max workgroups of an adjoint launch
-#define BKMAX 16              // max PWQuad bins handled here
-
-struct BwdK {
-  CellK c;                    // same per-cell view as the forward (in_plane, sizes, packed weights)
-  const double* x;            // plane set of the cell's input  (d+1 planes, leading dimension ld)
-  const double* xo;           // plane set of the cell's output (J_out lives in plane d)
-  double* g;                  // gradient planes (d+1): in = dL/d(output set), out = dL/d(input set), in place
-  double* dyp;                // WM planes: dL/d(BN_l output) of the layer being processed
-  double* alp;                // WM planes: a_L (input of the last Linear)
-  double* dzp;                // R planes: dL/dZ
-  const double* bn;           // saved (L+1) x 4 x WM: scale | shift | mean | rstd
-  double* part;               // records of this launch
-  const double* sums;         // reduced record of the previous launch (BNACC)
-  long ld, N;
-};
+#include "flow_bwd.h"
 
 template <int NACC>
 __device__ __forceinline__ void bw_block_reduce(const double (&acc)[NACC], double* part) {
@@ -398,6 +379,9 @@ __global__ void k_bwd_scatter(CellK c, int WM, const double* __restrict__ sums, 
 
 // ---------------------------------------------------------------------------------------------
 bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm) {
+  if (wm == 16) return bwd_wide_supported<16>(cd);
+  if (wm == 32) return bwd_wide_supported<32>(cd);
+  if (wm == 64) return bwd_wide_supported<64>(cd);
   if (wm != 4 && wm != 8) return false;
   if (cd.kind == NIS_PWQUAD) return cd.K <= BKMAX;
   return cd.K <= NIS_MAX_BINS;
@@ -406,6 +390,9 @@ bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm) {
 static size_t bwd_chunks(int R) { return (size_t)(R + BRC - 1) / BRC; }
 
 size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N) {
+  if (wm == 16) return bwd_wide_workspace_doubles<16>(cd, N);
+  if (wm == 32) return bwd_wide_workspace_doubles<32>(cd, N);
+  if (wm == 64) return bwd_wide_workspace_doubles<64>(cd, N);
   const int T = cd.d - cd.P;
   const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.K);
   const size_t nch = bwd_chunks(R);
@@ -457,7 +444,7 @@ static int bwd_run(const CellK& c, BwdK k, double* ws, double* gparams, hipStrea
 }
 
 int nis_bwd_cell_run(const CellK& c, int wm, const double* x, const double* xo, double* g, const double* bnsave, long ld, long N,
-                     double* ws, double* gparams, hipStream_t s) {
+                     double* ws, double* gparams, const MfmaW& mw, hipStream_t s) {
   BwdK k;
   memset(&k, 0, sizeof(k));
   k.c = c;
@@ -469,5 +456,8 @@ int nis_bwd_cell_run(const CellK& c, int wm, const double* x, const double* xo, 
   k.N = N;
   if (wm == 4) return bwd_run<4>(c, k, ws, gparams, s);
   if (wm == 8) return bwd_run<8>(c, k, ws, gparams, s);
+  if (wm == 16) return bwd_wide_run<16>(c, k, mw, ws, gparams, s);
+  if (wm == 32) return bwd_wide_run<32>(c, k, mw, ws, gparams, s);
+  if (wm == 64) return bwd_wide_run<64>(c, k, mw, ws, gparams, s);
   return NIS_E_UNSUPPORTED;
 }

@@ -1,0 +1,666 @@
+// Adjoint (backward) of a coupling cell with a WIDE conditioner (register width NIS_WM = 16 / 32 / 64), train-mode
+// BatchNorm, on the f64 matrix cores (v_mfma_f64_16x16x4_f64).  One translation unit per width (-DNIS_WM=...).
+// Reference: the gradients torch.autograd produces at normalizing_flows/manager.py:275-278 for the forward of
+// normalizing_flows/layers/coupling_cells.py:107-142, :159-228, :236-254.
+//
+// Same launch chain as the narrow adjoint (flow_bwd.hip): head -> [layer L .. 1] -> input, every step followed by a
+// fixed-order reduction of its per-workgroup records.  Orientation as in flow_mfma.h: tiles are C[feature][sample]
+// with 16 samples per tile, so
+//   * the forward is recomputed register-to-register (accumulators of one layer are the B operands of the next);
+//   * d a = W^T d h needs no transposition either: the k index of the MFMA runs over the rows of W, lane l supplies
+//     W[4 ks + (l>>4)][16 qt + (l&15)] straight from the row-major weight image and d h[4 ks + (l>>4)][sample l&15]
+//     from its accumulator registers;
+//   * in the head the bijector adjoint leaves dZ of (sample l&15, column slot l>>4) in that lane's registers: with the
+//     k index running over the 4 column slots of a batch, row q of each slot is one MFMA k-step of d a_L = W_L^T dZ;
+//   * only the weight gradients dW = d h a^T reduce over SAMPLES, which this layout keeps in the n index.  They are
+//     taken from the planes the chain stores anyway (dZ, d h, a) by a tall-skinny MFMA GEMM (k_bwd_xty_w) whose
+//     k index runs over samples.
+#include <algorithm>
+#include <cstring>
+
+#include "flow_bwd.h"
+#include "flow_mfma.h"
+
+#ifndef NIS_WM
+#error "compile with -DNIS_WM=<16|32|64>"
+#endif
+
+namespace {
+constexpr int WM = NIS_WM, JT = WM / 16, KQ = WM / 4, NW = 4, TPB = 256, NCB = NIS_MF_NCB;
+constexpr int ST = WM >= 64 ? 1 : 2;            // sample tiles (of 16) per wave pass
+constexpr int RPW = WM >= 64 ? 2 : 4;           // row tiles (of 16) per workgroup of the weight-gradient GEMM
+constexpr int GREC = RPW * 16 * (WM + 1);       // its record: RPW*16 rows x (WM products | row sum)
+constexpr int SREC = 2 * WM;                    // BatchNorm record: sum dy | sum dy*xhat
+constexpr int BNLDS = (NIS_MAX_HIDDEN + 1) * 4 * WM;
+
+struct BwdW {
+  const double* wm_all;                         // MFMA fragments of the hidden layers / last layer (k_pack_mfma)
+  const double* wm_last;
+  const double* bias_pad;
+  double* dhp;                                  // WM planes: dL/d(pre-BN_l activations), A operand of the dW GEMM
+};
+
+__device__ __forceinline__ nis_d4 mfma(double a, double b, nis_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ void bw_dense(const double* __restrict__ wm, int nq, const double (&H)[KQ][ST], nis_d4 (&acc)[JT][ST]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+    for (int st = 0; st < ST; ++st) acc[jt][st] = nis_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+      if (q < nq) {
+        const double a = wm[((size_t)jt * KQ + q) * 64 + lane];
+#pragma unroll
+        for (int st = 0; st < ST; ++st) acc[jt][st] = mfma(a, H[q][st], acc[jt][st]);
+      }
+  }
+}
+
+// Forward recompute with the SAVED statistics up to BN layer `upto` (1..L).  Feature of H[q] / XH[q]: 4 q + (lane>>4).
+//   acc: pre-BN activations of BN_upto | H: input of Linear_{upto-1} | XH: normalised input of BN_{upto-1}
+__device__ __forceinline__ void bww_forward(const CellK& c, const double* __restrict__ x, long ld, long N, long base, const int* lds_plane,
+                                            const double* lds_bn, const double* __restrict__ wm_all, int upto, double (&H)[KQ][ST],
+                                            double (&XH)[KQ][ST], nis_d4 (&acc)[JT][ST]) {
+  const int lane = threadIdx.x & 63, gq = lane >> 4, s = lane & 15;
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int kf = 4 * q + gq;
+    const bool kv = kf < c.P;
+    const size_t pl = kv ? (size_t)lds_plane[kf] * ld : 0;
+    const double sc = lds_bn[kf], sh = lds_bn[WM + kf], mu = lds_bn[2 * WM + kf], rs = lds_bn[3 * WM + kf];
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+      const long i = base + 16 * st + s;
+      const double xv = (kv && i < N) ? x[pl + i] : 0.0;
+      H[q][st] = kv ? fma(xv, sc, sh) : 0.0;
+      XH[q][st] = kv ? (xv - mu) * rs : 0.0;
+    }
+  }
+  for (int l = 0; l < upto; ++l) {
+    bw_dense(wm_all + (size_t)l * WM * WM, l == 0 ? (c.P + 3) / 4 : KQ, H, acc);
+    if (l + 1 < upto) {
+      const double* bn = lds_bn + (size_t)(l + 1) * 4 * WM;
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * jt + gq + 4 * r;
+          const double sc = bn[j], sh = bn[WM + j], mu = bn[2 * WM + j], rs = bn[3 * WM + j];
+#pragma unroll
+          for (int st = 0; st < ST; ++st) {
+            const double v = acc[jt][st][r];
+            XH[4 * jt + r][st] = (v - mu) * rs;
+            H[4 * jt + r][st] = fmax(fma(v, sc, sh), 0.0);
+          }
+        }
+    }
+  }
+}
+
+// per-lane BatchNorm sums (feature 4 q + (lane>>4), this lane's samples) -> one record of the workgroup
+__device__ __forceinline__ void bww_emit_sums(double (&a1)[KQ], double (&a2)[KQ], double (*sm)[SREC], double* rec) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      a1[q] += __shfl_xor(a1[q], o, 64);
+      a2[q] += __shfl_xor(a2[q], o, 64);
+    }
+  if (s == 0) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      sm[wave][4 * q + gq] = a1[q];
+      sm[wave][WM + 4 * q + gq] = a2[q];
+    }
+  }
+  __syncthreads();
+  if (tid < SREC) {
+    double t = 0.0;
+    for (int w = 0; w < NW; ++w) t += sm[w][tid];
+    rec[tid] = t;
+  }
+}
+
+__device__ __forceinline__ void bww_stage(const BwdK& k, double* lds_bn, int* lds_plane) {
+  const int tid = threadIdx.x;
+  if (tid < NIS_MAX_DIM) lds_plane[tid] = k.c.in_plane[tid];
+  for (int idx = tid; idx < (k.c.L + 1) * 4 * WM; idx += TPB) lds_bn[idx] = k.bn[idx];
+}
+
+// ---------------------------------------------------------------------------------------------
+// head: recompute the cell, bijector adjoint -> dZ planes, d a_L = W_L^T dZ, dy_L, sums of BN_L, a_L planes
+template <int KIND, int KM>
+__global__ __launch_bounds__(TPB, 1) void k_bwd_head_w(BwdK k, BwdW w) {
+  extern __shared__ double mf_dyn[];                 // per wave: [NCB*out rows][16 samples] of exp(Z)
+  __shared__ double lds_bn[BNLDS];
+  __shared__ int lds_plane[NIS_MAX_DIM];
+  __shared__ double etab[64];
+  __shared__ double sm[NW][SREC];
+  const CellK& c = k.c;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
+  bww_stage(k, lds_bn, lds_plane);
+  nis_exp_init(etab);
+  __syncthreads();
+  const int L = c.L, K = c.K, out = c.out;
+  const long ld = k.ld, N = k.N;
+  double* ring = mf_dyn + (size_t)wave * NCB * out * 16;
+  const double* bnL = lds_bn + (size_t)L * 4 * WM;
+  double a1[KQ], a2[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) a1[q] = a2[q] = 0.0;
+  const long wstride = (long)gridDim.x * NW * 16 * ST;
+  for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
+    double H[KQ][ST], XH[KQ][ST];
+    {
+      nis_d4 acc[JT][ST];
+      bww_forward(c, k.x, ld, N, base, lds_plane, lds_bn, w.wm_all, L, H, XH, acc);
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * jt + gq + 4 * r;
+          const double sc = bnL[j], sh = bnL[WM + j], mu = bnL[2 * WM + j], rs = bnL[3 * WM + j];
+#pragma unroll
+          for (int st = 0; st < ST; ++st) {
+            const double v = acc[jt][st][r];
+            XH[4 * jt + r][st] = (v - mu) * rs;
+            H[4 * jt + r][st] = fmax(fma(v, sc, sh), 0.0);            // a_L
+          }
+        }
+    }
+#pragma unroll 1
+    for (int st = 0; st < ST; ++st) {
+      double Hs[KQ], XHs[KQ];
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        Hs[q] = H[q][0];
+        XHs[q] = XH[q][0];
+#pragma unroll
+        for (int u = 1; u < ST; ++u) {
+          Hs[q] = (st == u) ? H[q][u] : Hs[q];
+          XHs[q] = (st == u) ? XH[q][u] : XHs[q];
+        }
+      }
+      const long i = base + 16 * st + s;
+      const bool iv = i < N;
+      nis_d4 da[JT];
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt) da[jt] = nis_d4{0.0, 0.0, 0.0, 0.0};
+      double jfprod = 1.0;
+      const double gJ = iv ? k.g[(size_t)c.jplane * ld + i] : 0.0;
+      const double Jout = iv ? k.xo[(size_t)c.jplane * ld + i] : 1.0;
+#pragma unroll 1
+      for (int cb = 0; cb * NCB < c.T; ++cb) {
+        const int r0 = cb * NCB * out;
+        const int r1 = min(c.R, r0 + NCB * out);
+        for (int jt = r0 / 16; jt * 16 < r1; ++jt) {
+          nis_d4 z;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z[r] = w.bias_pad[16 * jt + gq + 4 * r];
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) z = mfma(w.wm_last[((size_t)jt * KQ + q) * 64 + lane], Hs[q], z);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + gq + 4 * r - r0;
+            if (j >= 0 && j < NCB * out && 16 * jt + gq + 4 * r < c.R) ring[j * 16 + s] = nis_exp(z[r], etab);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // (sample s, column slot gq) per lane.  Lanes without a column / sample run on dummy data with zero incoming
+        // gradients, so that the MFMAs below stay in wave-uniform control flow and receive dZ = 0 from them.
+        const int t = cb * NCB + gq;
+        const bool valid = t < c.T && iv;
+        const int tc = min(t, c.T - 1);
+        const size_t colp = (size_t)lds_plane[c.P + tc] * ld;
+        const int row0 = tc * out;
+        const double xraw = valid ? k.x[colp + i] : 0.5;
+        const double gy = valid ? k.g[colp + i] : 0.0;
+        const double gJv = valid ? gJ : 0.0;
+        const double* zr = ring + (size_t)gq * out * 16 + s;
+        const double* wrow = c.wlast + (size_t)row0 * WM + s;
+        double gx = 0.0, jf = 1.0;
+        if (KIND == NIS_PWQUAD) {
+          const bool clamped = xraw > 1.0 - 1e-6;
+          const double xb = clamped ? 1.0 - 1e-6 : xraw;
+          double V[KM + 1], W[KM];
+#pragma unroll
+          for (int q = 0; q < KM + 1; ++q) V[q] = (q <= K) ? (valid ? zr[q * 16] : 1.0) : 0.0;
+#pragma unroll
+          for (int q = 0; q < KM; ++q) W[q] = (q < K) ? (valid ? zr[(K + 1 + q) * 16] : 1.0) : 0.0;
+          double wn = 0.0;
+#pragma unroll
+          for (int q = 0; q < KM; ++q)
+            if (q < K) wn += W[q];
+          int b;
+          double left;
+          pwquad_bin<KM, false>(xb, K, W, wn, &b, &left);
+          const double iwn = 1.0 / wn;
+          double area = 0.0;
+#pragma unroll
+          for (int q = 0; q < KM; ++q)
+            if (q < K) {
+              W[q] = W[q] * iwn;
+              area += (V[q] + V[q + 1]) / 2 * W[q];
+            }
+          const double iarea = 1.0 / area;
+#pragma unroll
+          for (int q = 0; q < KM + 1; ++q)
+            if (q <= K) V[q] = V[q] * iarea;
+          double Wb = 1.0, Vb = 0.0, Vb1 = 0.0;
+#pragma unroll
+          for (int q = 0; q < KM; ++q)
+            if (q < K) {
+              const bool hit = q == b;
+              Wb = hit ? W[q] : Wb;
+              Vb = hit ? V[q] : Vb;
+              Vb1 = hit ? V[q + 1] : Vb1;
+            }
+          const double alpha = (xb - left) / Wb;
+          const double D = Vb1 - Vb;
+          jf = lerp_torch(Vb, Vb1, alpha);
+          const double gjf = gJv * Jout / jf;                  // J_out = J_in prod_t jf_t
+          const double galpha = gy * jf * Wb + gjf * D;
+          gx = clamped ? 0.0 : galpha / Wb;
+          const double gleft = -galpha / Wb;
+          double gv[KM + 1], gw[KM];
+#pragma unroll
+          for (int q = 0; q < KM + 1; ++q) gv[q] = 0.0;
+#pragma unroll
+          for (int q = 0; q < KM; ++q) {
+            gw[q] = 0.0;
+            if (q < K) {
+              const bool below = q < b, hit = q == b;
+              gw[q] += below ? gy * (V[q] + V[q + 1]) / 2 + gleft : 0.0;
+              gv[q] += below ? gy * W[q] / 2 : 0.0;
+              gv[q + 1] += below ? gy * W[q] / 2 : 0.0;
+              gw[q] += hit ? gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb : 0.0;
+              gv[q] += hit ? gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha) : 0.0;
+              gv[q + 1] += hit ? gy * alpha * alpha / 2 * Wb + gjf * alpha : 0.0;
+            }
+          }
+          double S = 0.0;
+#pragma unroll
+          for (int q = 0; q < KM + 1; ++q)
+            if (q <= K) S += gv[q] * V[q];
+          double Sw = 0.0;
+#pragma unroll
+          for (int q = 0; q < KM; ++q)
+            if (q < K) {
+              gw[q] -= S * (V[q] + V[q + 1]) / 2;
+              Sw += gw[q] * W[q];
+            }
+#pragma unroll
+          for (int q = 0; q < KM + 1; ++q)
+            if (q <= K) {                                    // wave-uniform
+              const double wl_ = (q >= 1) ? W[q >= 1 ? q - 1 : 0] : 0.0;
+              const double wr_ = (q < K && q < KM) ? W[q < KM ? q : 0] : 0.0;
+              double dz = gv[q] * V[q] - S * V[q] * (wl_ + wr_) / 2;
+              dz = valid ? dz : 0.0;
+              if (valid) k.dzp[(size_t)(row0 + q) * ld + i] = dz;
+#pragma unroll
+              for (int jt = 0; jt < JT; ++jt) da[jt] = mfma(wrow[(size_t)q * WM + 16 * jt], dz, da[jt]);
+            }
+#pragma unroll
+          for (int q = 0; q < KM; ++q)
+            if (q < K) {
+              double dz = W[q] * (gw[q] - Sw);
+              dz = valid ? dz : 0.0;
+              if (valid) k.dzp[(size_t)(row0 + K + 1 + q) * ld + i] = dz;
+#pragma unroll
+              for (int jt = 0; jt < JT; ++jt) da[jt] = mfma(wrow[(size_t)(K + 1 + q) * WM + 16 * jt], dz, da[jt]);
+            }
+        } else {
+          // PWLin: Q_q = K e_q / tot, y = Q_b alpha + sum_{q<b} e_q / tot, jf = Q_b  (two streamed passes over the ring)
+          const double ak = xraw * K;
+          const double bf = floor(ak);
+          const double alpha = (ak - bf) / K;
+          const int b = (int)bf;
+          double tot = 0.0, below = 0.0, eb = 0.0;
+          for (int q = 0; q < K; ++q) {
+            const double e = valid ? zr[q * 16] : 1.0;
+            const bool hit = q == b;
+            below = hit ? tot : below;
+            eb = hit ? e : eb;
+            tot += e;
+          }
+          const double Qb = eb / (tot / K);
+          const double Qs = below / tot;
+          jf = Qb;
+          const double gjf = gJv * Jout / jf;
+          const double gQb = gy * alpha + gjf, gQs = gy;
+          gx = gy * Qb;
+          for (int q = 0; q < K; ++q) {
+            const double e = valid ? zr[q * 16] : 1.0;
+            const double pq = e / tot;
+            double dz = gQb * ((q == b ? Qb : 0.0) - Qb * pq) + gQs * ((q < b ? pq : 0.0) - Qs * pq);
+            dz = valid ? dz : 0.0;
+            if (valid) k.dzp[(size_t)(row0 + q) * ld + i] = dz;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) da[jt] = mfma(wrow[(size_t)q * WM + 16 * jt], dz, da[jt]);
+          }
+        }
+        if (valid) {
+          k.g[colp + i] = gx;
+          jfprod *= jf;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      jfprod *= __shfl_xor(jfprod, 16, 64);
+      jfprod *= __shfl_xor(jfprod, 32, 64);
+      if (gq == 0 && iv) k.g[(size_t)c.jplane * ld + i] = gJ * jfprod;   // dL/dJ_in = dL/dJ_out prod_t dy_t/dx_t
+      // through ReLU to BN_L's output; sums of BN_L; a_L planes for dW_L
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        const int j = 4 * q + gq;
+        const double dy = Hs[q] > 0.0 ? da[q >> 2][q & 3] : 0.0;
+        if (iv) {
+          k.dyp[(size_t)j * ld + i] = dy;
+          k.alp[(size_t)j * ld + i] = Hs[q];
+        }
+        a1[q] += dy;
+        a2[q] = fma(dy, XHs[q], a2[q]);
+      }
+    }
+  }
+  bww_emit_sums(a1, a2, sm, k.part + (size_t)blockIdx.x * SREC);
+}
+
+// ---------------------------------------------------------------------------------------------
+// layer l (L..1): BN_l backward -> d h_l planes, a_{l-1} planes, dy_{l-1} = relu'(.) W_{l-1}^T d h_l, sums of BN_{l-1}
+__global__ __launch_bounds__(TPB, 1) void k_bwd_layer_w(BwdK k, BwdW w, int l) {
+  __shared__ double lds_bn[BNLDS];
+  __shared__ int lds_plane[NIS_MAX_DIM];
+  __shared__ double lds_m[SREC];
+  __shared__ double sm[NW][SREC];
+  const CellK& c = k.c;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
+  bww_stage(k, lds_bn, lds_plane);
+  const long ld = k.ld, N = k.N;
+  if (tid < SREC) lds_m[tid] = k.sums[tid] * (1.0 / (double)N);
+  __syncthreads();
+  const double* bnl = lds_bn + (size_t)l * 4 * WM;
+  const double* wt = c.wp + (size_t)(l - 1) * WM * WM + (size_t)gq * WM + s;       // W_{l-1}[4 ks + gq][16 qt + s]
+  const int nqt = l == 1 ? (c.P + 15) / 16 : JT;
+  double a1[KQ], a2[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) a1[q] = a2[q] = 0.0;
+  const long wstride = (long)gridDim.x * NW * 16 * ST;
+  for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
+    double H[KQ][ST], XH[KQ][ST], DH[KQ][ST];
+    {
+      nis_d4 acc[JT][ST];
+      bww_forward(c, k.x, ld, N, base, lds_plane, lds_bn, w.wm_all, l, H, XH, acc);
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * jt + gq + 4 * r, q = 4 * jt + r;
+          const double sc = bnl[j], mu = bnl[2 * WM + j], rs = bnl[3 * WM + j], m1 = lds_m[j], m2 = lds_m[WM + j];
+#pragma unroll
+          for (int st = 0; st < ST; ++st) {
+            const long i = base + 16 * st + s;
+            const bool iv = i < N;
+            const double xh = (acc[jt][st][r] - mu) * rs;
+            const double dy = iv ? k.dyp[(size_t)j * ld + i] : 0.0;
+            const double dh = iv ? sc * (dy - m1 - xh * m2) : 0.0;          // scale_l = gamma_l * rstd_l
+            DH[q][st] = dh;
+            if (iv) {
+              w.dhp[(size_t)j * ld + i] = dh;
+              k.alp[(size_t)j * ld + i] = H[q][st];
+            }
+          }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < JT; ++qt) {
+      nis_d4 dacc[ST];
+#pragma unroll
+      for (int st = 0; st < ST; ++st) dacc[st] = nis_d4{0.0, 0.0, 0.0, 0.0};
+      if (qt < nqt) {
+#pragma unroll
+        for (int ks = 0; ks < KQ; ++ks) {
+          const double a = wt[(size_t)(4 * ks) * WM + 16 * qt];
+#pragma unroll
+          for (int st = 0; st < ST; ++st) dacc[st] = mfma(a, DH[ks][st], dacc[st]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * qt + gq + 4 * r, q = 4 * qt + r;
+#pragma unroll
+        for (int st = 0; st < ST; ++st) {
+          const long i = base + 16 * st + s;
+          const double dy = (l == 1 || H[q][st] > 0.0) ? dacc[st][r] : 0.0;   // BN_0 has no ReLU behind it
+          if (i < N) k.dyp[(size_t)j * ld + i] = dy;
+          a1[q] += dy;
+          a2[q] = fma(dy, XH[q][st], a2[q]);
+        }
+      }
+    }
+  }
+  bww_emit_sums(a1, a2, sm, k.part + (size_t)blockIdx.x * SREC);
+}
+
+// BN_0 backward: gradient of the pass-through columns
+__global__ __launch_bounds__(TPB) void k_bwd_input_w(BwdK k) {
+  const CellK& c = k.c;
+  const double invN = 1.0 / (double)k.N;
+  const long stride = (long)gridDim.x * TPB;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < k.N; i += stride)
+    for (int p = 0; p < c.P; ++p) {
+      const size_t at = (size_t)c.in_plane[p] * k.ld + i;
+      const double xh = (k.x[at] - k.bn[2 * WM + p]) * k.bn[3 * WM + p];
+      const double dy = k.dyp[(size_t)p * k.ld + i];
+      k.g[at] += k.bn[p] * (dy - k.sums[p] * invN - xh * k.sums[WM + p] * invN);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[r][q] = sum_i A[r][i] B[q][i] (+ row sums of A) for RPW*16 rows per workgroup row group: the MFMA k index
+// runs over samples (lane l supplies sample 4 (l>>4) + m of a 16-sample tile in k-step m).
+__global__ __launch_bounds__(TPB) void k_bwd_xty_w(const double* __restrict__ Ap, int R, const double* __restrict__ Bp, long ld, long N,
+                                                   double* __restrict__ part) {
+  __shared__ double sm[GREC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
+  const int rb = blockIdx.y * RPW * 16;
+  nis_d4 acc[RPW][JT];
+  double rsum[RPW];
+#pragma unroll
+  for (int rt = 0; rt < RPW; ++rt) {
+    rsum[rt] = 0.0;
+#pragma unroll
+    for (int qt = 0; qt < JT; ++qt) acc[rt][qt] = nis_d4{0.0, 0.0, 0.0, 0.0};
+  }
+  const long ntiles = (N + 15) / 16;
+  for (long tile = (long)blockIdx.x * NW + wave; tile < ntiles; tile += (long)gridDim.x * NW) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const long ii = tile * 16 + 4 * gq + m;
+      const bool ok = ii < N;
+      double b[JT];
+#pragma unroll
+      for (int qt = 0; qt < JT; ++qt) b[qt] = ok ? Bp[(size_t)(16 * qt + s) * ld + ii] : 0.0;
+#pragma unroll
+      for (int rt = 0; rt < RPW; ++rt) {
+        const int row = rb + 16 * rt + s;
+        const double a = (ok && row < R) ? Ap[(size_t)row * ld + ii] : 0.0;
+        rsum[rt] += a;
+#pragma unroll
+        for (int qt = 0; qt < JT; ++qt) acc[rt][qt] = mfma(a, b[qt], acc[rt][qt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < RPW; ++rt) {
+    rsum[rt] += __shfl_xor(rsum[rt], 16, 64);
+    rsum[rt] += __shfl_xor(rsum[rt], 32, 64);
+  }
+  for (int wv = 0; wv < NW; ++wv) {                 // wave after wave: fixed summation order
+    if (wave == wv) {
+#pragma unroll
+      for (int rt = 0; rt < RPW; ++rt) {
+#pragma unroll
+        for (int qt = 0; qt < JT; ++qt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = (16 * rt + gq + 4 * r) * (WM + 1) + 16 * qt + s;
+            sm[e] = (wv == 0 ? 0.0 : sm[e]) + acc[rt][qt][r];
+          }
+        if (gq == 0) {
+          const int e = (16 * rt + s) * (WM + 1) + WM;
+          sm[e] = (wv == 0 ? 0.0 : sm[e]) + rsum[rt];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  double* rec = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GREC;
+  for (int e = tid; e < GREC; e += TPB) rec[e] = sm[e];
+}
+
+// records -> their sum (one thread per element, fixed order over the records)
+__global__ __launch_bounds__(TPB) void k_bwd_reduce_w(const double* __restrict__ part, int nparts, int nacc, double* __restrict__ out) {
+  const int e = blockIdx.x * TPB + threadIdx.x;
+  if (e >= nacc) return;
+  part += (size_t)blockIdx.y * nparts * nacc;
+  double t = 0.0;
+  for (int b = 0; b < nparts; ++b) t += part[(size_t)b * nacc + e];
+  out[(size_t)blockIdx.y * nacc + e] = t;
+}
+
+// Reduced records -> gradient blob in the reference's parameter order (include/nis_hip.h).
+//   sums : pass p (0 = head, L - l + 1 = layer kernel l) holds the sums of BN_{L-p}: [sum dy | sum dy xhat]
+//   glast: GEMM result of the last Linear (row groups of GREC); ghid + m*ngh*GREC: of hidden Linear m
+__global__ void k_bwd_scatter_w(CellK c, const double* __restrict__ sums, const double* __restrict__ glast,
+                                const double* __restrict__ ghid, int ngh, double* __restrict__ gparams) {
+  const int L = c.L, tid = threadIdx.x, nth = blockDim.x;
+  size_t off = 0;
+  for (int l = 0; l <= L; ++l) {
+    const int F = cellk_feat(c, l);
+    const int O = l < L ? c.width[l] : c.R;
+    const double* sl = sums + (size_t)(L - l) * SREC;
+    for (int j = tid; j < F; j += nth) {
+      gparams[off + j] = sl[WM + j];
+      gparams[off + F + j] = sl[j];
+    }
+    off += 2 * (size_t)F;
+    const double* src = l < L ? ghid + (size_t)l * ngh * GREC : glast;
+    for (int e = tid; e < O * F; e += nth) {
+      const int r = e / F, q = e % F;
+      gparams[off + e] = src[(size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + q];
+    }
+    off += (size_t)O * F;
+  }
+  for (int r = tid; r < c.R; r += nth) gparams[off + r] = glast[(size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + WM];
+}
+
+// ---------------------------------------------------------------------------------------------
+int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
+size_t ring_bytes(int out) { return (size_t)NW * NCB * out * 16 * sizeof(double); }
+int groups_of(int rows) { return (rows + RPW * 16 - 1) / (RPW * 16); }
+
+struct Plan {
+  int nb;            // workgroups of the head / layer launches
+  int ngl, ngh;      // row groups of the last-layer / hidden GEMMs
+  int nxl, nxh;      // sample chunks (workgroups in x) of those GEMMs
+  size_t part;       // doubles of the shared record area
+};
+
+Plan plan_for(int R, long N) {
+  Plan p;
+  const int cus = device_cus();
+  const long per_wg = (long)NW * 16 * ST;
+  p.nb = (int)std::max<long>(1, std::min<long>((N + per_wg - 1) / per_wg, (long)cus * 2));
+  p.ngl = groups_of(R);
+  p.ngh = groups_of(WM);
+  const long tiles_wg = ((N + 15) / 16 + NW - 1) / NW;
+  p.nxl = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 4 / p.ngl)));
+  p.nxh = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 2 / p.ngh)));
+  p.part = std::max<size_t>((size_t)p.nb * SREC, std::max((size_t)p.ngl * p.nxl, (size_t)p.ngh * p.nxh) * GREC);
+  return p;
+}
+}  // namespace
+
+template <>
+bool bwd_wide_supported<NIS_WM>(const nis_cell_desc& cd) {
+  const int out = cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.K;
+  if (cd.kind == NIS_PWQUAD && cd.K > BKMAX) return false;
+  const size_t fixed = (size_t)(BNLDS + NW * SREC + 64) * sizeof(double) + NIS_MAX_DIM * sizeof(int) + 1024;   // static LDS of the head
+  return ring_bytes(out) + fixed <= 160 * 1024;
+}
+
+template <>
+size_t bwd_wide_workspace_doubles<NIS_WM>(const nis_cell_desc& cd, int64_t N) {
+  const int T = cd.d - cd.P;
+  const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.K);
+  const Plan p = plan_for(R, (long)N);
+  return (size_t)(3 * WM + R) * N + p.part + (size_t)(cd.n_hidden + 2) * SREC + (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC;
+}
+
+template <>
+int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, double* gparams, hipStream_t s) {
+  const long N = k.N;
+  const int L = c.L;
+  const Plan p = plan_for(c.R, N);
+  BwdW w;
+  w.wm_all = mw.wm_all;
+  w.wm_last = mw.wm_last;
+  w.bias_pad = mw.bias_pad;
+  k.dyp = ws;
+  k.alp = ws + (size_t)WM * N;
+  w.dhp = ws + (size_t)2 * WM * N;
+  k.dzp = ws + (size_t)3 * WM * N;
+  double* part = k.dzp + (size_t)c.R * N;
+  double* sums = part + p.part;
+  double* glast = sums + (size_t)(L + 2) * SREC;
+  double* ghid = glast + (size_t)p.ngl * GREC;
+  k.part = part;
+  const size_t ring = ring_bytes(c.out);
+  const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : 16;
+  if (c.kind == NIS_PWLIN)
+    hipLaunchKernelGGL((k_bwd_head_w<NIS_PWLIN, 4>), dim3(p.nb), dim3(TPB), ring, s, k, w);
+  else if (km == 4)
+    hipLaunchKernelGGL((k_bwd_head_w<NIS_PWQUAD, 4>), dim3(p.nb), dim3(TPB), ring, s, k, w);
+  else if (km == 8)
+    hipLaunchKernelGGL((k_bwd_head_w<NIS_PWQUAD, 8>), dim3(p.nb), dim3(TPB), ring, s, k, w);
+  else
+    hipLaunchKernelGGL((k_bwd_head_w<NIS_PWQUAD, 16>), dim3(p.nb), dim3(TPB), ring, s, k, w);
+  hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + TPB - 1) / TPB, 1), dim3(TPB), 0, s, (const double*)part, p.nb, SREC, sums);
+  // dW_L = dZ a_L^T, db_L = row sums of dZ
+  hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.ngl), dim3(TPB), 0, s, (const double*)k.dzp, c.R, (const double*)k.alp, k.ld, N, part);
+  hipLaunchKernelGGL(k_bwd_reduce_w, dim3((GREC + TPB - 1) / TPB, p.ngl), dim3(TPB), 0, s, (const double*)part, p.nxl, GREC, glast);
+  for (int l = L; l >= 1; --l) {
+    const int pass = L - l + 1;
+    k.sums = sums + (size_t)(pass - 1) * SREC;
+    hipLaunchKernelGGL(k_bwd_layer_w, dim3(p.nb), dim3(TPB), 0, s, k, w, l);
+    hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + TPB - 1) / TPB, 1), dim3(TPB), 0, s, (const double*)part, p.nb, SREC,
+                       sums + (size_t)pass * SREC);
+    // dW_{l-1} = d h_l a_{l-1}^T
+    hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxh, p.ngh), dim3(TPB), 0, s, (const double*)w.dhp, c.width[l - 1], (const double*)k.alp, k.ld,
+                       N, part);
+    hipLaunchKernelGGL(k_bwd_reduce_w, dim3((GREC + TPB - 1) / TPB, p.ngh), dim3(TPB), 0, s, (const double*)part, p.nxh, GREC,
+                       ghid + (size_t)(l - 1) * p.ngh * GREC);
+  }
+  k.sums = sums + (size_t)L * SREC;
+  {
+    const int gi = (int)std::max<long>(1, std::min<long>((N + TPB - 1) / TPB, (long)device_cus() * 8));
+    hipLaunchKernelGGL(k_bwd_input_w, dim3(gi), dim3(TPB), 0, s, k);
+  }
+  hipLaunchKernelGGL(k_bwd_scatter_w, dim3(1), dim3(TPB), 0, s, c, (const double*)sums, (const double*)glast, (const double*)ghid, p.ngh,
+                     gparams);
+  return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
+}

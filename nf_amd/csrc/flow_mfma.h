@@ -217,6 +217,14 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
       mf_hidden<WM>(c, wm_all, lds_coef, c.L, H, acc);
       mf_bn_relu<WM>(lds_coef + (size_t)c.L * 2 * WM, acc, H);
     }
+    if (c.out_off != 0) {                              // history mode: the next plane set gets the pass-through block too
+      for (int p = gq; p < c.P; p += 4)
+#pragma unroll
+        for (int st = 0; st < ST; ++st) {
+          const long i = base + 16 * st + s;
+          if (i < N) planes[(size_t)lds_plane[p] * ld + c.out_off + i] = planes[(size_t)lds_plane[p] * ld + i];
+        }
+    }
     // ---- last layer + bijector, one tile of 16 samples and NCB columns at a time
 #pragma unroll 1
     for (int st = 0; st < ST; ++st) {
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
             y = qn * alpha + below / tot;
             jf = qn;
           }
-          col[i] = y;
+          col[c.out_off + i] = y;
           jprod *= jf;
           if (bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
         }
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
       const long i = base + 16 * st + s;
       if (gq == 0 && i < N) {
         double* jp = planes + (size_t)c.jplane * ld;
-        jp[i] = (c.first ? 1.0 : jp[i]) * jprod;
+        jp[c.out_off + i] = (c.first ? 1.0 : jp[i]) * jprod;
       }
     }
   }

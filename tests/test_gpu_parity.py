@@ -169,6 +169,57 @@ def test_hip_backward_general_narrow_models(monkeypatch):
                                        err_msg=f"{c} {name}")
 
 
+WIDE_BWD_CASES = [("pwquad", dict(d=16, n_cells=8, K=16, NN=[32, 32, 32])),          # C5 topology (matrix-core adjoint)
+                  ("pwquad", dict(d=10, n_cells=5, K=16, NN=[32, 32, 32])),          # C4 topology: P in {8,2,6,4,6,4,5,5}
+                  ("pwlin", dict(d=8, P=4, n_cells=4, K=64, NN=[32, 32, 32], roll=4)),  # C3 topology
+                  ("pwquad", dict(d=6, n_cells=3, K=7, NN=[16, 12])),
+                  ("pwquad", dict(d=5, n_cells=2, K=3, NN=[20])),
+                  ("pwlin", dict(d=7, P=3, n_cells=3, K=21, NN=[64, 48], roll=2)),
+                  ("pwquad", dict(d=4, n_cells=2, K=9, NN=[40, 64, 33]))]
+
+
+@pytest.mark.parametrize("kind,c", WIDE_BWD_CASES, ids=[f"{k}-d{c['d']}-K{c['K']}-NN{'x'.join(map(str, c['NN']))}" for k, c in WIDE_BWD_CASES])
+def test_hip_backward_wide_models(kind, c, monkeypatch):
+    """Matrix-core adjoint (flow_bwd_wm.hip: conditioner widths 9..64) against autograd through the stock-PyTorch
+    re-evaluation of the same cells; N is not a multiple of the 16-sample tile."""
+    from nf_amd.normalizing_flows.manager import PWLinManager, PWQuadManager
+    torch.manual_seed(c["d"] * 7 + c["K"])
+    if kind == "pwquad":
+        NF = PWQuadManager(n_flow=c["d"])
+        NF.create_model(c["n_cells"], c["K"], list(c["NN"]))
+    else:
+        NF = PWLinManager(n_flow=c["d"])
+        NF.create_model(c["P"], c["n_cells"], c["K"], list(c["NN"]), c["roll"])
+    model = NF._model.train()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    assert model.engine().backward_supported(), c
+    N, d = 1931, c["d"]
+    x0 = torch.rand(N, d + 1, dtype=torch.double, device=dev()) * (1 - 1e-9)
+    x0[:, d] += 0.5
+    R = torch.randn(N, d + 1, dtype=torch.double, device=dev())
+
+    def grads(force_torch):
+        if force_torch:
+            monkeypatch.setenv("NF_AMD_TORCH_ADJOINT", "1")
+        else:
+            monkeypatch.delenv("NF_AMD_TORCH_ADJOINT", raising=False)
+        for p in model.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        out = model(x)
+        (out * R).sum().backward()
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in model.parameters()]
+
+    o_h, gx_h, gp_h = grads(False)
+    o_t, gx_t, gp_t = grads(True)
+    np.testing.assert_allclose(t2n(o_h), t2n(o_t), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(t2n(gx_h), t2n(gx_t), rtol=1e-6, atol=1e-8 * float(gx_t.abs().max()), err_msg=str(c))
+    for (name, _), a, b in zip(model.named_parameters(), gp_h, gp_t):
+        np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-6, atol=1e-8 * max(1.0, float(b.abs().max())), err_msg=f"{c} {name}")
+
+
 @pytest.mark.parametrize("kind,K,NN,n_cells", [("pwquad", 4, [3, 3, 3], 2), ("pwquad", 3, [4], 3), ("pwquad", 2, [2, 3], 2),
                                                ("pwlin", 7, [3, 3], 3), ("pwlin", 12, [4, 4, 4], 2)])
 def test_hip_backward_matches_torch_adjoint(kind, K, NN, n_cells, monkeypatch):
