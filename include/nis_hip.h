@@ -130,13 +130,15 @@ int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_b
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Training forward + hand-written adjoint (replaces loss.backward() through the flow, manager.py:275-278, for the
- * cell class the adjoint kernels cover: conditioner widths and pass-through size <= 8, PWQuad n_bins <= 16, PWLin
- * any n_bins, any number of transformed columns; nis_flow_backward_supported tells).
+ * cell class the adjoint kernels cover: conditioner widths and pass-through size <= 64 (<= 8: fp64 VALU kernels,
+ * wider: v_mfma_f64_16x16x4_f64 kernels), PWQuad n_bins <= 16, PWLin any n_bins whose LDS image fits, any number of
+ * transformed columns; nis_flow_backward_supported tells).
  *   nis_flow_forward_train: train-mode forward that keeps every cell's input: planes_hist holds n_cells+1 plane
  *     sets of (d+1, ld) doubles (set c = input of cell c, last set = model output); bnsave
  *     (nis_flow_bnsave_count doubles) receives scale | shift | batch mean | rstd of every BN layer.
  *   nis_flow_backward: gxj = dL/dXJ (N, d+1) row-major in output column order -> gparams[c] = dL/d(parameter
- *     blob of cell c) (same layout as params[c], overwritten) and optionally gx_out = dL/d(input) (N, d+1). */
+ *     blob of cell c) (same layout as params[c], overwritten) and optionally gx_out = dL/d(input) (N, d+1);
+ *     ld must equal N here (the gradient planes in the workspace share the leading dimension). */
 int nis_flow_backward_supported(const nis_flow* f);
 size_t nis_flow_bnsave_count(const nis_flow* f);
 int nis_flow_forward_train(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N,

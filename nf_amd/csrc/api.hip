@@ -994,14 +994,14 @@ extern "C" size_t nis_flow_backward_workspace_bytes(const nis_flow* f, int64_t N
 extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
                                  const double* const* params, const double* bnsave, const double* gxj, double* const* gparams,
                                  double* gx_out, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!f || !planes_hist || !params || !bnsave || !gxj || !gparams || N < 1 || ld < N) return NIS_E_ARG;
+  if (!f || !planes_hist || !params || !bnsave || !gxj || !gparams || N < 1 || ld != N) return NIS_E_ARG;   // gradient planes share ld
   if (!nis_flow_backward_supported(f)) return NIS_E_UNSUPPORTED;
   if (!workspace || workspace_bytes < nis_flow_backward_workspace_bytes(f, N)) return NIS_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int d = f->d;
   const long set = (long)(d + 1) * ld;
   double* g = (double*)workspace;                       // gradient planes (d+1, ld)
-  double* cellws = g + (size_t)(d + 1) * N;
+  double* cellws = g + ((size_t)(d + 1) * N + 15) / 16 * 16;      // 128-byte aligned: the wide adjoint uses vector loads
   size_t cw = 0;
   std::vector<CellLayout> lay;
   flow_layout(f, 1, &lay, nullptr);

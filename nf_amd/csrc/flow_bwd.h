@@ -20,6 +20,7 @@ struct BwdK {
   double* part;               // records of this launch
   const double* sums;         // reduced record of the previous launch (BNACC)
   long ld, N;
+  long ldw;                   // leading dimension of the workspace planes dyp / alp / dzp (wide adjoint: multiple of 16)
 };
 
 // ---- wide conditioners (register width 16 / 32 / 64), one translation unit per width

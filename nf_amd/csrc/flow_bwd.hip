@@ -453,6 +453,7 @@ int nis_bwd_cell_run(const CellK& c, int wm, const double* x, const double* xo, 
   k.g = g;
   k.bn = bnsave;
   k.ld = ld;
+  k.ldw = ld;
   k.N = N;
   if (wm == 4) return bwd_run<4>(c, k, ws, gparams, s);
   if (wm == 8) return bwd_run<8>(c, k, ws, gparams, s);

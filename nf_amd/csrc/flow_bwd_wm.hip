@@ -27,7 +27,8 @@
 
 namespace {
 constexpr int WM = NIS_WM, JT = WM / 16, KQ = WM / 4, NW = 4, TPB = 256, NCB = NIS_MF_NCB;
-constexpr int ST = WM >= 64 ? 1 : 2;            // sample tiles (of 16) per wave pass
+constexpr int ST = 1;                           // sample tiles (of 16) per wave pass: keeps the chain kernels at <= 256 registers
+constexpr int WPS = WM >= 64 ? 1 : 2;           // waves per SIMD the chain kernels are compiled for
 constexpr int RPW = WM >= 64 ? 2 : 4;           // row tiles (of 16) per workgroup of the weight-gradient GEMM
 constexpr int GREC = RPW * 16 * (WM + 1);       // its record: RPW*16 rows x (WM products | row sum)
 constexpr int SREC = 2 * WM;                    // BatchNorm record: sum dy | sum dy*xhat
@@ -39,6 +40,10 @@ struct BwdW {
   const double* bias_pad;
   double* dhp;                                  // WM planes: dL/d(pre-BN_l activations), A operand of the dW GEMM
 };
+
+// Workspace buffers (dZ, dy, d h, a) are tile-major: [16-sample tile][feature][16 samples], so one wave's tile is a
+// contiguous block (feature stride 128 B: immediate offsets) and the GEMM reads whole 2 KB runs of 16 rows.
+__device__ __forceinline__ size_t tmx(int F, int j, long i) { return ((size_t)(i >> 4) * F + j) * 16 + (i & 15); }
 
 __device__ __forceinline__ nis_d4 mfma(double a, double b, nis_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
@@ -124,6 +129,39 @@ __device__ __forceinline__ void bww_emit_sums(double (&a1)[KQ], double (&a2)[KQ]
   }
 }
 
+// d a += W_rows^T dz for NQ consecutive rows of the row-major last-layer image (wr points at row 0, column lane&15):
+// row q of the 4 column slots is one MFMA k-step.  The A operands are fetched one chunk of CH rows ahead of their
+// use; the compiler barriers keep the scheduler from hoisting ALL loads (which costs > 100 registers).
+template <int NQ, bool EXACT>
+__device__ __forceinline__ void bww_da(const double* __restrict__ wr, const double (&dz)[NQ], int nq, nis_d4 (&da)[JT]) {
+  constexpr int CH = 4, NC = (NQ + CH - 1) / CH;
+  double a[2][CH][JT];
+#pragma unroll
+  for (int u = 0; u < CH; ++u)
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) a[0][u][jt] = (u < NQ && (EXACT || u < nq)) ? wr[(size_t)u * WM + 16 * jt] : 0.0;
+#pragma unroll
+  for (int ch = 0; ch < NC; ++ch) {
+    asm volatile("" ::: "memory");
+    if (ch + 1 < NC) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int q = (ch + 1) * CH + u;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) a[(ch + 1) & 1][u][jt] = (q < NQ && (EXACT || q < nq)) ? wr[(size_t)q * WM + 16 * jt] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int q = ch * CH + u;
+      if (q < NQ && (EXACT || q < nq)) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) da[jt] = mfma(a[ch & 1][u][jt], dz[q], da[jt]);
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void bww_stage(const BwdK& k, double* lds_bn, int* lds_plane) {
   const int tid = threadIdx.x;
   if (tid < NIS_MAX_DIM) lds_plane[tid] = k.c.in_plane[tid];
@@ -132,8 +170,8 @@ __device__ __forceinline__ void bww_stage(const BwdK& k, double* lds_bn, int* ld
 
 // ---------------------------------------------------------------------------------------------
 // head: recompute the cell, bijector adjoint -> dZ planes, d a_L = W_L^T dZ, dy_L, sums of BN_L, a_L planes
-template <int KIND, int KM>
-__global__ __launch_bounds__(TPB, 1) void k_bwd_head_w(BwdK k, BwdW w) {
+template <int KIND, int KM, bool KEXACT>
+__global__ __launch_bounds__(TPB, WPS) void k_bwd_head_w(BwdK k, BwdW w) {
   extern __shared__ double mf_dyn[];                 // per wave: [NCB*out rows][16 samples] of exp(Z)
   __shared__ double lds_bn[BNLDS];
   __shared__ int lds_plane[NIS_MAX_DIM];
@@ -144,13 +182,12 @@ __global__ __launch_bounds__(TPB, 1) void k_bwd_head_w(BwdK k, BwdW w) {
   bww_stage(k, lds_bn, lds_plane);
   nis_exp_init(etab);
   __syncthreads();
-  const int L = c.L, K = c.K, out = c.out;
+  const int L = c.L, K = KEXACT ? KM : c.K, out = c.out;
   const long ld = k.ld, N = k.N;
   double* ring = mf_dyn + (size_t)wave * NCB * out * 16;
   const double* bnL = lds_bn + (size_t)L * 4 * WM;
-  double a1[KQ], a2[KQ];
-#pragma unroll
-  for (int q = 0; q < KQ; ++q) a1[q] = a2[q] = 0.0;
+  // BN_L sums live in LDS (sm[wave]: sum dy | sum dy*xhat), updated once per tile: 32 registers less in the bijector phase
+  if (lane < SREC / 2) sm[wave][lane] = 0.0, sm[wave][SREC / 2 + lane] = 0.0;
   const long wstride = (long)gridDim.x * NW * 16 * ST;
   for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
     double H[KQ][ST], XH[KQ][ST];
@@ -196,17 +233,26 @@ __global__ __launch_bounds__(TPB, 1) void k_bwd_head_w(BwdK k, BwdW w) {
       for (int cb = 0; cb * NCB < c.T; ++cb) {
         const int r0 = cb * NCB * out;
         const int r1 = min(c.R, r0 + NCB * out);
+        double fa[KQ];                                  // fragments of the row tile being multiplied (prefetched one tile ahead)
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) fa[q] = w.wm_last[((size_t)(r0 / 16) * KQ + q) * 64 + lane];
         for (int jt = r0 / 16; jt * 16 < r1; ++jt) {
+          double fb[KQ];
+          const int jn = (jt + 1) * 16 < r1 ? jt + 1 : jt;
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) fb[q] = w.wm_last[((size_t)jn * KQ + q) * 64 + lane];
           nis_d4 z;
 #pragma unroll
           for (int r = 0; r < 4; ++r) z[r] = w.bias_pad[16 * jt + gq + 4 * r];
 #pragma unroll
-          for (int q = 0; q < KQ; ++q) z = mfma(w.wm_last[((size_t)jt * KQ + q) * 64 + lane], Hs[q], z);
+          for (int q = 0; q < KQ; ++q) z = mfma(fa[q], Hs[q], z);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int j = 16 * jt + gq + 4 * r - r0;
             if (j >= 0 && j < NCB * out && 16 * jt + gq + 4 * r < c.R) ring[j * 16 + s] = nis_exp(z[r], etab);
           }
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) fa[q] = fb[q];
         }
         __builtin_amdgcn_wave_barrier();
         // (sample s, column slot gq) per lane.  Lanes without a column / sample run on dummy data with zero incoming
@@ -227,9 +273,9 @@ __global__ __launch_bounds__(TPB, 1) void k_bwd_head_w(BwdK k, BwdW w) {
           const double xb = clamped ? 1.0 - 1e-6 : xraw;
           double V[KM + 1], W[KM];
 #pragma unroll
-          for (int q = 0; q < KM + 1; ++q) V[q] = (q <= K) ? (valid ? zr[q * 16] : 1.0) : 0.0;
+          for (int q = 0; q < KM + 1; ++q) V[q] = (KEXACT || q <= K) ? (valid ? zr[q * 16] : 1.0) : 0.0;
 #pragma unroll
-          for (int q = 0; q < KM; ++q) W[q] = (q < K) ? (valid ? zr[(K + 1 + q) * 16] : 1.0) : 0.0;
+          for (int q = 0; q < KM; ++q) W[q] = (KEXACT || q < K) ? (valid ? zr[(K + 1 + q) * 16] : 1.0) : 0.0;
           double wn = 0.0;
 #pragma unroll
           for (int q = 0; q < KM; ++q)
@@ -265,53 +311,56 @@ __global__ __launch_bounds__(TPB, 1) void k_bwd_head_w(BwdK k, BwdW w) {
           const double galpha = gy * jf * Wb + gjf * D;
           gx = clamped ? 0.0 : galpha / Wb;
           const double gleft = -galpha / Wb;
-          double gv[KM + 1], gw[KM];
+          // Gradients w.r.t. the normalised heights v_q and widths w_q are sparse in q (bins below the hit, the hit, its
+          // right edge), so they are re-formed on the fly in each of the three passes instead of being kept in arrays:
+          //   gv(q) = [q-1 < b] gy w_{q-1}/2 + [q < b] gy w_q/2 + [q == b] A0 + [q == b+1] A1
+          //   gw0(q) = [q < b] (gy (v_q + v_{q+1})/2 + gleft) + [q == b] B0
+          const double hgy = gy / 2;
+          const double A0 = gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha);
+          const double A1 = gy * alpha * alpha / 2 * Wb + gjf * alpha;
+          const double B0 = gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb;
+#define NIS_GV(q, wm1, wq) (((q) >= 1 && (q) - 1 < b ? hgy * (wm1) : 0.0) + ((q) < b ? hgy * (wq) : 0.0) + ((q) == b ? A0 : 0.0) + ((q) == b + 1 ? A1 : 0.0))
+#define NIS_GW0(q) (((q) < b ? hgy * (V[q] + V[(q) + 1]) + gleft : 0.0) + ((q) == b ? B0 : 0.0))
+          double S = 0.0;                                    // through v = eV / area: S = sum_q gv(q) v_q
 #pragma unroll
-          for (int q = 0; q < KM + 1; ++q) gv[q] = 0.0;
-#pragma unroll
-          for (int q = 0; q < KM; ++q) {
-            gw[q] = 0.0;
-            if (q < K) {
-              const bool below = q < b, hit = q == b;
-              gw[q] += below ? gy * (V[q] + V[q + 1]) / 2 + gleft : 0.0;
-              gv[q] += below ? gy * W[q] / 2 : 0.0;
-              gv[q + 1] += below ? gy * W[q] / 2 : 0.0;
-              gw[q] += hit ? gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb : 0.0;
-              gv[q] += hit ? gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha) : 0.0;
-              gv[q + 1] += hit ? gy * alpha * alpha / 2 * Wb + gjf * alpha : 0.0;
+          for (int q = 0; q < KM + 1; ++q)
+            if (KEXACT || q <= K) {
+              const double wm1 = q >= 1 ? W[q >= 1 ? q - 1 : 0] : 0.0;
+              const double wq = (q < KM && (KEXACT || q < K)) ? W[q < KM ? q : 0] : 0.0;
+              S += NIS_GV(q, wm1, wq) * V[q];
             }
+          double Sw = 0.0;                                   // through w = softmax: Sw = sum_q gw(q) w_q
+#pragma unroll
+          for (int q = 0; q < KM; ++q)
+            if (KEXACT || q < K) Sw += (NIS_GW0(q) - S * (V[q] + V[q + 1]) / 2) * W[q];
+          // dZ in place: height rows into V, width rows into W (zero for lanes without a column / sample)
+          double wprev = 0.0;
+#pragma unroll
+          for (int q = 0; q < KM + 1; ++q)
+            if (KEXACT || q <= K) {                          // wave-uniform
+              const bool hasw = q < KM && (KEXACT || q < K);
+              const double wq = hasw ? W[q < KM ? q : 0] : 0.0;
+              const double vq = V[q];
+              const double dzv = NIS_GV(q, wprev, wq) * vq - S * vq * (wprev + wq) / 2;
+              if (hasw) {
+                const double dzw = wq * (NIS_GW0(q) - S * (vq + V[q + 1]) / 2 - Sw);
+                W[q < KM ? q : 0] = valid ? dzw : 0.0;
+              }
+              V[q] = valid ? dzv : 0.0;
+              wprev = wq;
+            }
+#undef NIS_GV
+#undef NIS_GW0
+          if (valid) {
+#pragma unroll
+            for (int q = 0; q < KM + 1; ++q)
+              if (KEXACT || q <= K) k.dzp[tmx(c.R, row0 + q, i)] = V[q];
+#pragma unroll
+            for (int q = 0; q < KM; ++q)
+              if (KEXACT || q < K) k.dzp[tmx(c.R, row0 + K + 1 + q, i)] = W[q];
           }
-          double S = 0.0;
-#pragma unroll
-          for (int q = 0; q < KM + 1; ++q)
-            if (q <= K) S += gv[q] * V[q];
-          double Sw = 0.0;
-#pragma unroll
-          for (int q = 0; q < KM; ++q)
-            if (q < K) {
-              gw[q] -= S * (V[q] + V[q + 1]) / 2;
-              Sw += gw[q] * W[q];
-            }
-#pragma unroll
-          for (int q = 0; q < KM + 1; ++q)
-            if (q <= K) {                                    // wave-uniform
-              const double wl_ = (q >= 1) ? W[q >= 1 ? q - 1 : 0] : 0.0;
-              const double wr_ = (q < K && q < KM) ? W[q < KM ? q : 0] : 0.0;
-              double dz = gv[q] * V[q] - S * V[q] * (wl_ + wr_) / 2;
-              dz = valid ? dz : 0.0;
-              if (valid) k.dzp[(size_t)(row0 + q) * ld + i] = dz;
-#pragma unroll
-              for (int jt = 0; jt < JT; ++jt) da[jt] = mfma(wrow[(size_t)q * WM + 16 * jt], dz, da[jt]);
-            }
-#pragma unroll
-          for (int q = 0; q < KM; ++q)
-            if (q < K) {
-              double dz = W[q] * (gw[q] - Sw);
-              dz = valid ? dz : 0.0;
-              if (valid) k.dzp[(size_t)(row0 + K + 1 + q) * ld + i] = dz;
-#pragma unroll
-              for (int jt = 0; jt < JT; ++jt) da[jt] = mfma(wrow[(size_t)(K + 1 + q) * WM + 16 * jt], dz, da[jt]);
-            }
+          bww_da<KM + 1, KEXACT>(wrow, V, K + 1, da);
+          bww_da<KM, KEXACT>(wrow + (size_t)(K + 1) * WM, W, K, da);
         } else {
           // PWLin: Q_q = K e_q / tot, y = Q_b alpha + sum_{q<b} e_q / tot, jf = Q_b  (two streamed passes over the ring)
           const double ak = xraw * K;
@@ -332,14 +381,27 @@ __global__ __launch_bounds__(TPB, 1) void k_bwd_head_w(BwdK k, BwdW w) {
           const double gjf = gJv * Jout / jf;
           const double gQb = gy * alpha + gjf, gQs = gy;
           gx = gy * Qb;
-          for (int q = 0; q < K; ++q) {
-            const double e = valid ? zr[q * 16] : 1.0;
-            const double pq = e / tot;
-            double dz = gQb * ((q == b ? Qb : 0.0) - Qb * pq) + gQs * ((q < b ? pq : 0.0) - Qs * pq);
-            dz = valid ? dz : 0.0;
-            if (valid) k.dzp[(size_t)(row0 + q) * ld + i] = dz;
+          for (int q0 = 0; q0 < K; q0 += 8) {                 // 8 rows per step: their A operands are in flight while dz is formed
+            double a[8][JT], dzv[8];
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) da[jt] = mfma(wrow[(size_t)q * WM + 16 * jt], dz, da[jt]);
+            for (int u = 0; u < 8; ++u) {
+              const int q = min(q0 + u, K - 1);
+#pragma unroll
+              for (int jt = 0; jt < JT; ++jt) a[u][jt] = wrow[(size_t)q * WM + 16 * jt];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int q = q0 + u;
+              const double e = (valid && q < K) ? zr[min(q, K - 1) * 16] : 1.0;
+              const double pq = e / tot;
+              const double dz = gQb * ((q == b ? Qb : 0.0) - Qb * pq) + gQs * ((q < b ? pq : 0.0) - Qs * pq);
+              dzv[u] = (valid && q < K) ? dz : 0.0;
+              if (valid && q < K) k.dzp[tmx(c.R, row0 + q, i)] = dzv[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+              for (int jt = 0; jt < JT; ++jt) da[jt] = mfma(a[u][jt], dzv[u], da[jt]);
           }
         }
         if (valid) {
@@ -357,20 +419,33 @@ __global__ __launch_bounds__(TPB, 1) void k_bwd_head_w(BwdK k, BwdW w) {
         const int j = 4 * q + gq;
         const double dy = Hs[q] > 0.0 ? da[q >> 2][q & 3] : 0.0;
         if (iv) {
-          k.dyp[(size_t)j * ld + i] = dy;
-          k.alp[(size_t)j * ld + i] = Hs[q];
+          k.dyp[tmx(WM, j, i)] = dy;
+          k.alp[tmx(WM, j, i)] = Hs[q];
         }
-        a1[q] += dy;
-        a2[q] = fma(dy, XHs[q], a2[q]);
+        double t1 = dy, t2 = dy * XHs[q];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          t1 += __shfl_xor(t1, o, 64);
+          t2 += __shfl_xor(t2, o, 64);
+        }
+        if (s == 0) {
+          sm[wave][j] += t1;
+          sm[wave][WM + j] += t2;
+        }
       }
     }
   }
-  bww_emit_sums(a1, a2, sm, k.part + (size_t)blockIdx.x * SREC);
+  __syncthreads();
+  if (tid < SREC) {
+    double t = 0.0;
+    for (int wv = 0; wv < NW; ++wv) t += sm[wv][tid];
+    k.part[(size_t)blockIdx.x * SREC + tid] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // layer l (L..1): BN_l backward -> d h_l planes, a_{l-1} planes, dy_{l-1} = relu'(.) W_{l-1}^T d h_l, sums of BN_{l-1}
-__global__ __launch_bounds__(TPB, 1) void k_bwd_layer_w(BwdK k, BwdW w, int l) {
+__global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l) {
   __shared__ double lds_bn[BNLDS];
   __shared__ int lds_plane[NIS_MAX_DIM];
   __shared__ double lds_m[SREC];
@@ -404,12 +479,12 @@ __global__ __launch_bounds__(TPB, 1) void k_bwd_layer_w(BwdK k, BwdW w, int l) {
             const long i = base + 16 * st + s;
             const bool iv = i < N;
             const double xh = (acc[jt][st][r] - mu) * rs;
-            const double dy = iv ? k.dyp[(size_t)j * ld + i] : 0.0;
+            const double dy = iv ? k.dyp[tmx(WM, j, i)] : 0.0;
             const double dh = iv ? sc * (dy - m1 - xh * m2) : 0.0;          // scale_l = gamma_l * rstd_l
             DH[q][st] = dh;
             if (iv) {
-              w.dhp[(size_t)j * ld + i] = dh;
-              k.alp[(size_t)j * ld + i] = H[q][st];
+              w.dhp[tmx(WM, j, i)] = dh;
+              k.alp[tmx(WM, j, i)] = H[q][st];
             }
           }
         }
@@ -434,7 +509,7 @@ __global__ __launch_bounds__(TPB, 1) void k_bwd_layer_w(BwdK k, BwdW w, int l) {
         for (int st = 0; st < ST; ++st) {
           const long i = base + 16 * st + s;
           const double dy = (l == 1 || H[q][st] > 0.0) ? dacc[st][r] : 0.0;   // BN_0 has no ReLU behind it
-          if (i < N) k.dyp[(size_t)j * ld + i] = dy;
+          if (i < N) k.dyp[tmx(WM, j, i)] = dy;
           a1[q] += dy;
           a2[q] = fma(dy, XH[q][st], a2[q]);
         }
@@ -453,16 +528,46 @@ __global__ __launch_bounds__(TPB) void k_bwd_input_w(BwdK k) {
     for (int p = 0; p < c.P; ++p) {
       const size_t at = (size_t)c.in_plane[p] * k.ld + i;
       const double xh = (k.x[at] - k.bn[2 * WM + p]) * k.bn[3 * WM + p];
-      const double dy = k.dyp[(size_t)p * k.ld + i];
+      const double dy = k.dyp[tmx(WM, p, i)];
       k.g[at] += k.bn[p] * (dy - k.sums[p] * invN - xh * k.sums[WM + p] * invN);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // out[r][q] = sum_i A[r][i] B[q][i] (+ row sums of A) for RPW*16 rows per workgroup row group: the MFMA k index
-// runs over samples (lane l supplies sample 4 (l>>4) + m of a 16-sample tile in k-step m).
-__global__ __launch_bounds__(TPB) void k_bwd_xty_w(const double* __restrict__ Ap, int R, const double* __restrict__ Bp, long ld, long N,
-                                                   double* __restrict__ part) {
+// runs over samples.  Lane l owns samples 4 (l>>4) .. 4 (l>>4) + 3 of a 16-sample tile (one 32-byte load per row of the
+// tile-major buffers) and feeds sample 4 (l>>4) + m to k-step m.
+// The operands of the next tile are in flight while the current one is multiplied.
+struct XtyOps {
+  nis_d4 a[RPW], b[JT];
+};
+__device__ __forceinline__ void xty_load(const double* __restrict__ Ap, int FA, int R, int rb, const double* __restrict__ Bp, long N, long tile,
+                                         XtyOps& o) {
+  const int lane = threadIdx.x & 63, gq = lane >> 4, s = lane & 15;
+  const long i0 = tile * 16 + 4 * gq;
+  const nis_d4 zero = {0.0, 0.0, 0.0, 0.0};
+  const bool in = i0 < N;                               // the padded tail of a plane is allocated but not initialised
+#pragma unroll
+  for (int qt = 0; qt < JT; ++qt) o.b[qt] = in ? *reinterpret_cast<const nis_d4*>(Bp + ((size_t)tile * WM + 16 * qt + s) * 16 + 4 * gq) : zero;
+#pragma unroll
+  for (int rt = 0; rt < RPW; ++rt) {
+    const int row = rb + 16 * rt + s;
+    o.a[rt] = (in && row < R) ? *reinterpret_cast<const nis_d4*>(Ap + ((size_t)tile * FA + row) * 16 + 4 * gq) : zero;
+  }
+  if (in && i0 + 3 >= N) {
+#pragma unroll
+    for (int m = 1; m < 4; ++m)
+      if (i0 + m >= N) {
+#pragma unroll
+        for (int qt = 0; qt < JT; ++qt) o.b[qt][m] = 0.0;
+#pragma unroll
+        for (int rt = 0; rt < RPW; ++rt) o.a[rt][m] = 0.0;
+      }
+  }
+}
+
+__global__ __launch_bounds__(TPB, 2) void k_bwd_xty_w(const double* __restrict__ Ap, int FA, int R, const double* __restrict__ Bp, long N,
+                                                      double* __restrict__ part) {
   __shared__ double sm[GREC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
   const int rb = blockIdx.y * RPW * 16;
@@ -474,24 +579,22 @@ __global__ __launch_bounds__(TPB) void k_bwd_xty_w(const double* __restrict__ Ap
 #pragma unroll
     for (int qt = 0; qt < JT; ++qt) acc[rt][qt] = nis_d4{0.0, 0.0, 0.0, 0.0};
   }
-  const long ntiles = (N + 15) / 16;
-  for (long tile = (long)blockIdx.x * NW + wave; tile < ntiles; tile += (long)gridDim.x * NW) {
+  const long ntiles = (N + 15) / 16, tstride = (long)gridDim.x * NW;
+  long tile = (long)blockIdx.x * NW + wave;
+  XtyOps cur, nxt;
+  if (tile < ntiles) xty_load(Ap, FA, R, rb, Bp, N, tile, cur);
+  for (; tile < ntiles; tile += tstride) {
+    const bool more = tile + tstride < ntiles;
+    if (more) xty_load(Ap, FA, R, rb, Bp, N, tile + tstride, nxt);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const long ii = tile * 16 + 4 * gq + m;
-      const bool ok = ii < N;
-      double b[JT];
-#pragma unroll
-      for (int qt = 0; qt < JT; ++qt) b[qt] = ok ? Bp[(size_t)(16 * qt + s) * ld + ii] : 0.0;
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int rt = 0; rt < RPW; ++rt) {
-        const int row = rb + 16 * rt + s;
-        const double a = (ok && row < R) ? Ap[(size_t)row * ld + ii] : 0.0;
-        rsum[rt] += a;
+        rsum[rt] += cur.a[rt][m];
 #pragma unroll
-        for (int qt = 0; qt < JT; ++qt) acc[rt][qt] = mfma(a, b[qt], acc[rt][qt]);
+        for (int qt = 0; qt < JT; ++qt) acc[rt][qt] = mfma(cur.a[rt][m], cur.b[qt][m], acc[rt][qt]);
       }
-    }
+    if (more) cur = nxt;
   }
 #pragma unroll
   for (int rt = 0; rt < RPW; ++rt) {
@@ -521,14 +624,30 @@ __global__ __launch_bounds__(TPB) void k_bwd_xty_w(const double* __restrict__ Ap
   for (int e = tid; e < GREC; e += TPB) rec[e] = sm[e];
 }
 
-// records -> their sum (one thread per element, fixed order over the records)
+// records -> their sum: a workgroup owns 4 elements, 64 slices of the records each; fixed order (bitwise reproducible)
 __global__ __launch_bounds__(TPB) void k_bwd_reduce_w(const double* __restrict__ part, int nparts, int nacc, double* __restrict__ out) {
-  const int e = blockIdx.x * TPB + threadIdx.x;
-  if (e >= nacc) return;
+  __shared__ double sm[64][4];
+  const int el = threadIdx.x & 3, slice = threadIdx.x >> 2;
+  const int e = blockIdx.x * 4 + el;
   part += (size_t)blockIdx.y * nparts * nacc;
-  double t = 0.0;
-  for (int b = 0; b < nparts; ++b) t += part[(size_t)b * nacc + e];
-  out[(size_t)blockIdx.y * nacc + e] = t;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  if (e < nacc) {
+    int b = slice;
+    for (; b + 192 < nparts; b += 256) {
+      t0 += part[(size_t)b * nacc + e];
+      t1 += part[(size_t)(b + 64) * nacc + e];
+      t2 += part[(size_t)(b + 128) * nacc + e];
+      t3 += part[(size_t)(b + 192) * nacc + e];
+    }
+    for (; b < nparts; b += 64) t0 += part[(size_t)b * nacc + e];
+  }
+  sm[slice][el] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  for (int h = 32; h > 0; h >>= 1) {
+    if (slice < h) sm[slice][el] += sm[slice + h][el];
+    __syncthreads();
+  }
+  if (slice == 0 && e < nacc) out[(size_t)blockIdx.y * nacc + e] = sm[0][el];
 }
 
 // Reduced records -> gradient blob in the reference's parameter order (include/nis_hip.h).
@@ -571,6 +690,7 @@ int device_cus() {
 }
 
 size_t ring_bytes(int out) { return (size_t)NW * NCB * out * 16 * sizeof(double); }
+long ldw_of(long N) { return (N + 15) / 16 * 16; }
 int groups_of(int rows) { return (rows + RPW * 16 - 1) / (RPW * 16); }
 
 struct Plan {
@@ -588,7 +708,7 @@ Plan plan_for(int R, long N) {
   p.ngl = groups_of(R);
   p.ngh = groups_of(WM);
   const long tiles_wg = ((N + 15) / 16 + NW - 1) / NW;
-  p.nxl = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 4 / p.ngl)));
+  p.nxl = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 2 / p.ngl)));      // 2 resident workgroups per CU
   p.nxh = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 2 / p.ngh)));
   p.part = std::max<size_t>((size_t)p.nb * SREC, std::max((size_t)p.ngl * p.nxl, (size_t)p.ngh * p.nxh) * GREC);
   return p;
@@ -608,7 +728,7 @@ size_t bwd_wide_workspace_doubles<NIS_WM>(const nis_cell_desc& cd, int64_t N) {
   const int T = cd.d - cd.P;
   const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.K);
   const Plan p = plan_for(R, (long)N);
-  return (size_t)(3 * WM + R) * N + p.part + (size_t)(cd.n_hidden + 2) * SREC + (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC;
+  return (size_t)(3 * WM + R) * ldw_of((long)N) + p.part + (size_t)(cd.n_hidden + 2) * SREC + (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC;
 }
 
 template <>
@@ -620,39 +740,49 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   w.wm_all = mw.wm_all;
   w.wm_last = mw.wm_last;
   w.bias_pad = mw.bias_pad;
+  const long ldw = ldw_of(N);                      // workspace planes: 16-sample aligned rows (vector loads in the GEMM)
+  k.ldw = ldw;
   k.dyp = ws;
-  k.alp = ws + (size_t)WM * N;
-  w.dhp = ws + (size_t)2 * WM * N;
-  k.dzp = ws + (size_t)3 * WM * N;
-  double* part = k.dzp + (size_t)c.R * N;
+  k.alp = ws + (size_t)WM * ldw;
+  w.dhp = ws + (size_t)2 * WM * ldw;
+  k.dzp = ws + (size_t)3 * WM * ldw;
+  double* part = k.dzp + (size_t)c.R * ldw;
   double* sums = part + p.part;
   double* glast = sums + (size_t)(L + 2) * SREC;
   double* ghid = glast + (size_t)p.ngl * GREC;
   k.part = part;
   const size_t ring = ring_bytes(c.out);
   const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : 16;
+#define NIS_HEAD(KIND, KMV, EX) hipLaunchKernelGGL((k_bwd_head_w<KIND, KMV, EX>), dim3(p.nb), dim3(TPB), ring, s, k, w)
   if (c.kind == NIS_PWLIN)
-    hipLaunchKernelGGL((k_bwd_head_w<NIS_PWLIN, 4>), dim3(p.nb), dim3(TPB), ring, s, k, w);
+    NIS_HEAD(NIS_PWLIN, 4, false);
+  else if (c.K == 4)
+    NIS_HEAD(NIS_PWQUAD, 4, true);
+  else if (c.K == 8)
+    NIS_HEAD(NIS_PWQUAD, 8, true);
+  else if (c.K == 16)
+    NIS_HEAD(NIS_PWQUAD, 16, true);
   else if (km == 4)
-    hipLaunchKernelGGL((k_bwd_head_w<NIS_PWQUAD, 4>), dim3(p.nb), dim3(TPB), ring, s, k, w);
+    NIS_HEAD(NIS_PWQUAD, 4, false);
   else if (km == 8)
-    hipLaunchKernelGGL((k_bwd_head_w<NIS_PWQUAD, 8>), dim3(p.nb), dim3(TPB), ring, s, k, w);
+    NIS_HEAD(NIS_PWQUAD, 8, false);
   else
-    hipLaunchKernelGGL((k_bwd_head_w<NIS_PWQUAD, 16>), dim3(p.nb), dim3(TPB), ring, s, k, w);
-  hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + TPB - 1) / TPB, 1), dim3(TPB), 0, s, (const double*)part, p.nb, SREC, sums);
+    NIS_HEAD(NIS_PWQUAD, 16, false);
+#undef NIS_HEAD
+  hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + 3) / 4, 1), dim3(TPB), 0, s, (const double*)part, p.nb, SREC, sums);
   // dW_L = dZ a_L^T, db_L = row sums of dZ
-  hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.ngl), dim3(TPB), 0, s, (const double*)k.dzp, c.R, (const double*)k.alp, k.ld, N, part);
-  hipLaunchKernelGGL(k_bwd_reduce_w, dim3((GREC + TPB - 1) / TPB, p.ngl), dim3(TPB), 0, s, (const double*)part, p.nxl, GREC, glast);
+  hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.ngl), dim3(TPB), 0, s, (const double*)k.dzp, c.R, c.R, (const double*)k.alp, N, part);
+  hipLaunchKernelGGL(k_bwd_reduce_w, dim3((GREC + 3) / 4, p.ngl), dim3(TPB), 0, s, (const double*)part, p.nxl, GREC, glast);
   for (int l = L; l >= 1; --l) {
     const int pass = L - l + 1;
     k.sums = sums + (size_t)(pass - 1) * SREC;
     hipLaunchKernelGGL(k_bwd_layer_w, dim3(p.nb), dim3(TPB), 0, s, k, w, l);
-    hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + TPB - 1) / TPB, 1), dim3(TPB), 0, s, (const double*)part, p.nb, SREC,
+    hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + 3) / 4, 1), dim3(TPB), 0, s, (const double*)part, p.nb, SREC,
                        sums + (size_t)pass * SREC);
     // dW_{l-1} = d h_l a_{l-1}^T
-    hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxh, p.ngh), dim3(TPB), 0, s, (const double*)w.dhp, c.width[l - 1], (const double*)k.alp, k.ld,
+    hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxh, p.ngh), dim3(TPB), 0, s, (const double*)w.dhp, WM, c.width[l - 1], (const double*)k.alp,
                        N, part);
-    hipLaunchKernelGGL(k_bwd_reduce_w, dim3((GREC + TPB - 1) / TPB, p.ngh), dim3(TPB), 0, s, (const double*)part, p.nxh, GREC,
+    hipLaunchKernelGGL(k_bwd_reduce_w, dim3((GREC + 3) / 4, p.ngh), dim3(TPB), 0, s, (const double*)part, p.nxh, GREC,
                        ghid + (size_t)(l - 1) * p.ngh * GREC);
   }
   k.sums = sums + (size_t)L * SREC;

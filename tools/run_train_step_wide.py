@@ -45,9 +45,10 @@ for name in which:
             loss.backward()
             return loss
 
-        step()
+        for _ in range(3):
+            step()
         torch.cuda.synchronize()
-        reps = 3
+        reps = 5
         t0 = time.perf_counter()
         for _ in range(reps):
             loss = step()
