@@ -101,6 +101,7 @@ class BasicManager(ModelAPI):
         self.optimizer_object = None
         self.best_model = None
         self.sample_hook = None      # callable(n, d, dtype, stage) -> tensor: replaces the uniform draws
+        self.data_parallel = None    # nf_amd.parallel.DataParallel: gradient / bookkeeping all-reduce per optimizer step
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -159,6 +160,12 @@ class BasicManager(ModelAPI):
             m2 = hip_moments(((fres / maxf) ** 2).detach())
             self.best_var += float((m2[2] / (m2[0] - 1.0)) / 2 * mini_batch_size)   # precedence as in :165
 
+        if self.data_parallel is not None:                  # same normalisation / starting point on every rank
+            dp = self.data_parallel
+            maxf = dp.sync_max(torch.as_tensor(maxf, device=dev))
+            self.best_loss = dp.mean(self.best_loss)
+            self.best_var = float(dp.mean(torch.as_tensor(self.best_var, device=dev, dtype=torch.double)))
+            integ[0], err[0] = dp.mean(integ[0]), dp.mean(err[0])
         if save_best or log:                                                        # :170-196
             XJ = self._forward(w, dev)
             X, J = XJ[:, :-1], XJ[:, -1]
@@ -209,6 +216,12 @@ class BasicManager(ModelAPI):
                 del XJ, fXJ
             loss = loss / n_minibatches
             loss.backward()
+            if self.data_parallel is not None:              # nf_amd.parallel.DataParallel: one all-reduce per step
+                sc = self.data_parallel.sync_step(self.model, torch.stack(
+                    [loss.detach().double(), torch.as_tensor(var, device=dev).double(), integ[i + 1].double(),
+                     err[i + 1].double()]))
+                loss, var = sc[0].to(loss.dtype), sc[1]
+                integ[i + 1], err[i + 1] = sc[2].to(integ.dtype), sc[3].to(err.dtype)
             optimizer_object.step()
             self.history.append(loss.detach())
             if run is not None and log:

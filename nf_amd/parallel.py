@@ -99,3 +99,60 @@ def integrate_sharded(manager, f, nitn, neval, dev=None):
     sig = torch.sum(mean / var) / torch.sum(1 / var)
     sig_err = torch.sqrt(1 / torch.sum(1 / var)) / np.sqrt(int(neval) * int(nitn))
     return (sig, sig_err)
+
+
+class DataParallel:
+    """Sample-sharded training ("data-parallel - same sharding + gradient all-reduce").
+
+    Every rank runs `_train_variance_forward_seq` on its OWN minibatches (`batch_size` / `mini_batch_size` are per
+    rank; seed the ranks differently), as independent train-mode BatchNorm batches.  Per optimizer step ONE all-reduce
+    carries the flattened parameter gradients (<= 448 KB at C5) together with the bookkeeping scalars (loss, variance,
+    estimator terms); all of them are averaged over the ranks, so the optimizer states, the early-stopping decisions and
+    the saved best model stay identical everywhere.  `max f` of the survey is combined with one all-reduce(MAX).
+
+        rank, ws, _ = parallel.init_from_env()
+        NF = PWQuadManager(n_flow=2); NF.create_model(2, 4, [3] * 3)
+        parallel.DataParallel(NF)                      # broadcasts rank 0's parameters / BN buffers, installs itself
+        NF._train_variance_forward_seq(f, optim, ...)
+    """
+
+    def __init__(self, manager, group=None, src=0):
+        self.group = group
+        self.rank, self.world = world()
+        self.manager = manager
+        if self.world > 1:
+            with torch.no_grad():
+                for t in list(manager._model.parameters()) + list(manager._model.buffers()):
+                    dist.broadcast(t, src=src, group=group)
+        manager.data_parallel = self
+
+    def sync_max(self, t):
+        """Element-wise maximum over the ranks (survey: max |f|)."""
+        if self.world == 1:
+            return t
+        t = t.detach().clone()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def mean(self, t):
+        """Average of a tensor over the ranks."""
+        if self.world == 1:
+            return t
+        t = t.detach().clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t / self.world
+
+    def sync_step(self, model, scalars):
+        """Average the gradients of `model` (in place) and the 1-d tensor `scalars` over the ranks: one all-reduce."""
+        if self.world == 1:
+            return scalars
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads] + [scalars.detach().reshape(-1).to(grads[0].dtype)])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat /= self.world
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+        return flat[off:].to(scalars.dtype)

@@ -5,6 +5,8 @@ size-independent properties at BASELINE.json's full batch sizes.
 Tolerances (float64 everywhere): bin indices bit-exact; values rtol 1e-9 (different summation order in
 the conditioner, device libm exp/log within 1-2 ulp, batch statistics merged pairwise instead of
 sequentially).  float32 results of integrate(): rtol 2e-6."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -589,3 +591,21 @@ def test_flow_into_rambo_integrand_vs_oracle(cfg):
         assert got[0] == N
         np.testing.assert_allclose(got[1], m, rtol=1e-8)
         np.testing.assert_allclose(got[2] / (N - 1), v, rtol=1e-7)
+
+
+def test_data_parallel_training_two_ranks_one_gpu():
+    """nf_amd.parallel.DataParallel under torch.distributed.run (2 ranks, gloo, both on this GPU): parameters, loss
+    history and the returned estimate agree bit for bit across ranks although every rank sees its own minibatches."""
+    import socket
+    import subprocess
+    import sys
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NIS_DIST_BACKEND="gloo", DP_EPOCHS="25", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "dp_train_check.py")],
+                       env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0 and "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from nf_amd.parallel import allreduce_moments, merge_moments, shard_size
+from nf_amd.parallel import DataParallel, allreduce_moments, merge_moments, shard_size
 from oracle import flow as oflow
 
 
@@ -74,3 +74,65 @@ def test_merge_moments_handles_empty_and_uneven_shards():
     np.testing.assert_allclose(m[:3], ref[:3], rtol=1e-12)
     assert m[3] == ref[3]
     assert [shard_size(10, r, 4) for r in range(4)] == [3, 3, 2, 2]
+
+
+class _FakeManager:
+    """What DataParallel touches of a manager: `_model` and the `data_parallel` slot."""
+
+    def __init__(self, model):
+        self._model = model
+        self.data_parallel = None
+
+
+def _dp_worker(rank, ws, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    torch.manual_seed(100 + rank)                       # ranks start from DIFFERENT parameters and buffers
+    model = torch.nn.Sequential(torch.nn.BatchNorm1d(3), torch.nn.Linear(3, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2)).double()
+    with torch.no_grad():
+        model[0].running_mean += rank + 1.0
+    mgr = _FakeManager(model)
+    dp = DataParallel(mgr)
+    assert mgr.data_parallel is dp
+    start = torch.cat([p.detach().reshape(-1) for p in model.parameters()] + [model[0].running_mean.reshape(-1)])
+    torch.manual_seed(7 + rank)                         # ... and see different minibatches
+    x = torch.rand(64, 3, dtype=torch.double)
+    loss = (model(x) ** 2).mean()
+    loss.backward()
+    local_g = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    sc = dp.sync_step(model, torch.stack([loss.detach(), torch.tensor(float(rank), dtype=torch.double)]))
+    synced_g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    mx = dp.sync_max(torch.tensor([float(rank), -float(rank)], dtype=torch.double))
+    mean = dp.mean(torch.tensor([float(rank)], dtype=torch.double))
+    np.savez(os.path.join(outdir, f"dp{rank}.npz"), start=start.numpy(), local_g=local_g.numpy(), synced_g=synced_g.numpy(),
+             sc=sc.numpy(), loss=float(loss), mx=mx.numpy(), mean=mean.numpy())
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_broadcast_and_one_allreduce_per_step():
+    """DataParallel: rank 0's parameters / BN buffers everywhere, gradients and bookkeeping scalars averaged."""
+    ws = 2
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(_dp_worker, args=(ws, port, td), nprocs=ws, join=True)
+        o = [np.load(os.path.join(td, f"dp{r}.npz")) for r in range(ws)]
+    np.testing.assert_array_equal(o[0]["start"], o[1]["start"])                 # broadcast from rank 0
+    np.testing.assert_array_equal(o[0]["synced_g"], o[1]["synced_g"])           # identical after the all-reduce
+    np.testing.assert_allclose(o[0]["synced_g"], (o[0]["local_g"] + o[1]["local_g"]) / 2, rtol=1e-15, atol=1e-18)
+    assert np.abs(o[0]["local_g"] - o[1]["local_g"]).max() > 0                  # the shards really differed
+    np.testing.assert_allclose(o[0]["sc"], [(o[0]["loss"] + o[1]["loss"]) / 2, 0.5], rtol=1e-15)
+    np.testing.assert_array_equal(o[0]["sc"], o[1]["sc"])
+    np.testing.assert_array_equal(o[0]["mx"], [1.0, 0.0])
+    np.testing.assert_array_equal(o[1]["mean"], [0.5])
+
+
+def test_data_parallel_single_process_is_a_no_op():
+    model = torch.nn.Linear(2, 2).double()
+    mgr = _FakeManager(model)
+    dp = DataParallel(mgr)
+    (model(torch.ones(3, 2, dtype=torch.double)).sum()).backward()
+    g = model.weight.grad.clone()
+    sc = dp.sync_step(model, torch.tensor([1.5], dtype=torch.double))
+    assert torch.equal(model.weight.grad, g) and float(sc[0]) == 1.5
+    assert float(dp.sync_max(torch.tensor(2.0))) == 2.0 and float(dp.mean(torch.tensor(2.0))) == 2.0
