@@ -304,6 +304,44 @@ class BasicManager(ModelAPI):
             print("Torch save not possible")
         return filename
 
+    # ------------------------------------------------------------------ checkpoints
+    def load_checkpoint(self, filename, map_location=None):
+        """Load a checkpoint the REFERENCE (or this package) wrote into the instantiated model: `logdir/torch_int`
+        ({'model_state_dict'}, manager.py:107-109) or `logdir/torch` (+ best_epoch, best_loss, int_loss, best_loss_rel,
+        best_func_count, integ, err; manager.py:360-369).  The state_dict key layout is the reference's, so models trained
+        there integrate here and vice versa.  Returns the loaded dict."""
+        model = self.model                                   # AttributeError("No model was instantiated") like the reference
+        ck = torch.load(filename, map_location=map_location or "cpu", weights_only=False)
+        model.load_state_dict(ck["model_state_dict"])
+        self.best_model = model
+        for key in ("best_epoch", "best_loss", "int_loss", "best_loss_rel", "best_func_count"):
+            if key in ck:
+                setattr(self, key, ck[key])
+        if "integ" in ck:
+            self.integ_tot, self.err_tot = ck["integ"], ck["err"]
+        return ck
+
+    def save_training_state(self, filename, optimizer_object, epoch):
+        """Everything needed to continue `_train_variance_forward_seq` later (the reference can only restart from
+        scratch): model, best model, optimizer state, bookkeeping, and the epoch to continue from."""
+        keep = {k: getattr(self, k) for k in ("best_epoch", "best_loss", "int_loss", "best_loss_rel", "best_func_count", "best_var",
+                                              "history") if hasattr(self, k)}
+        torch.save({"model_state_dict": self.model.state_dict(),
+                    "best_model_state_dict": (self.best_model or self.model).state_dict(),
+                    "optimizer_state_dict": optimizer_object.state_dict(), "epoch": int(epoch), **keep}, filename)
+
+    def load_training_state(self, filename, optimizer_object, map_location=None):
+        """Inverse of `save_training_state`; returns the epoch to pass as `epoch_start`."""
+        ck = torch.load(filename, map_location=map_location or "cpu", weights_only=False)
+        self.model.load_state_dict(ck["model_state_dict"])
+        self.best_model = copy.deepcopy(self.model)
+        self.best_model.load_state_dict(ck["best_model_state_dict"])
+        optimizer_object.load_state_dict(ck["optimizer_state_dict"])
+        for key in ("best_epoch", "best_loss", "int_loss", "best_loss_rel", "best_func_count", "best_var", "history"):
+            if key in ck:
+                setattr(self, key, ck[key])
+        return int(ck["epoch"])
+
     # ------------------------------------------------------------------ integration
     def integrate(self, f, nitn, neval, dev=None):
         """Inverse-variance weighted Monte-Carlo estimate over nitn batches of neval points drawn in

@@ -141,3 +141,42 @@ def test_nisrep_import_paths():
     assert gen.nDimPhaseSpace() == 8
     np.testing.assert_allclose(ps.FlatInvertiblePhasespace.get_flatWeights(1000., 4),
                                golden("rambo.npz").meta["m2to4_massive"]["flat"], rtol=1e-14)
+
+
+def test_reference_checkpoints_load_and_training_state_round_trips(tmp_path, g_models):
+    """the reference's `torch.save` dicts (manager.py:107-109, :360-369) load unchanged; the
+    added resume state (model, best model, optimizer, bookkeeping, epoch) survives a save / load cycle."""
+    case = golden("models.npz").cases()[0]
+    m = g_models.meta[case]
+    sd_ref = {k: torch.as_tensor(v) for k, v in g_models.sub(case, "sd").items()}
+    # what the reference writes at the end of training, and its initial dump
+    full = {"best_epoch": 17, "best_loss": torch.tensor(0.123), "int_loss": torch.tensor(0.5), "best_loss_rel": torch.tensor(0.246),
+            "best_func_count": 123456, "model_state_dict": sd_ref, "integ": torch.tensor(0.2322), "err": torch.tensor(1e-4)}
+    torch.save(full, tmp_path / "torch")
+    torch.save({"model_state_dict": sd_ref}, tmp_path / "torch_int")
+    NF = build_manager(m)
+    NF.load_checkpoint(str(tmp_path / "torch_int"))
+    for k, v in NF._model.state_dict().items():
+        np.testing.assert_allclose(v.double().cpu().numpy(), sd_ref[k].double().numpy(), rtol=1e-6, err_msg=k)
+    NF2 = build_manager(m)
+    ck = NF2.load_checkpoint(str(tmp_path / "torch"))
+    assert NF2.best_epoch == 17 and NF2.best_func_count == 123456 and float(NF2.integ_tot) == float(full["integ"])
+    assert NF2.best_model is NF2._model and set(ck) == set(full)
+    # resume state
+    opt = torch.optim.Adamax(NF2._model.parameters(), lr=2e-3, weight_decay=1e-4)
+    for p in NF2._model.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    NF2.history = [torch.tensor(1.0), torch.tensor(0.5)]
+    NF2.best_var = 0.25
+    NF2.save_training_state(str(tmp_path / "resume"), opt, epoch=2)
+    NF3 = build_manager(m)
+    opt3 = torch.optim.Adamax(NF3._model.parameters(), lr=2e-3, weight_decay=1e-4)
+    assert NF3.load_training_state(str(tmp_path / "resume"), opt3) == 2
+    for (k, a), (_, b) in zip(NF2._model.state_dict().items(), NF3._model.state_dict().items()):
+        assert torch.equal(a, b), k
+    sa, sb = opt.state_dict()["state"], opt3.state_dict()["state"]
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[i]["exp_avg"], sb[i]["exp_avg"]) for i in sa)
+    assert NF3.best_epoch == 17 and NF3.best_var == 0.25 and len(NF3.history) == 2
+    with pytest.raises(AttributeError, match="No model was instantiated"):
+        type(NF)(n_flow=2).load_checkpoint(str(tmp_path / "torch"))
