@@ -37,7 +37,7 @@ extern "C" {
 #define NIS_MAX_CELLS   64
 #define NIS_MAX_LEGS    10   /* RAMBO: max number of final-state particles            */
 
-enum { NIS_PWLIN = 0, NIS_PWQUAD = 1 };
+enum { NIS_PWLIN = 0, NIS_PWQUAD = 1, NIS_AFFINE = 2 };
 enum { NIS_BN_EVAL = 0, NIS_BN_TRAIN = 1 };
 enum { NIS_F64 = 0, NIS_F32 = 1 };
 
@@ -57,12 +57,13 @@ enum {
  */
 enum { NIS_F_CAMEL = 0, NIS_F_NORMAL = 1, NIS_F_ONE = 2 };
 
-/* One coupling cell (PWLin: layers/coupling_cells.py:73-142, PWQuad: :144-228) with its
+/* One coupling cell (PWLin: layers/coupling_cells.py:73-142, PWQuad: :144-228, AffineCoupling: :6-70; K is
+ * ignored for NIS_AFFINE, whose conditioner has 2 outputs per transformed column laid out [scale|shift][T]) with its
  * conditioner (RectNN :230-254).  `in_col[j]` is the state plane that feeds the cell's local
  * column j (0..P-1 pass-through, P..d-1 transformed): the composition of all permutation
  * layers in front of the cell.  Transformed columns are written back to the same planes. */
 typedef struct nis_cell_desc {
-  int32_t kind;                    /* NIS_PWLIN | NIS_PWQUAD                                  */
+  int32_t kind;                    /* NIS_PWLIN | NIS_PWQUAD | NIS_AFFINE                      */
   int32_t d;                       /* flow_size                                                */
   int32_t P;                       /* pass_through_size                                        */
   int32_t K;                       /* n_bins                                                   */
@@ -76,6 +77,7 @@ typedef struct nis_cell_desc {
  *   BN_0.weight[P] BN_0.bias[P] Lin_0.weight[w0*P]
  *   BN_1.weight[w0] BN_1.bias[w0] Lin_1.weight[w1*w0] ... BN_L.weight BN_L.bias
  *   Lin_L.weight[(T*out)*w_{L-1}] Lin_L.bias[T*out]          (Linear weights row-major (out,in))
+ * NIS_AFFINE: the hidden Linears carry a bias too (coupling_cells.py:26-40): Lin_l.bias[w_l] follows Lin_l.weight.
  * Running-statistics blob:  for l = 0..L: running_mean[f_l] running_var[f_l]   (f_0=P, f_l=w_{l-1})
  */
 size_t nis_cell_param_count(const nis_cell_desc* c);

@@ -13,7 +13,7 @@ NIS_MAX_BINS = 128
 NIS_MAX_CELLS = 64
 NIS_MAX_LEGS = 10
 
-NIS_PWLIN, NIS_PWQUAD = 0, 1
+NIS_PWLIN, NIS_PWQUAD, NIS_AFFINE = 0, 1, 2
 NIS_BN_EVAL, NIS_BN_TRAIN = 0, 1
 NIS_F64, NIS_F32 = 0, 1
 NIS_F_CAMEL, NIS_F_NORMAL, NIS_F_ONE = 0, 1, 2

@@ -85,7 +85,8 @@ extern "C" int nis_prof_read(double* total_ms, int32_t* launches) {
 // ---------------------------------------------------------------------------------------------
 // sizes
 static inline int cell_T(const nis_cell_desc& c) { return c.d - c.P; }
-static inline int cell_out(const nis_cell_desc& c) { return c.kind == NIS_PWQUAD ? 2 * c.K + 1 : c.K; }
+static inline int cell_out(const nis_cell_desc& c) { return c.kind == NIS_PWQUAD ? 2 * c.K + 1 : c.kind == NIS_AFFINE ? 2 : c.K; }
+static inline bool cell_hidden_bias(const nis_cell_desc& c) { return c.kind == NIS_AFFINE; }
 static inline int cell_R(const nis_cell_desc& c) { return cell_T(c) * cell_out(c); }
 static inline int cell_feat(const nis_cell_desc& c, int l) { return l == 0 ? c.P : c.width[l - 1]; }
 
@@ -95,6 +96,7 @@ extern "C" size_t nis_cell_param_count(const nis_cell_desc* c) {
     const int F = cell_feat(*c, l);
     const int O = l < c->n_hidden ? c->width[l] : cell_R(*c);
     n += 2 * (size_t)F + (size_t)O * F;
+    if (l < c->n_hidden && cell_hidden_bias(*c)) n += O;
   }
   return n + cell_R(*c);
 }
@@ -106,7 +108,7 @@ extern "C" size_t nis_cell_running_count(const nis_cell_desc* c) {
 
 struct CellLayout {
   int WM, KM;
-  size_t off_wp, off_wlast, off_bias, off_gb, off_coef, off_part, off_gstat;   // in doubles from the workspace body
+  size_t off_wp, off_wlast, off_bias, off_gb, off_hb, off_coef, off_part, off_gstat;   // in doubles from the workspace body
   size_t off_wm, off_wmlast, off_biaspad;                                      // matrix-core fragment images (WM >= 16)
   int RT;                                                                      // row tiles of the last layer
 };
@@ -144,6 +146,7 @@ static size_t flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay
     L.off_wlast = off;   off += R * WM;
     L.off_bias = off;    off += (R + 7) / 8 * 8;
     L.off_gb = off;      off += (nl + 1) * 2 * WM;
+    L.off_hb = off;      off += (nl + 1) * WM;        // bias of the Linear in front of BN layer l (zero unless NIS_AFFINE)
     L.off_coef = off;    off += (size_t)G * (nl + 1) * 2 * WM;
     L.off_gstat = off;   off += (size_t)G * (nl + 1) * 2 * WM;
     L.off_part = off;    off += (nl + 1) * (size_t)G * NIS_MAXB * WM * 3;
@@ -162,8 +165,8 @@ static size_t flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay
 }
 
 static int validate_cell(const nis_cell_desc& c, int d) {
-  if (c.kind != NIS_PWLIN && c.kind != NIS_PWQUAD) return NIS_E_ARG;
-  if (c.d != d || c.P < 1 || c.P >= d || c.K < 1) return NIS_E_ARG;
+  if (c.kind != NIS_PWLIN && c.kind != NIS_PWQUAD && c.kind != NIS_AFFINE) return NIS_E_ARG;
+  if (c.d != d || c.P < 1 || c.P >= d || (c.K < 1 && c.kind != NIS_AFFINE)) return NIS_E_ARG;
   if (c.n_hidden < 1 || c.n_hidden > NIS_MAX_HIDDEN) return NIS_E_UNSUPPORTED;
   int m = c.P;
   for (int l = 0; l < c.n_hidden; ++l) {
@@ -216,7 +219,8 @@ extern "C" size_t nis_flow_workspace_bytes(const nis_flow* f, int64_t n_batches)
 // ---------------------------------------------------------------------------------------------
 // k_pack: reference-order parameter blob -> zero-padded WM-strided weights (+ eval-mode BN affine).
 __global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double* __restrict__ prm, const double* __restrict__ run,
-                                                  int eval_mode, double* wp, double* wlast, double* bias, double* gb) {
+                                                  int eval_mode, double* wp, double* wlast, double* bias, double* gb, double* hb,
+                                                  int hidden_bias) {
   const int tid = blockIdx.x * NIS_TPB + threadIdx.x, nth = gridDim.x * NIS_TPB;
   size_t off = 0;
   int roff = 0;
@@ -226,15 +230,20 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double*
     const double* gam = prm + off;
     const double* bet = prm + off + F;
     const double* W = prm + off + 2 * F;
+    // bias of the Linear that FEEDS this BN layer (NIS_AFFINE): the kernels evaluate the Linear without it -- a constant
+    // in front of a BatchNorm cancels -- and account for it where it is visible: the running mean and the eval-mode shift
+    const double* hbin = (hidden_bias && l >= 1) ? prm + off - F : nullptr;
     for (int j = tid; j < WM; j += nth) {
       const double g = j < F ? gam[j] : 0.0, b = j < F ? bet[j] : 0.0;
+      const double hbv = (hbin && j < F) ? hbin[j] : 0.0;
       gb[(l * 2 + 0) * WM + j] = g;
       gb[(l * 2 + 1) * WM + j] = b;
+      if (hb) hb[l * WM + j] = hbv;
       if (eval_mode) {                       // BatchNorm1d.eval(): running statistics
         double sc = 0.0, sh = 0.0;
         if (j < F) {
           sc = g / sqrt(run[roff + F + j] + NIS_BN_EPS);
-          sh = b - run[roff + j] * sc;
+          sh = b - (run[roff + j] - hbv) * sc;
         }
         c.coef[(l * 2 + 0) * WM + j] = sc;
         c.coef[(l * 2 + 1) * WM + j] = sh;
@@ -255,6 +264,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double*
       for (int r = tid; r < c.R; r += nth) bias[r] = bs[r];
     }
     off += 2 * (size_t)F + (size_t)O * F;
+    if (l < c.L && hidden_bias) off += O;
     roff += 2 * F;
   }
 }
@@ -789,6 +799,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     c.wlast = body + L.off_wlast;
     c.bias = body + L.off_bias;
     c.gb = body + L.off_gb;
+    c.hb = body + L.off_hb;
     c.coef = body + L.off_coef;
     c.partials = body + L.off_part;
     c.gstat = body + L.off_gstat;
@@ -846,7 +857,8 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       const int pgrid = (int)std::min<size_t>(64, ((size_t)c.R * L.WM + NIS_TPB - 1) / NIS_TPB);
       NisProfScope ps(NIS_K_PACK, s);
       hipLaunchKernelGGL(k_pack, dim3(std::max(1, pgrid)), dim3(NIS_TPB), 0, s, c, L.WM, params[ci], (const double*)running[ci],
-                         train ? 0 : 1, body + L.off_wp, body + L.off_wlast, body + L.off_bias, body + L.off_gb);
+                         train ? 0 : 1, body + L.off_wp, body + L.off_wlast, body + L.off_bias, body + L.off_gb, body + L.off_hb,
+                         cell_hidden_bias(cd) ? 1 : 0);
       HIP_OK(hipGetLastError());
       if (mfma) {
         hipLaunchKernelGGL(k_pack_mfma, dim3(std::max(1, pgrid)), dim3(NIS_TPB), 0, s, L.WM, c.L, c.R, L.RT,
@@ -1050,7 +1062,7 @@ extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t
     c.gb = gb;
     c.coef = coef;
     hipLaunchKernelGGL(k_pack, dim3(WM >= 16 ? 32 : 1), dim3(NIS_TPB), 0, s, c, (int)WM, params[ci], (const double*)nullptr, 0, wp, wlast,
-                       bias, gb);
+                       bias, gb, (double*)nullptr, 0);
     HIP_OK(hipGetLastError());
     MfmaW mw;
     mw.wm_all = mw.wm_last = mw.bias_pad = nullptr;

@@ -379,6 +379,7 @@ __global__ void k_bwd_scatter(CellK c, int WM, const double* __restrict__ sums, 
 
 // ---------------------------------------------------------------------------------------------
 bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm) {
+  if (cd.kind == NIS_AFFINE) return false;       // AffineCoupling differentiates through the PyTorch re-evaluation for now
   if (wm == 16) return bwd_wide_supported<16>(cd);
   if (wm == 32) return bwd_wide_supported<32>(cd);
   if (wm == 64) return bwd_wide_supported<64>(cd);

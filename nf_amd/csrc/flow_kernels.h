@@ -69,13 +69,14 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
         shift = be - mean * scale;
         if (writer) {
           const double unb = n > 1.0 ? m2 / (n - 1.0) : var_b;   // running_var takes the unbiased one
+          const double mean_r = mean + (c.hb ? c.hb[fresh * WM + j] : 0.0);   // what torch's BN sees: Linear output incl. its bias
           if (c.G == 1) {
             double* run = c.running + cellk_running_off(c, fresh);
-            run[j] = (1.0 - NIS_BN_MOM) * run[j] + NIS_BN_MOM * mean;
+            run[j] = (1.0 - NIS_BN_MOM) * run[j] + NIS_BN_MOM * mean_r;
             run[F + j] = (1.0 - NIS_BN_MOM) * run[F + j] + NIS_BN_MOM * unb;
             if (j == 0 && c.tracked) c.tracked[fresh] += 1;
           } else {                                               // applied in batch order by k_running_update
-            c.gstat[(((size_t)fresh * c.G + g) * 2 + 0) * WM + j] = mean;
+            c.gstat[(((size_t)fresh * c.G + g) * 2 + 0) * WM + j] = mean_r;
             c.gstat[(((size_t)fresh * c.G + g) * 2 + 1) * WM + j] = unb;
           }
         }
@@ -124,13 +125,14 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
           shift = be - mean1 * scale;
           if (writer) {
             const double unb = n > 1.0 ? var1 * (n / (n - 1.0)) : var1;
+            const double mean1_r = mean1 + (c.hb ? c.hb[1 * WM + tid] : 0.0);
             if (c.G == 1) {
               double* run = c.running + cellk_running_off(c, 1);
-              run[tid] = (1.0 - NIS_BN_MOM) * run[tid] + NIS_BN_MOM * mean1;
+              run[tid] = (1.0 - NIS_BN_MOM) * run[tid] + NIS_BN_MOM * mean1_r;
               run[F1 + tid] = (1.0 - NIS_BN_MOM) * run[F1 + tid] + NIS_BN_MOM * unb;
               if (tid == 0 && c.tracked) c.tracked[1] += 1;
             } else {
-              c.gstat[(((size_t)1 * c.G + g) * 2 + 0) * WM + tid] = mean1;
+              c.gstat[(((size_t)1 * c.G + g) * 2 + 0) * WM + tid] = mean1_r;
               c.gstat[(((size_t)1 * c.G + g) * 2 + 1) * WM + tid] = unb;
             }
           }
@@ -515,6 +517,14 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
         for (int k = 0; k < KM; ++k)
           W[k] = (KEXACT || k < c.K) ? nis_exp(last_dot<WM>(wl, bias, row0 + Kq + 1 + k, a), etab) : 0.0;             // :175,178
         y = pwquad_column<KM, KEXACT>(xb, c.K, V, W, &jf, &bin);
+      } else if (KIND == NIS_AFFINE) {
+        // AffineCoupling (coupling_cells.py:56-68): rows [scale | shift][T];  y = atan(20 e^z0 x + relu(z1)) / (pi/2)
+        const double s0 = 20.0 * nis_exp(last_dot<WM>(wl, bias, t, a), etab);
+        const double z1 = last_dot<WM>(wl, bias, c.T + t, a);
+        const double u = xb * s0 + (z1 > 0.0 ? z1 : 0.0);
+        y = atan(u) / (M_PI / 2);
+        jf = s0 * (1.0 / (u * u + 1.0));
+        bin = 0;
       } else {
         // PWLin: equal-width bins -> the index is known before the heights (coupling_cells.py:126-133),
         // so the K heights are streamed: total, prefix below the bin, and the bin's own height.
@@ -541,7 +551,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
       }
       if (fz.write_planes) col[c.out_off + i] = y;
       jprod *= jf;
-      if (bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
+      if (KIND != NIS_AFFINE && bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
       if (next) {
 #pragma unroll
         for (int f = 0; f < NF; ++f)
@@ -554,6 +564,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
       }
     }
     double* jp = planes + (size_t)c.jplane * ld;
+    if (KIND == NIS_AFFINE) jprod *= 1.0 / (M_PI / 2);          // the reference applies 2/pi ONCE per cell (:68)
     const double jout = (c.first ? 1.0 : jp[i]) * jprod;
     if (fz.write_planes) jp[c.out_off + i] = jout;
     if (next) {

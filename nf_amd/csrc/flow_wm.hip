@@ -60,10 +60,10 @@ static int occ_of(K kern) {
 
 template <>
 int apply_blocks_per_cu<NIS_WM>(int kind, int km) {
-  static int cache[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+  static int cache[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
   const bool exact = km < 0;
   const int kk = exact ? -km : km;
-  const int slot = kind == NIS_PWLIN ? 0 : (kk == 4 ? 1 : kk == 8 ? 2 : kk == 16 ? 3 : 4) + (exact ? 4 : 0);
+  const int slot = kind == NIS_PWLIN ? 0 : kind == NIS_AFFINE ? 9 : (kk == 4 ? 1 : kk == 8 ? 2 : kk == 16 ? 3 : 4) + (exact ? 4 : 0);
   if (cache[slot] < 0) {
     switch (slot) {
       case 0: cache[slot] = occ_of(k_cell_apply<NIS_PWLIN, NIS_WM, 4, false>); break;
@@ -74,6 +74,7 @@ int apply_blocks_per_cu<NIS_WM>(int kind, int km) {
       case 5: cache[slot] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 4, true>); break;
       case 6: cache[slot] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 8, true>); break;
       case 7: cache[slot] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 16, true>); break;
+      case 9: cache[slot] = occ_of(k_cell_apply<NIS_AFFINE, NIS_WM, 4, false>); break;
       default: cache[slot] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 32, true>); break;
     }
   }
@@ -89,6 +90,8 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
                                 int grid, hipStream_t s) {
   if (c.kind == NIS_PWLIN) {
     NIS_APPLY(NIS_PWLIN, 4, false);
+  } else if (c.kind == NIS_AFFINE) {
+    NIS_APPLY(NIS_AFFINE, 4, false);
   } else {
     switch (km) {
       case 4: NIS_APPLY(NIS_PWQUAD, 4, false); break;
@@ -114,6 +117,7 @@ static size_t mf_ring_bytes(const CellK& c) { return (size_t)(NIS_MF_TPB / 64) *
 
 template <>
 bool mfma_supported<NIS_WM>(const CellK& c) {
+  if (c.kind == NIS_AFFINE) return false;       // rows of one column are not contiguous ([scale|shift][T]): fp64 VALU kernels
   return mf_ring_bytes(c) + 24 * 1024 <= 160 * 1024 && (c.kind == NIS_PWLIN || c.K <= 32);
 }
 

@@ -119,6 +119,7 @@ struct CellK {
   const double* wlast;                   // padded last layer:    R x WM
   const double* bias;                    // R
   const double* gb;                      // (L+1) x 2 x WM  gamma | beta, zero padded
+  const double* hb;                      // (L+1) x WM  bias of the Linear feeding BN layer l (NIS_AFFINE; else zeros / null)
   double* coef;                          // (L+1) x 2 x WM  scale | shift  (finalised BN affine form)
   double* partials;                      // (L+1) x maxb x WM x 3
   double* next_partials;                 // BN_0 records of the next cell (maxb x WMnext x 3), stride next_wm

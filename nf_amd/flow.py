@@ -20,6 +20,8 @@ def _param_tensors(cell):
     ps, rs = [], []
     for l, bn in enumerate(bns):
         ps += [bn.weight, bn.bias, lins[l].weight]
+        if l < len(bns) - 1 and lins[l].bias is not None:       # AffineCoupling: biased hidden Linears
+            ps.append(lins[l].bias)
         rs += [(bn, "running_mean"), (bn, "running_var")]
     ps.append(lins[-1].bias)
     return ps, rs, bns
@@ -84,7 +86,7 @@ def cell_desc(cell, in_col):
     d.kind = cell.KIND
     d.d = cell.flow_size
     d.P = cell.pass_through_size
-    d.K = cell.n_bins
+    d.K = int(getattr(cell, "n_bins", 0) or 0)
     widths = cell.hidden_widths
     d.n_hidden = len(widths)
     if len(widths) > _lib.NIS_MAX_HIDDEN:

@@ -11,7 +11,9 @@ Forward values ALWAYS come from the HIP kernels.  Gradients (needed only by
     recomputation is a device-side adjoint helper, not a fallback: it never produces a forward result and refuses to run
     without a GPU.  NF_AMD_TORCH_ADJOINT=1 forces it everywhere (A/B checks).
 """
+import math
 import os
+
 import torch
 import torch.nn.functional as F
 
@@ -36,6 +38,8 @@ def _conditioner_torch(cell, xA, train):
             h = F.linear(h, m.weight, m.bias)
         elif isinstance(m, torch.nn.ReLU):
             h = torch.relu(h)
+    if cell.KIND == _lib.NIS_AFFINE:
+        return h.reshape(h.shape[0], 2, cell.transform_size)
     return h.reshape(h.shape[0], cell.transform_size, -1)
 
 
@@ -45,10 +49,15 @@ def _gather(A, idx):
 
 def cell_torch(cell, x, train):
     """Differentiable re-evaluation of one cell (same maths as k_cell_apply) for the backward pass."""
-    P, d, K = cell.pass_through_size, cell.flow_size, cell.n_bins
+    P, d, K = cell.pass_through_size, cell.flow_size, getattr(cell, "n_bins", 0)
     xA, xB, jac = x[:, :P], x[:, P:d], x[:, d]
     Z = _conditioner_torch(cell, xA, train)
-    if cell.KIND == _lib.NIS_PWQUAD:
+    if cell.KIND == _lib.NIS_AFFINE:
+        s0 = 20 * torch.exp(Z[:, 0])
+        u = xB * s0 + torch.relu(Z[:, 1])
+        yB = torch.atan(u) / (math.pi / 2)
+        jac = jac * torch.prod(s0, 1) * (1 / (math.pi / 2)) * torch.prod(1 / (u ** 2 + 1), 1)
+    elif cell.KIND == _lib.NIS_PWQUAD:
         xB = torch.clamp(xB, max=1.0 - 1e-6)
         V = torch.exp(Z[:, :, :K + 1])
         W = torch.exp(Z[:, :, K + 1:])

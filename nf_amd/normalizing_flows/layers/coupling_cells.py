@@ -15,16 +15,17 @@ from ...flow import FlowEngine
 from .._autograd import run_flow
 
 
-def _conditioner(pass_through_size, sizes, reshape):
+def _conditioner(pass_through_size, sizes, reshape, hidden_bias=False):
     """BN(P) -> Linear(no bias) -> BN -> ReLU -> [Linear(no bias) -> BN -> ReLU]* -> Linear(+bias) -> Reshape
-    (coupling_cells.py:236-254; the same stack is written inline in PWLin, :84-104)."""
+    (coupling_cells.py:236-254; the same stack is written inline in PWLin, :84-104).  AffineCoupling builds the
+    same stack with biased hidden Linears (coupling_cells.py:24-40): hidden_bias=True."""
     mods = [torch.nn.BatchNorm1d(pass_through_size),
-            torch.nn.Linear(pass_through_size, sizes[0], bias=False),
+            torch.nn.Linear(pass_through_size, sizes[0], bias=hidden_bias),
             torch.nn.BatchNorm1d(sizes[0]),
             torch.nn.ReLU()]
     old = sizes[0]
     for size in sizes[1:-1]:
-        mods += [torch.nn.Linear(old, size, bias=False), torch.nn.BatchNorm1d(size), torch.nn.ReLU()]
+        mods += [torch.nn.Linear(old, size, bias=hidden_bias), torch.nn.BatchNorm1d(size), torch.nn.ReLU()]
         old = size
     mods.append(torch.nn.Linear(old, sizes[-1]))
     mods.append(Reshape(reshape[0], reshape[1]))
@@ -43,6 +44,8 @@ class _PiecewiseCell(torch.nn.Module):
     KIND = None
     OUT_PER_BIN = None
 
+    HIDDEN_BIAS = False
+
     def __init__(self, flow_size, pass_through_size, n_bins, NN_layers):
         super().__init__()
         self.pass_through_size = pass_through_size
@@ -51,7 +54,7 @@ class _PiecewiseCell(torch.nn.Module):
         self.n_bins = n_bins
         out = self.outputs_per_column()
         sizes = list(NN_layers) + [self.transform_size * out]
-        self.NN = _conditioner(pass_through_size, sizes, (self.transform_size, out))
+        self.NN = _conditioner(pass_through_size, sizes, self.reshape_args(out), self.HIDDEN_BIAS)
         self.hidden_widths = [int(s) for s in sizes[:-1]] if len(sizes) > 1 else [int(sizes[0])]
         self._flat = None
         self._running = None
@@ -60,6 +63,9 @@ class _PiecewiseCell(torch.nn.Module):
 
     def outputs_per_column(self):
         raise NotImplementedError
+
+    def reshape_args(self, out):
+        return (self.transform_size, out)
 
     def _own_engine(self):
         if self._engine is None:
@@ -102,3 +108,20 @@ class PWQuad(_PiecewiseCell):
 
     def outputs_per_column(self):
         return 2 * self.n_bins + 1
+
+
+class AffineCoupling(_PiecewiseCell):
+    """Affine coupling cell (coupling_cells.py:6-70): y = atan(20 exp(z0) x + relu(z1)) / (pi/2), conditioner with
+    biased hidden Linears and a Reshape(2, T) head.  Same constructor as the reference (no n_bins)."""
+    KIND = _lib.NIS_AFFINE
+    HIDDEN_BIAS = True
+
+    def __init__(self, flow_size, pass_through_size, NN_layers):
+        super().__init__(flow_size, pass_through_size, 0, NN_layers)
+        del self.n_bins                                       # the reference cell has no such attribute
+
+    def outputs_per_column(self):
+        return 2
+
+    def reshape_args(self, out):
+        return (2, self.transform_size)

@@ -24,7 +24,7 @@ import torch
 
 from .. import _lib
 from ..flow import moments as hip_moments, moments_of
-from .layers.coupling_cells import PWLin, PWQuad
+from .layers.coupling_cells import AffineCoupling, PWLin, PWQuad
 from .layers.layers import AddJacobian, DeMaskLayer, MaskLayer, RollLayer
 from .sequential import FlowSequential
 
@@ -396,6 +396,23 @@ class BasicManager(ModelAPI):
                 XJ = model(self.format_input(w, dev)).detach()
                 out[i] = hip_moments(f(XJ[:, :-1]), XJ[:, -1])
         return out
+
+
+class AffineManager(BasicManager):
+    """Affine coupling cells with cyclic rolls (manager.py:411-453).  As in PWLinManager every roll is registered under
+    the name "roll", so one RollLayer (after cell 0) survives.  The reference never casts this model to float64 while
+    AddJacobian promotes the input, so its own warm-up forward raises "mixed dtype"; like PWLinManager's counterpart
+     this build casts to float64 -- recorded deviation."""
+
+    format_input = AddJacobian()
+
+    def create_model(self, n_pass_through, n_cells, NN, roll_step):
+        self._model = FlowSequential()
+        for i_cell in range(n_cells):
+            self._model.add_module(str(i_cell), AffineCoupling(flow_size=self.n_flow, pass_through_size=n_pass_through,
+                                                               NN_layers=NN))
+            self._model.add_module("roll", RollLayer(roll_step))
+        self._finish_model(0)
 
 
 class PWLinManager(BasicManager):

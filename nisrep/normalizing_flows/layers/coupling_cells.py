@@ -1,1 +1,1 @@
-from nf_amd.normalizing_flows.layers.coupling_cells import PWLin, PWQuad, RectNN  # noqa: F401
+from nf_amd.normalizing_flows.layers.coupling_cells import AffineCoupling, PWLin, PWQuad, RectNN  # noqa: F401

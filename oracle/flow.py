@@ -3,9 +3,11 @@
 Reference files restated (paths relative to /root/reference/nisrep/normalizing_flows):
   layers/coupling_cells.py:73-142   PWLin      -> pwlin_cell
   layers/coupling_cells.py:144-228  PWQuad     -> pwquad_cell
+  layers/coupling_cells.py:6-70     AffineCoupling -> affine_from_Z (conditioner with hidden-layer biases :26-40)
   layers/coupling_cells.py:230-254  RectNN     -> conditioner  (same stack inline in PWLin :84-104)
   layers/layers.py:6-51,66-91       Mask/DeMask/AddJacobian/Roll -> plan steps in model_forward
   manager.py:474-499, 518-600       create_model topology -> plan_pwlin / plan_pwquad
+  manager.py:428-453                AffineManager.create_model -> plan_affine
   manager.py:380-405                integrate  -> integrate_combine (+ moments)
 
 Parameters are passed as a dict of NumPy arrays keyed like the reference's
@@ -60,11 +62,14 @@ def batchnorm(h, params, key, train, update=None):
 
 
 def conditioner(xA, params, prefix, train, update=None):
-    """BN(P) -> Linear(no bias) -> BN -> ReLU -> ... -> Linear(+bias)   (coupling_cells.py:236-254)."""
+    """BN(P) -> Linear(no bias) -> BN -> ReLU -> ... -> Linear(+bias)   (coupling_cells.py:236-254).
+    AffineCoupling builds the same stack with biased hidden Linears (coupling_cells.py:26-40)."""
     L = n_hidden_from_params(params, prefix)
     h = batchnorm(xA, params, f"{prefix}.NN.{bn_index(0)}", train, update)
     for l in range(L):
         h = h @ params[f"{prefix}.NN.{lin_index(l)}.weight"].T
+        if f"{prefix}.NN.{lin_index(l)}.bias" in params:
+            h = h + params[f"{prefix}.NN.{lin_index(l)}.bias"]
         h = batchnorm(h, params, f"{prefix}.NN.{bn_index(l + 1)}", train, update)
         h = np.maximum(h, 0.0)
     return h @ params[f"{prefix}.NN.{lin_index(L)}.weight"].T + params[f"{prefix}.NN.{lin_index(L)}.bias"]
@@ -127,12 +132,29 @@ def pwlin_from_Z(xB, jac, Z, K):
     return yB, jac, b
 
 
+def affine_from_Z(xB, jac, Z):
+    """Affine coupling transform (coupling_cells.py:56-68).  Z (N,2,T): row 0 -> scale, row 1 -> shift."""
+    s0 = np.exp(Z[:, 0])                                                   # :56
+    s1 = np.where(Z[:, 1] > 0, Z[:, 1], 0.0)                               # :57
+    u = xB * (20 * s0) + s1                                                # :60
+    diff = 1 / (u ** 2 + 1)                                                # :62
+    yB = np.arctan(u) / (np.pi / 2)                                        # :64
+    jac = jac * np.prod(20 * s0, axis=1) * (1 / (np.pi / 2)) * np.prod(diff, axis=1)   # :68 (2/pi enters ONCE)
+    return yB, jac
+
+
 def cell_forward(x, params, prefix, kind, P, K, train, update=None, want=None):
     """One coupling cell on x = (N, d+1) [d variables | running Jacobian]  (coupling_cells.py:107,159)."""
     d = x.shape[1] - 1
     T = d - P
     xA, xB, jac = x[:, :P], x[:, P:d], x[:, d]
     Z = conditioner(xA, params, prefix, train, update)
+    if kind == "affine":
+        Z = Z.reshape(x.shape[0], 2, T)                                    # Reshape(2, T), coupling_cells.py:44
+        yB, jac = affine_from_Z(xB, jac, Z)
+        if want is not None:
+            want["Z"] = Z
+        return np.concatenate([xA, yB, jac[:, None]], axis=1)
     out = (2 * K + 1) if kind == "pwquad" else K
     Z = Z.reshape(x.shape[0], T, out)                                      # Reshape layer, layers.py:63-64
     if kind == "pwquad":
@@ -202,6 +224,16 @@ def plan_pwlin(d, P, n_cells, K, roll_step):
     steps = []
     for i in range(n_cells):
         steps.append(("cell", str(i), "pwlin", P, K))
+        if i == 0:
+            steps.append(("roll", roll_step))
+    return steps
+
+
+def plan_affine(d, P, n_cells, roll_step):
+    """AffineManager.create_model (manager.py:440-446): like PWLinManager, every roll is registered as "roll"."""
+    steps = []
+    for i in range(n_cells):
+        steps.append(("cell", str(i), "affine", P, 0))
         if i == 0:
             steps.append(("roll", roll_step))
     return steps

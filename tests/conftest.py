@@ -69,3 +69,8 @@ def g_training():
 @pytest.fixture(scope="session")
 def g_rambo():
     return golden("rambo.npz")
+
+
+@pytest.fixture(scope="session")
+def g_affine():
+    return golden("affine.npz")

@@ -17,6 +17,7 @@ Output files (np.savez_compressed, keys are "<case>/<name>"):
     integrate.npz  BasicManager.integrate runs (captured w draws, per-iteration mean/var)
     training.npz   short _train_variance_forward_seq runs (history, grads, returns)
     rambo.npz      FlatInvertiblePhasespace.generateKinematics_batch cases
+    affine.npz     AffineCoupling cells and AffineManager models
 """
 import os
 import sys
@@ -34,8 +35,8 @@ sys.path.insert(0, REF)
 # pdf=None (no lhapdf function is ever called in that case) -> empty stub module.
 sys.modules.setdefault("lhapdf", types.ModuleType("lhapdf"))
 
-from nisrep.normalizing_flows.manager import PWQuadManager, PWLinManager, normal  # noqa: E402
-from nisrep.normalizing_flows.layers.coupling_cells import PWQuad, PWLin  # noqa: E402
+from nisrep.normalizing_flows.manager import PWQuadManager, PWLinManager, AffineManager, normal  # noqa: E402
+from nisrep.normalizing_flows.layers.coupling_cells import PWQuad, PWLin, AffineCoupling  # noqa: E402
 from nisrep.normalizing_flows.layers.layers import AddJacobian  # noqa: E402
 from nisrep.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace  # noqa: E402
 
@@ -334,7 +335,69 @@ def gen_rambo():
     print("rambo.npz:", len(meta), "cases")
 
 
+# --------------------------------------------------------------------------- affine cells / models
+def gen_affine():
+    out, meta = {}, {}
+    shapes = [(2, 1, [3] * 3), (5, 2, [7, 7]), (8, 4, [32] * 3), (6, 5, [4]), (9, 3, [20, 12])]
+    for si, (d, P, NN) in enumerate(shapes):
+        for N in (7, 64, 1024):
+            if N == 1024 and si not in (0, 2):
+                continue
+            for mode in ("train", "eval"):
+                name = f"affine_d{d}_P{P}_N{N}_{mode}"
+                torch.manual_seed(3000 + 13 * si + N)
+                cell = AffineCoupling(d, P, list(NN)).double()
+                randomize(cell, 177 + si, last_scale=1.0)
+                x = torch.rand(N, d + 1, dtype=torch.double)
+                x[:, -1] = 0.5 + torch.rand(N, dtype=torch.double)
+                x[0, P] = 0.0
+                x[1, P] = 1.0
+                put_state(out, name, cell)
+                out[f"{name}/x"] = npy(x)
+                cell.train(mode == "train")
+                zs = []
+                h = cell.NN.register_forward_hook(lambda m, i, o: zs.append(o.detach().clone()))
+                y = cell(x.clone())
+                h.remove()
+                out[f"{name}/y"] = npy(y)
+                if N <= 64:
+                    out[f"{name}/Z"] = npy(zs[0])
+                for k, v in cell.state_dict().items():
+                    if "running" in k or "num_batches" in k:
+                        out[f"{name}/sd_after/{k}"] = npy(v)
+                meta[name] = dict(kind="affine", what="cell", d=d, P=P, NN=list(NN), N=N, mode=mode)
+    models = [dict(d=2, P=1, n_cells=2, NN=[3] * 3, roll=1), dict(d=5, P=2, n_cells=3, NN=[8, 8], roll=2),
+              dict(d=8, P=4, n_cells=4, NN=[32] * 3, roll=4)]
+    for ci, c in enumerate(models):
+        name = f"affine_model_d{c['d']}_c{c['n_cells']}"
+        torch.manual_seed(90 + ci)
+        NF = AffineManager(n_flow=c["d"])
+        try:
+            NF.create_model(c["P"], c["n_cells"], list(c["NN"]), c["roll"])
+        except RuntimeError:
+            # same reference quirk as PWLinManager: the model is never cast to double while AddJacobian promotes the
+            # input to float64, so the warm-up forward raises "mixed dtype"; _model is already assigned.
+            pass
+        NF._model.double()
+        names, passes = topo(NF._model)
+        put_state(out, name, NF._model)
+        N = 257
+        w = torch.rand(N, c["d"], dtype=torch.double)
+        out[f"{name}/w"] = npy(w)
+        NF._model.train()
+        out[f"{name}/XJ_train"] = npy(NF._model(NF.format_input(w, torch.device("cpu"))))
+        for k, v in NF._model.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                out[f"{name}/sd_after/{k}"] = npy(v)
+        NF._model.eval()
+        out[f"{name}/XJ_eval"] = npy(NF._model(NF.format_input(w, torch.device("cpu"))))
+        meta[name] = dict(kind="affine", what="model", children=names, passes=passes, N=N, **c)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "affine.npz"), **out)
+    print("affine.npz:", len(meta), "cases")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cells", "models", "integrate", "training", "rambo"]
+    which = sys.argv[1:] or ["cells", "models", "integrate", "training", "rambo", "affine"]
     for w in which:
         globals()["gen_" + w]()

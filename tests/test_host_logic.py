@@ -131,6 +131,19 @@ def test_product_never_imports_the_oracle():
     assert not bad, bad
 
 
+def test_affine_cell_param_count_matches_abi():
+    from nf_amd.flow import cell_desc, _param_tensors
+    from nf_amd.normalizing_flows.layers.coupling_cells import AffineCoupling
+    cell = AffineCoupling(7, 3, [6, 5])
+    d = cell_desc(cell, list(range(7)))
+    ps, rs, _ = _param_tensors(cell)
+    L = _lib.lib()
+    assert d.kind == _lib.NIS_AFFINE and L.nis_cell_param_count(ctypes.byref(d)) == sum(p.numel() for p in ps) == \
+        sum(p.numel() for p in cell.parameters())
+    assert [tuple(p.shape) for p in ps] == [tuple(p.shape) for p in cell.parameters()]      # blob order == Sequential order
+    assert L.nis_cell_running_count(ctypes.byref(d)) == sum(getattr(bn, n).numel() for bn, n in rs)
+
+
 def test_nisrep_import_paths():
     import importlib
     mgr = importlib.import_module("nisrep.normalizing_flows.manager")

@@ -131,3 +131,40 @@ def test_camel_known_integral():
     x = rng.random((400000, 2))
     est = oflow.camel(x).mean()
     assert abs(est - truth) < 5e-3 * truth * 3
+
+
+# --------------------------------------------------------------------------- AffineCoupling
+@pytest.mark.parametrize("case", [c for c in _cases("affine.npz") if "model" not in c])
+def test_affine_cell_matches_reference(case, g_affine):
+    m = g_affine.meta[case]
+    params = {"c." + k: v for k, v in g_affine.sub(case, "sd").items()}
+    x = g_affine.get(case, "x")
+    want, upd = {}, {}
+    y = oflow.cell_forward(x, params, "c", "affine", m["P"], 0, m["mode"] == "train", upd, want)
+    np.testing.assert_allclose(y, g_affine.get(case, "y"), rtol=RTOL, atol=1e-14)
+    if g_affine.has(case, "Z"):
+        np.testing.assert_allclose(want["Z"], g_affine.get(case, "Z"), rtol=1e-10, atol=1e-12)
+    for k, v in g_affine.sub(case, "sd_after").items():
+        if m["mode"] == "train":
+            np.testing.assert_allclose(upd["c." + k], v, rtol=1e-12, atol=1e-15)
+        else:
+            np.testing.assert_array_equal(params["c." + k], v)
+
+
+@pytest.mark.parametrize("case", [c for c in _cases("affine.npz") if "model" in c])
+def test_affine_model_topology_and_forward(case, g_affine):
+    m = g_affine.meta[case]
+    steps = oflow.plan_affine(m["d"], m["P"], m["n_cells"], m["roll"])
+    names = [f"{st[1]}:AffineCoupling" if st[0] == "cell" else "roll:RollLayer" for st in steps]
+    assert names == m["children"] and [st[3] for st in steps if st[0] == "cell"] == m["passes"]
+    params = g_affine.sub(case, "sd")
+    w = g_affine.get(case, "w")
+    upd = {}
+    XJ = oflow.model_forward(w, params, steps, True, upd)
+    np.testing.assert_allclose(XJ, g_affine.get(case, "XJ_train"), rtol=1e-10, atol=1e-13)
+    for k, v in g_affine.sub(case, "sd_after").items():
+        np.testing.assert_allclose(upd[k], v, rtol=1e-11, atol=1e-14)
+    params2 = dict(params)
+    params2.update(upd)
+    XJe = oflow.model_forward(w, params2, steps, False)
+    np.testing.assert_allclose(XJe, g_affine.get(case, "XJ_eval"), rtol=1e-10, atol=1e-13)
