@@ -2,7 +2,7 @@
 """bench.py -- headline metric of BASELINE.json: MC samples/sec at batch 1e6 (camel-2D through the flow;
 2->4 RAMBO) on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -200,8 +200,8 @@ def cpu_baseline(NF):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--roofline-kernel", default="apply", choices=["apply", "stats", "ingest", "integrand"])
     ap.add_argument("--group", type=int, default=10, help="steps fused into one launch set (independent BN batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
