@@ -116,6 +116,7 @@ def bench_flow(args, rank, ws, dev):
     var = mom[:, 2] / (mom[:, 0] - 1)
     sig = float(np.sum(mom[:, 1] / var) / np.sum(1 / var))
     sig_err = float(np.sqrt(1 / np.sum(1 / var)) / np.sqrt(mom[0, 0] * args.steps))
+    sig_mc = float(1 / np.sqrt(np.sum(mom[:, 0] / var)))
     # algorithmic bytes of the dominant kernel (DESIGN.md "Kernels"): the cell-apply kernel reads the
     # pass-through, transformed and Jacobian columns and writes the transformed + Jacobian columns:
     # 8*((d+1) + (T+1)) B/sample; the first cell does not read J (it is 1): 8*(d + T+1).
@@ -139,7 +140,7 @@ def bench_flow(args, rank, ws, dev):
                     args.roofline_kernel, ""), gmean),
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches": kern_n, "steps_per_launch": gmean,
                 "algorithmic_bytes_per_launch": per_launch}
-    return dict(dt=dt, samples=BATCH * args.steps * ws, sig=sig, sig_err=sig_err, roofline=roof, NF=NF)
+    return dict(dt=dt, samples=BATCH * args.steps * ws, sig=sig, sig_err=sig_err, sig_mc=sig_mc, roofline=roof, NF=NF)
 
 
 def bench_rambo(args, rank, ws, dev):
@@ -232,7 +233,8 @@ def main():
         "config": {"workload": "C2: 2-D camel, PWQuad 2 cells, n_bins 4, NN [3,3,3], train-mode BN, fused camel*J + moments",
                    "batch_per_gpu": BATCH, "global_batch": BATCH * ws, "parallelism": f"sample-shard x{ws}",
                    "collective": "one all-reduce of (steps,4) moment records"},
-        "integral": {"value": flow["sig"], "sigma": flow["sig_err"], "truth": 0.232279},
+        "integral": {"value": flow["sig"], "sigma": flow["sig_err"], "sigma_mc": flow["sig_mc"], "truth": 0.2323235706,
+                     "note": "sigma = the reference's formula (manager.py:403); sigma_mc = 1/sqrt(sum_i N/var_i)"},
         "roofline": flow["roofline"],
         "rambo": rambo,
     }

@@ -810,6 +810,15 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     c.coef_gs = train ? (cd.n_hidden + 1) * 2 * L.WM : 0;     // eval: every batch shares the running-stat coefficients
     c.plane_gs = plane_gs;
     c.derive1 = (train && cd.P == 1 && !env_int("NIS_NO_DERIVE1", 0)) ? 1 : 0;
+    // single pass-through column on the fp64 VALU kernels: BN_0, Linear_0 and BN_1 collapse into one affine map of x
+    // (needs the layer-1 statistics launch to be gone: train mode with derive1, or eval mode)
+    c.fold = (cd.P == 1 && !mfma && (c.derive1 || !train) && !env_int("NIS_NO_FOLD", 0)) ? 1 : 0;
+    c.wx = 0;
+    if (L.WM == 4 && cd.P <= 3 && !env_int("NIS_NO_WX", 0)) {
+      bool all3 = true;
+      for (int l = 0; l < cd.n_hidden; ++l) all3 = all3 && cd.width[l] <= 3;
+      if (all3) c.wx = 3;
+    }
     c.out_off = o.hist ? plane_gs : 0;
     c.bnsave = (o.hist && o.bnsave && train) ? o.bnsave + bn_off : nullptr;
     bn_off += (size_t)(cd.n_hidden + 1) * 4 * L.WM;

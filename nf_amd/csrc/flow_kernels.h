@@ -186,14 +186,17 @@ __device__ __forceinline__ void emit_records(const double (&S1)[F], const double
   }
 }
 
-// h <- W(WMxWM, row-major, zero padded) * a
-template <int WM>
+// h <- W(WMxWM, row-major, zero padded) * a.  WX < WM: every layer is known to be at most WX wide (the padding rows and
+// columns are zero), so only the WX x WX block is multiplied.
+template <int WM, int WX = WM>
 __device__ __forceinline__ void dense(nis_cptr W, const double (&a)[WM], double (&b)[WM]) {
 #pragma unroll
   for (int j = 0; j < WM; ++j) {
     double acc = 0.0;
+    if (j < WX) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) acc = fma(W[j * WM + i], a[i], acc);
+      for (int i = 0; i < WX; ++i) acc = fma(W[j * WM + i], a[i], acc);
+    }
     b[j] = acc;
   }
 }
@@ -206,19 +209,29 @@ __device__ __forceinline__ void load_passthrough(const CellK& c, const double* p
 
 // Conditioner up to (and excluding) BN layer `upto`: leaves the pre-BN activations of that layer in `a`
 // (upto == 0: the raw pass-through block).  With `finish`, BN_upto (+ReLU) is applied as well.
-template <int WM>
-__device__ __forceinline__ void hidden_stack(const CellK& c, const double* lds_coef, int upto, bool finish, double (&a)[WM]) {
+// `fold` (single pass-through column, see fold_coefs): BN_0, Linear_0 and BN_1 are one affine map of x that sits in
+// BN_1's coefficient slot, so the stack starts at layer 1 with x broadcast to every feature.
+template <int WM, int WX = WM>
+__device__ __forceinline__ void hidden_stack(const CellK& c, const double* lds_coef, int upto, bool finish, double (&a)[WM],
+                                             bool fold = false) {
   double b[WM];
   nis_cptr wp = as_const(c.wp);
-  for (int l = 0; l < upto; ++l) {
+  int l = 0;
+  if (fold && upto >= 1) {
+    const double x = a[0];
+#pragma unroll
+    for (int j = 0; j < WM; ++j) a[j] = j < WX ? x : 0.0;
+    l = 1;
+  }
+  for (; l < upto; ++l) {
     const double* sc = lds_coef + (l * 2 + 0) * WM;
     const double* sh = lds_coef + (l * 2 + 1) * WM;
 #pragma unroll
-    for (int j = 0; j < WM; ++j) {
+    for (int j = 0; j < WX; ++j) {
       const double v = fma(a[j], sc[j], sh[j]);
       a[j] = (l == 0) ? v : fmax(v, 0.0);                 // BN_0 has no ReLU behind it (coupling_cells.py:236-239)
     }
-    dense<WM>(wp + (size_t)l * WM * WM, a, b);
+    dense<WM, WX>(wp + (size_t)l * WM * WM, a, b);
 #pragma unroll
     for (int j = 0; j < WM; ++j) a[j] = b[j];
   }
@@ -226,16 +239,38 @@ __device__ __forceinline__ void hidden_stack(const CellK& c, const double* lds_c
     const double* sc = lds_coef + (upto * 2 + 0) * WM;
     const double* sh = lds_coef + (upto * 2 + 1) * WM;
 #pragma unroll
-    for (int j = 0; j < WM; ++j) {
+    for (int j = 0; j < WX; ++j) {
       const double v = fma(a[j], sc[j], sh[j]);
       a[j] = (upto == 0) ? v : fmax(v, 0.0);
     }
   }
 }
 
+// P == 1: h1_j = W0[j][0] (sc0 x + sh0), so BN_1(h1)_j = A_j x + B_j with A_j = sc1_j W0[j][0] sc0 and
+// B_j = sc1_j W0[j][0] sh0 + sh1_j.  The pair replaces BN_1's (scale, shift) in the LDS copy of the coefficients
+// (the published coefficients and the saved statistics stay unfolded); hidden_stack(.., fold = true) then skips
+// BN_0 and Linear_0.  Called by every thread after load_coefs; `upto` = layers present in lds_coef.
+template <int WM>
+__device__ __forceinline__ void fold_coefs(const CellK& c, double* lds_coef, int upto) {
+  if (!c.fold || upto < 2) return;
+  double A = 0.0, B = 0.0;
+  const int j = threadIdx.x;
+  if (j < WM) {
+    const double w = c.wp[(size_t)j * WM], sc1 = lds_coef[2 * WM + j];
+    A = sc1 * (w * lds_coef[0]);
+    B = fma(sc1, w * lds_coef[WM], lds_coef[3 * WM + j]);
+  }
+  __syncthreads();
+  if (j < WM) {
+    lds_coef[2 * WM + j] = A;
+    lds_coef[3 * WM + j] = B;
+  }
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Batch statistics of BN layer `layer` (0..L): partial (count, mean, M2) per workgroup & feature.
-template <int WM, int TPB>
+template <int WM, int TPB, int WX = WM>
 __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restrict__ planes, long ld, long N, int layer) {
   constexpr int NW = TPB / NIS_WAVE;
   __shared__ double lds_coef[NIS_MAX_HIDDEN * 2 * WM];
@@ -247,6 +282,8 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
   planes += (size_t)g * c.plane_gs;
   // G == 1: the previous layer's records are merged here; G > 1: k_bn_finalize already published the coefficients
   load_coefs<WM, TPB>(c, g, layer, c.G == 1 ? cellk_fresh(c, layer) : -1, blockIdx.x == 0, lds_coef, red);
+  fold_coefs<WM>(c, lds_coef, layer);
+  const bool fold = c.fold && layer >= 2;
 
   double S1[WM], S2[WM];
 #pragma unroll
@@ -277,7 +314,7 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
         } else {
           load_passthrough<WM>(c, planes, ld, i, a);
         }
-        hidden_stack<WM>(c, lds_coef, layer, false, a);
+        hidden_stack<WM, WX>(c, lds_coef, layer, false, a, fold);
         if (firstit) {                  // wave-uniform shift = lane 0's first value (lane 0 owns the lowest index)
 #pragma unroll
           for (int j = 0; j < WM; ++j) {
@@ -287,7 +324,7 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
           firstit = false;
         }
 #pragma unroll
-        for (int j = 0; j < WM; ++j) {
+        for (int j = 0; j < WX; ++j) {
           const double t = a[j] - wshift[wave][j];
           S1[j] += t;
           S2[j] = fma(t, t, S2[j]);
@@ -328,12 +365,12 @@ __global__ void k_running_update(CellK c) {
 
 // ---------------------------------------------------------------------------------------------
 // z = bias[row] + <wlast[row,:], a>
-template <int WM>
+template <int WM, int WX = WM>
 __device__ __forceinline__ double last_dot(nis_cptr wl, nis_cptr bias, int row, const double (&a)[WM]) {
   double acc = bias[row];
   nis_cptr w = wl + (size_t)row * WM;
 #pragma unroll
-  for (int i = 0; i < WM; ++i) acc = fma(w[i], a[i], acc);
+  for (int i = 0; i < WX; ++i) acc = fma(w[i], a[i], acc);
   return acc;
 }
 
@@ -443,7 +480,7 @@ __device__ __forceinline__ double pwquad_column(double xb, int Krt, double (&V)[
 // Full cell: conditioner with finalised BN + bijector, in place on the transformed planes.  Optional riders:
 //   * BN_0 records of the NEXT cell (its pass-through columns are all in this thread's registers),
 //   * a built-in integrand f(X)*J with its moment records (last cell), optionally without storing X, J.
-template <int KIND, int WM, int KM, bool KEXACT>
+template <int KIND, int WM, int KM, bool KEXACT, int WX = WM>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                         int* __restrict__ bins_out, FuseF fz) {
   constexpr int NW = NIS_TPB / NIS_WAVE;
@@ -459,6 +496,8 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   planes += (size_t)g * c.plane_gs;
   nis_exp_init(etab);
   load_coefs<WM, NIS_TPB>(c, g, c.L + 1, (bn_train && c.G == 1) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red);
+  fold_coefs<WM>(c, lds_coef, c.L + 1);
+  const bool fold = c.fold != 0;
   nis_cptr wl = as_const(c.wlast);
   nis_cptr bias = as_const(c.bias);
   constexpr bool RIDERS = WM <= 8;          // wide conditioners keep their registers for the GEMV
@@ -499,7 +538,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
           if (p < c.P) nsum += ((a[p] - fz.p[0]) * (a[p] - fz.p[0])) / (2 * fz.p[1] * fz.p[1]);
       }
     }
-    hidden_stack<WM>(c, lds_coef, c.L, true, a);
+    hidden_stack<WM, WX>(c, lds_coef, c.L, true, a, fold);
     double jprod = 1.0;
     for (int t = 0; t < c.T; ++t) {
       double* col = planes + (size_t)c.in_plane[c.P + t] * ld;
@@ -511,16 +550,16 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
         double V[KM + 1], W[KM];
 #pragma unroll
         for (int k = 0; k < KM + 1; ++k)
-          V[k] = (KEXACT || k <= c.K) ? nis_exp(last_dot<WM>(wl, bias, row0 + k, a), etab) : 0.0;                   // :173,189
+          V[k] = (KEXACT || k <= c.K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + k, a), etab) : 0.0;                   // :173,189
         const int Kq = KEXACT ? KM : c.K;
 #pragma unroll
         for (int k = 0; k < KM; ++k)
-          W[k] = (KEXACT || k < c.K) ? nis_exp(last_dot<WM>(wl, bias, row0 + Kq + 1 + k, a), etab) : 0.0;             // :175,178
+          W[k] = (KEXACT || k < c.K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + Kq + 1 + k, a), etab) : 0.0;             // :175,178
         y = pwquad_column<KM, KEXACT>(xb, c.K, V, W, &jf, &bin);
       } else if (KIND == NIS_AFFINE) {
         // AffineCoupling (coupling_cells.py:56-68): rows [scale | shift][T];  y = atan(20 e^z0 x + relu(z1)) / (pi/2)
-        const double s0 = 20.0 * nis_exp(last_dot<WM>(wl, bias, t, a), etab);
-        const double z1 = last_dot<WM>(wl, bias, c.T + t, a);
+        const double s0 = 20.0 * nis_exp(last_dot<WM, WX>(wl, bias, t, a), etab);
+        const double z1 = last_dot<WM, WX>(wl, bias, c.T + t, a);
         const double u = xb * s0 + (z1 > 0.0 ? z1 : 0.0);
         y = atan(u) / (M_PI / 2);
         jf = s0 * (1.0 / (u * u + 1.0));
@@ -534,7 +573,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
         bin = (int)bf;
         double tot = 0.0, below = 0.0, qb = 0.0;
         for (int k = 0; k < c.K; ++k) {
-          const double e = nis_exp(last_dot<WM>(wl, bias, row0 + k, a), etab);                 // :115
+          const double e = nis_exp(last_dot<WM, WX>(wl, bias, row0 + k, a), etab);                 // :115
           if (k == bin) {
             below = tot;
             qb = e;

@@ -10,6 +10,12 @@
 template <>
 hipError_t launch_stats<NIS_WM>(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s) {
   constexpr int TPB = nis_stats_tpb(NIS_WM);
+#if NIS_WM == 4
+  if (c.wx == 3) {                       // every layer at most 3 wide (README / C1 / C2 nets): 3x3 blocks instead of 4x4
+    hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB, 3>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N, layer);
+    return hipGetLastError();
+  }
+#endif
   hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N, layer);
   return hipGetLastError();
 }
@@ -88,6 +94,27 @@ int apply_blocks_per_cu<NIS_WM>(int kind, int km) {
 template <>
 hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz,
                                 int grid, hipStream_t s) {
+#if NIS_WM == 4
+#define NIS_APPLY3(KIND, KMV, EX) \
+  hipLaunchKernelGGL((k_cell_apply<KIND, NIS_WM, KMV, EX, 3>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
+  if (c.wx == 3) {
+    if (c.kind == NIS_PWLIN) {
+      NIS_APPLY3(NIS_PWLIN, 4, false);
+      return hipGetLastError();
+    }
+    if (c.kind == NIS_PWQUAD) {
+      switch (km) {
+        case 4: NIS_APPLY3(NIS_PWQUAD, 4, false); return hipGetLastError();
+        case 8: NIS_APPLY3(NIS_PWQUAD, 8, false); return hipGetLastError();
+        case 16: NIS_APPLY3(NIS_PWQUAD, 16, false); return hipGetLastError();
+        case -4: NIS_APPLY3(NIS_PWQUAD, 4, true); return hipGetLastError();
+        case -8: NIS_APPLY3(NIS_PWQUAD, 8, true); return hipGetLastError();
+        case -16: NIS_APPLY3(NIS_PWQUAD, 16, true); return hipGetLastError();
+        default: break;                   // other bin counts: generic 4-wide kernel
+      }
+    }
+  }
+#endif
   if (c.kind == NIS_PWLIN) {
     NIS_APPLY(NIS_PWLIN, 4, false);
   } else if (c.kind == NIS_AFFINE) {

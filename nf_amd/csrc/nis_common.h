@@ -136,6 +136,8 @@ struct CellK {
   int derive1;                           // 1 (P == 1): BN_1's batch statistics follow analytically from BN_0's
                                          //   (h1_j = W0_j0 * BN_0(x) is affine in the single pass-through column),
                                          //   so the layer-1 statistics launch is skipped
+  int fold;                              // 1 (P == 1, fp64 VALU kernels): BN_0, Linear_0, BN_1 evaluated as ONE affine map of x (fold_coefs)
+  int wx;                                // exact common width of the hidden layers when a specialised kernel exists (WM = 4: 3), else 0
   long out_off;                          // doubles from a cell's input planes to its output planes (0: in place)
   double* bnsave;                        // (L+1) x 4 x WM: scale | shift | batch mean | 1/sqrt(var+eps)  (may be null)
 };

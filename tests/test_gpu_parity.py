@@ -500,7 +500,7 @@ def test_c2_full_batch_properties():
     assert merged[3] == t2n(whole)[3]
     # camel integral over the unit square (truncated Gaussians) = 0.2323 within MC error
     mean, var = merged[1], merged[2] / (merged[0] - 1)
-    assert abs(mean - 0.23228) < 5 * np.sqrt(var / 1e6)
+    assert abs(mean - 0.2323235706) < 5 * np.sqrt(var / 1e6)       # 2 (s sqrt(pi)/2 (erf(1.25) + erf(3.75)))^2, s = 0.2
 
 
 # ------------------------------------------------------------------------------ edge cases
