@@ -607,11 +607,12 @@ static int device_cus() {
   return n;
 }
 
-// x extent of a launch over G batches: one resident wave of workgroups (blocks_per_cu * CUs) shared by the
-// batches, never more workgroups than the batch has chunks of `tpb` samples, never more than NIS_MAXB records.
+// x extent of a launch over G batches: blocks_per_cu * CUs workgroups shared by the batches (rounded DOWN: one
+// workgroup more than a multiple of the CU count costs a whole extra round), never more workgroups than the batch has
+// chunks of `tpb` samples, never more than NIS_MAXB records.
 static int grid_for(int blocks_per_cu, int G, int64_t N, int tpb) {
   const int64_t resident = (int64_t)blocks_per_cu * device_cus();
-  int64_t gx = (resident + G - 1) / G;
+  int64_t gx = resident / G;
   gx = std::min<int64_t>(gx, (N + tpb - 1) / tpb);
   gx = std::min<int64_t>(gx, NIS_MAXB);
   return (int)std::max<int64_t>(1, gx);
@@ -622,11 +623,19 @@ static int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
+// exact common width of the hidden layers when a specialised instantiation exists (WM = 4: 3-wide nets), else 0
+static int cell_wx(const nis_cell_desc& cd, int WM) {
+  if (WM != 4 || cd.P > 3 || env_int("NIS_NO_WX", 0)) return 0;
+  for (int l = 0; l < cd.n_hidden; ++l)
+    if (cd.width[l] > 3) return 0;
+  return 3;
+}
+
 template <int WM>
-static void cell_grids(int kind, int km, int G, int64_t N, int* gs, int* ga) {
+static void cell_grids(int kind, int km, int wx, int G, int64_t N, int* gs, int* ga) {
   static const int bs = env_int("NIS_STATS_BPC", 0), ba = env_int("NIS_APPLY_BPC", 0);   // tuning overrides
-  *gs = grid_for(bs > 0 ? bs : stats_blocks_per_cu<WM>(), G, N, nis_stats_tpb(WM));
-  *ga = grid_for(ba > 0 ? ba : apply_blocks_per_cu<WM>(kind, km), G, N, NIS_TPB);
+  *gs = grid_for(bs > 0 ? bs : stats_blocks_per_cu<WM>(wx), G, N, nis_stats_tpb(WM));
+  *ga = grid_for(ba > 0 ? ba : apply_blocks_per_cu<WM>(kind, km, wx), G, N, NIS_TPB);
 }
 
 struct RunOpts {
@@ -758,11 +767,11 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     if (!params[ci] || !running[ci]) return NIS_E_ARG;
     int grid_stats = 1, grid_apply = 1;
     switch (L.WM) {
-      case 4: cell_grids<4>(cd.kind, L.KM, G, N, &grid_stats, &grid_apply); break;
-      case 8: cell_grids<8>(cd.kind, L.KM, G, N, &grid_stats, &grid_apply); break;
-      case 16: cell_grids<16>(cd.kind, L.KM, G, N, &grid_stats, &grid_apply); break;
-      case 32: cell_grids<32>(cd.kind, L.KM, G, N, &grid_stats, &grid_apply); break;
-      default: cell_grids<64>(cd.kind, L.KM, G, N, &grid_stats, &grid_apply); break;
+      case 4: cell_grids<4>(cd.kind, L.KM, cell_wx(cd, L.WM), G, N, &grid_stats, &grid_apply); break;
+      case 8: cell_grids<8>(cd.kind, L.KM, 0, G, N, &grid_stats, &grid_apply); break;
+      case 16: cell_grids<16>(cd.kind, L.KM, 0, G, N, &grid_stats, &grid_apply); break;
+      case 32: cell_grids<32>(cd.kind, L.KM, 0, G, N, &grid_stats, &grid_apply); break;
+      default: cell_grids<64>(cd.kind, L.KM, 0, G, N, &grid_stats, &grid_apply); break;
     }
     CellK c;
     memset(&c, 0, sizeof(c));
@@ -813,12 +822,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     // single pass-through column on the fp64 VALU kernels: BN_0, Linear_0 and BN_1 collapse into one affine map of x
     // (needs the layer-1 statistics launch to be gone: train mode with derive1, or eval mode)
     c.fold = (cd.P == 1 && !mfma && (c.derive1 || !train) && !env_int("NIS_NO_FOLD", 0)) ? 1 : 0;
-    c.wx = 0;
-    if (L.WM == 4 && cd.P <= 3 && !env_int("NIS_NO_WX", 0)) {
-      bool all3 = true;
-      for (int l = 0; l < cd.n_hidden; ++l) all3 = all3 && cd.width[l] <= 3;
-      if (all3) c.wx = 3;
-    }
+    c.wx = cell_wx(cd, L.WM);
     c.out_off = o.hist ? plane_gs : 0;
     c.bnsave = (o.hist && o.bnsave && train) ? o.bnsave + bn_off : nullptr;
     bn_off += (size_t)(cd.n_hidden + 1) * 4 * L.WM;

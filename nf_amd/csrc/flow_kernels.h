@@ -651,9 +651,9 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
 // *_blocks_per_cu: resident workgroups per CU of the kernel (occupancy query, cached) -> grids are sized to ONE
 // resident wave of workgroups so that every thread amortises the prologue / epilogue over many samples.
 template <int WM>
-int stats_blocks_per_cu();
+int stats_blocks_per_cu(int wx);
 template <int WM>
-int apply_blocks_per_cu(int kind, int km);
+int apply_blocks_per_cu(int kind, int km, int wx);
 template <int WM>
 hipError_t launch_stats(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s);
 template <int WM>
@@ -680,9 +680,9 @@ hipError_t launch_apply_mfma(const CellK& c, const MfmaW& w, double* planes, lon
                              hipStream_t s);
 #define NIS_DECL_WM(W)                                                                                                      \
   template <>                                                                                                               \
-  int stats_blocks_per_cu<W>();                                                                                             \
+  int stats_blocks_per_cu<W>(int wx);                                                                                          \
   template <>                                                                                                               \
-  int apply_blocks_per_cu<W>(int kind, int km);                                                                             \
+  int apply_blocks_per_cu<W>(int kind, int km, int wx);                                                                          \
   template <>                                                                                                               \
   hipError_t launch_stats<W>(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s);    \
   template <>                                                                                                               \

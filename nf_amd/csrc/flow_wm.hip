@@ -1,6 +1,9 @@
 // One translation unit per conditioner register width: compiled with -DNIS_WM={4,8,16,32,64}
 // so the five widths build in parallel.  Instantiates the statistics kernel and every
 // (cell kind, bin-array size) variant of the apply kernel for that width.
+#include <cstdio>
+#include <cstdlib>
+
 #include "flow_kernels.h"
 
 #ifndef NIS_WM
@@ -32,23 +35,36 @@ hipError_t launch_running_update<NIS_WM>(const CellK& c, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <>
-int stats_blocks_per_cu<NIS_WM>() {
-  static int v = -1;
-  if (v < 0) {
-    constexpr int TPB = nis_stats_tpb(NIS_WM);
-    hipFuncAttributes at;
-    int n = 1;
-    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(k_bn_stats<NIS_WM, TPB>)) == hipSuccess && at.numRegs > 0) {
-      const int alloc = (at.numRegs + 7) / 8 * 8;
-      int waves = 512 / alloc;
-      waves = waves < 1 ? 1 : waves > 8 ? 8 : waves;
-      n = waves * 4 * 64 / TPB;                 // waves/SIMD * 4 SIMDs * 64 lanes / workgroup size
-      if (n < 1) n = 1;
-    }
-    v = n;
+template <typename K>
+static int stats_occ_of(K kern) {
+  constexpr int TPB = nis_stats_tpb(NIS_WM);
+  hipFuncAttributes at;
+  int n = 1;
+  if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(kern)) == hipSuccess && at.numRegs > 0) {
+    const int alloc = (at.numRegs + 7) / 8 * 8;
+    int waves = 512 / alloc;
+    waves = waves < 1 ? 1 : waves > 8 ? 8 : waves;
+    n = (waves * 4 * 64 + TPB - 1) / TPB;     // waves/SIMD * 4 SIMDs * 64 lanes / workgroup size, rounded up (measured: 2 beats 1)
+    const int by_lds = at.sharedSizeBytes > 0 ? (int)(160 * 1024 / at.sharedSizeBytes) : 8;
+    n = n < by_lds ? n : by_lds;
+    if (n < 1) n = 1;
+    if (getenv("NIS_DEBUG_OCC")) fprintf(stderr, "[nis] k_bn_stats<%d>: numRegs %d lds %zu -> %d workgroups/CU\n", NIS_WM, at.numRegs, (size_t)at.sharedSizeBytes, n);
   }
-  return v;
+  return n;
+}
+
+template <>
+int stats_blocks_per_cu<NIS_WM>(int wx) {
+  static int v[2] = {-1, -1};
+  constexpr int TPB = nis_stats_tpb(NIS_WM);
+#if NIS_WM == 4
+  if (wx == 3) {
+    if (v[1] < 0) v[1] = stats_occ_of(k_bn_stats<NIS_WM, TPB, 3>);
+    return v[1];
+  }
+#endif
+  if (v[0] < 0) v[0] = stats_occ_of(k_bn_stats<NIS_WM, TPB>);
+  return v[0];
 }
 
 // resident 256-thread workgroups per CU from the kernel's register allocation (the occupancy API
@@ -61,14 +77,38 @@ static int occ_of(K kern) {
   int waves = 512 / alloc;                       // waves per SIMD; a 256-thread workgroup puts one wave on each SIMD
   waves = waves < 1 ? 1 : waves > 8 ? 8 : waves;
   int by_lds = at.sharedSizeBytes > 0 ? (int)(160 * 1024 / at.sharedSizeBytes) : 8;
-  return waves < by_lds ? waves : (by_lds < 1 ? 1 : by_lds);
+  int n = waves < by_lds ? waves : (by_lds < 1 ? 1 : by_lds);
+  // These kernels are fp64-issue bound: a CU works off its workgroups at the same rate with 2 or with 6 resident waves
+  // per SIMD, so MORE and smaller workgroups than fit at once only improve the balance between CUs (measured optimum
+  // for the C2 apply kernel: 5 per CU, 212 us vs 277 us at the 3 that are resident).
+  if (n < 5) n = 5;
+  if (getenv("NIS_DEBUG_OCC")) fprintf(stderr, "[nis] apply kernel (WM %d): numRegs %d lds %zu -> %d workgroups/CU\n", NIS_WM, at.numRegs, (size_t)at.sharedSizeBytes, n);
+  return n;
 }
 
 template <>
-int apply_blocks_per_cu<NIS_WM>(int kind, int km) {
+int apply_blocks_per_cu<NIS_WM>(int kind, int km, int wx) {
   static int cache[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
   const bool exact = km < 0;
   const int kk = exact ? -km : km;
+#if NIS_WM == 4
+  if (wx == 3 && kk <= 16 && kind != NIS_AFFINE) {           // the 3-wide instantiations have their own register budget
+    static int c3[7] = {-1, -1, -1, -1, -1, -1, -1};
+    const int s3 = kind == NIS_PWLIN ? 0 : (kk == 4 ? 1 : kk == 8 ? 2 : 3) + (exact ? 3 : 0);
+    if (c3[s3] < 0) {
+      switch (s3) {
+        case 0: c3[s3] = occ_of(k_cell_apply<NIS_PWLIN, NIS_WM, 4, false, 3>); break;
+        case 1: c3[s3] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 4, false, 3>); break;
+        case 2: c3[s3] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 8, false, 3>); break;
+        case 3: c3[s3] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 16, false, 3>); break;
+        case 4: c3[s3] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 4, true, 3>); break;
+        case 5: c3[s3] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 8, true, 3>); break;
+        default: c3[s3] = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, 16, true, 3>); break;
+      }
+    }
+    return c3[s3];
+  }
+#endif
   const int slot = kind == NIS_PWLIN ? 0 : kind == NIS_AFFINE ? 9 : (kk == 4 ? 1 : kk == 8 ? 2 : kk == 16 ? 3 : 4) + (exact ? 4 : 0);
   if (cache[slot] < 0) {
     switch (slot) {
