@@ -369,6 +369,59 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest(const TIN* __restrict__ w, l
   if (st.P > 0) emit_records<NF, NW>(S1, S2, cnt, wshift, wmom, st.P, st.partials + ((size_t)g * st.maxb + blockIdx.x) * st.wm * 3);
 }
 
+// d == 2 (README / C1 / C2): a row is one 8- or 16-byte vector, so every lane loads its own rows directly (coalesced),
+// four in flight; no LDS transpose, no barriers.
+template <typename TIN>
+__global__ __launch_bounds__(NIS_TPB) void k_ingest2(const TIN* __restrict__ w, long N, double* __restrict__ planes, long ld,
+                                                     IngestStats st) {
+  typedef TIN vec2 __attribute__((ext_vector_type(2)));
+  constexpr int NW = NIS_TPB / NIS_WAVE, NF = 2, U = 4;
+  __shared__ double wshift[NW][NF];
+  __shared__ double wmom[NW][NF][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = blockIdx.y;
+  const vec2* rows = reinterpret_cast<const vec2*>(w + (size_t)g * N * 2);
+  planes += (size_t)g * st.plane_gs;
+  if (blockIdx.x == 0 && g == 0 && threadIdx.x == 0 && st.status) *st.status = 0;
+  double S1[NF] = {0.0, 0.0}, S2[NF] = {0.0, 0.0};
+  double cnt = 0.0;
+  bool firstit = true;
+  const int s0 = st.P > 0 ? st.sel[0] : 0, s1 = st.P > 1 ? st.sel[1] : 0;
+  const long stride = (long)gridDim.x * NIS_TPB;
+  for (long i0 = (long)blockIdx.x * NIS_TPB + threadIdx.x; i0 < N; i0 += U * stride) {
+    vec2 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * stride;
+      r[u] = i < N ? rows[i] : vec2{0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * stride;
+      if (i < N) {
+        const double x0 = (double)r[u].x, x1 = (double)r[u].y;
+        planes[i] = x0;
+        planes[(size_t)ld + i] = x1;
+        if (st.P > 0) {
+          const double v0 = s0 == 0 ? x0 : x1, v1 = s1 == 0 ? x0 : x1;
+          if (firstit) {
+            const double f0 = wave_first(v0), f1 = wave_first(v1);
+            if (lane == 0) wshift[wave][0] = f0, wshift[wave][1] = f1;
+            firstit = false;
+          }
+          const double t0 = v0 - wshift[wave][0], t1 = v1 - wshift[wave][1];
+          S1[0] += t0;
+          S2[0] = fma(t0, t0, S2[0]);
+          S1[1] += t1;
+          S2[1] = fma(t1, t1, S2[1]);
+          cnt += 1.0;
+        }
+      }
+    }
+  }
+  if (st.P > 0) emit_records<NF, NW>(S1, S2, cnt, wshift, wmom, st.P, st.partials + ((size_t)g * st.maxb + blockIdx.x) * st.wm * 3);
+}
+
 // inverse of k_emit: column c of the row-major (N, cols) matrix goes to plane m.col[c]
 __global__ __launch_bounds__(NIS_TPB) void k_scatter_rows(const double* __restrict__ src, long N, int cols, ColMap m,
                                                           double* __restrict__ planes, long ld) {
@@ -747,7 +800,11 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     ist.partials = body + lay[0].off_part;
   }
   nis_prof_mark(NIS_K_INGEST, 1, s);
-  if (w_dtype == NIS_F64)
+  if (wcols == 2 && ist.P <= 2 && w_dtype == NIS_F64)
+    hipLaunchKernelGGL(k_ingest2<double>, dim3(tgrid, G), dim3(NIS_TPB), 0, s, (const double*)w, (long)N, planes, (long)ld, ist);
+  else if (wcols == 2 && ist.P <= 2)
+    hipLaunchKernelGGL(k_ingest2<float>, dim3(tgrid, G), dim3(NIS_TPB), 0, s, (const float*)w, (long)N, planes, (long)ld, ist);
+  else if (w_dtype == NIS_F64)
     hipLaunchKernelGGL(k_ingest<double>, dim3(tgrid, G), dim3(NIS_TPB), tile_bytes, s, (const double*)w, (long)N, wcols, planes, (long)ld,
                        ist);
   else
