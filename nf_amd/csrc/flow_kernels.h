@@ -480,11 +480,16 @@ __device__ __forceinline__ double pwquad_column(double xb, int Krt, double (&V)[
 // Full cell: conditioner with finalised BN + bijector, in place on the transformed planes.  Optional riders:
 //   * BN_0 records of the NEXT cell (its pass-through columns are all in this thread's registers),
 //   * a built-in integrand f(X)*J with its moment records (last cell), optionally without storing X, J.
-template <int KIND, int WM, int KM, bool KEXACT, int WX = WM>
+// SPEC != 0: compile-time copies of the launch's wave-uniform switches for the two cells of a d = 2 chain (P = T = 1,
+// folded conditioner input, in place, no bin output): 1 = inner cell (BN_0 rider of the next cell, planes written),
+// 2 = last cell with the camel integrand fused and nothing stored.  The generic kernel (SPEC 0) carries every switch
+// as a scalar branch; resolving them removes ~60 branches, the SGPR spills and their v_readlane traffic from the loop.
+template <int KIND, int WM, int KM, bool KEXACT, int WX = WM, int SPEC = 0>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                         int* __restrict__ bins_out, FuseF fz) {
   constexpr int NW = NIS_TPB / NIS_WAVE;
-  constexpr int NF = WM <= 4 ? 4 : NIS_PMAX_FUSED;      // next-cell pass-through features tracked here (<= its P)
+  constexpr int NF = SPEC ? 1 : WM <= 4 ? 4 : NIS_PMAX_FUSED;      // next-cell pass-through features tracked here (<= its P)
+  constexpr bool SP = SPEC != 0;
   __shared__ double lds_coef[(NIS_MAX_HIDDEN + 1) * 2 * WM];
   __shared__ double red[3 * NIS_TPB];
   __shared__ double wshift[NW][NF];
@@ -497,12 +502,18 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   nis_exp_init(etab);
   load_coefs<WM, NIS_TPB>(c, g, c.L + 1, (bn_train && c.G == 1) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red);
   fold_coefs<WM>(c, lds_coef, c.L + 1);
-  const bool fold = c.fold != 0;
+  const bool fold = SP ? true : c.fold != 0;
+  const int cP = SP ? 1 : c.P, cT = SP ? 1 : c.T;
+  const long out_off = SP ? 0 : c.out_off;
+  int* const bins_o = SP ? nullptr : bins_out;
   nis_cptr wl = as_const(c.wlast);
   nis_cptr bias = as_const(c.bias);
   constexpr bool RIDERS = WM <= 8;          // wide conditioners keep their registers for the GEMV
-  const bool next = RIDERS && c.next_P > 0;
-  const bool fuse = RIDERS && fz.kind >= 0;
+  const bool next = SPEC == 1 ? true : SPEC == 2 ? false : (RIDERS && c.next_P > 0);
+  const bool fuse = SPEC == 2 ? true : SPEC == 1 ? false : (RIDERS && fz.kind >= 0);
+  const int fkind = SPEC == 2 ? (int)NIS_F_CAMEL : fz.kind;
+  const bool wplanes = SPEC == 1 ? true : SPEC == 2 ? false : fz.write_planes != 0;
+  double* const fres = SP ? nullptr : fz.fres;
   double nS1[NF], nS2[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) nS1[f] = nS2[f] = 0.0;
@@ -511,11 +522,16 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   const long stride = (long)gridDim.x * NIS_TPB;
   for (long i = (long)blockIdx.x * NIS_TPB + tid; i < N; i += stride) {
     double a[WM];
-    load_passthrough<WM>(c, planes, ld, i, a);
-    if (c.out_off != 0) {                             // history mode: the next plane set gets the pass-through block too
+    if (SP) {
+#pragma unroll
+      for (int p = 0; p < WM; ++p) a[p] = p == 0 ? planes[(size_t)c.in_plane[0] * ld + i] : 0.0;
+    } else {
+      load_passthrough<WM>(c, planes, ld, i, a);
+    }
+    if (out_off != 0) {                             // history mode: the next plane set gets the pass-through block too
 #pragma unroll
       for (int p = 0; p < (WM < NIS_MAX_DIM ? WM : NIS_MAX_DIM); ++p)
-        if (p < c.P) planes[(size_t)c.in_plane[p] * ld + c.out_off + i] = a[p];
+        if (p < cP) planes[(size_t)c.in_plane[p] * ld + out_off + i] = a[p];
     }
     double nv[NF];
     double c0 = 0.0, c1 = 0.0, nsum = 0.0;
@@ -525,23 +541,23 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const int src = c.next_src[f];
-        nv[f] = (src >= 0 && src < c.P) ? planes[(size_t)c.in_plane[src < 0 ? 0 : src] * ld + i] : 0.0;
+        nv[f] = (src >= 0 && src < cP) ? planes[(size_t)c.in_plane[src < 0 ? 0 : src] * ld + i] : 0.0;
       }
     }
     if (fuse) {
-      if (fz.kind == NIS_F_CAMEL) {
-        if (fz.loc0 >= 0 && fz.loc0 < c.P) c0 = planes[(size_t)c.in_plane[fz.loc0] * ld + i];
-        if (fz.loc1 >= 0 && fz.loc1 < c.P) c1 = planes[(size_t)c.in_plane[fz.loc1] * ld + i];
-      } else if (fz.kind == NIS_F_NORMAL) {
+      if (fkind == NIS_F_CAMEL) {
+        if (fz.loc0 >= 0 && fz.loc0 < cP) c0 = planes[(size_t)c.in_plane[fz.loc0] * ld + i];
+        if (fz.loc1 >= 0 && fz.loc1 < cP) c1 = planes[(size_t)c.in_plane[fz.loc1] * ld + i];
+      } else if (fkind == NIS_F_NORMAL) {
 #pragma unroll
         for (int p = 0; p < (WM < NIS_MAX_DIM ? WM : NIS_MAX_DIM); ++p)
-          if (p < c.P) nsum += ((a[p] - fz.p[0]) * (a[p] - fz.p[0])) / (2 * fz.p[1] * fz.p[1]);
+          if (p < cP) nsum += ((a[p] - fz.p[0]) * (a[p] - fz.p[0])) / (2 * fz.p[1] * fz.p[1]);
       }
     }
     hidden_stack<WM, WX>(c, lds_coef, c.L, true, a, fold);
     double jprod = 1.0;
-    for (int t = 0; t < c.T; ++t) {
-      double* col = planes + (size_t)c.in_plane[c.P + t] * ld;
+    for (int t = 0; t < cT; ++t) {
+      double* col = planes + (size_t)c.in_plane[cP + t] * ld;
       const double xb = col[i];
       const int row0 = t * c.out;
       double y, jf;
@@ -559,7 +575,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
       } else if (KIND == NIS_AFFINE) {
         // AffineCoupling (coupling_cells.py:56-68): rows [scale | shift][T];  y = atan(20 e^z0 x + relu(z1)) / (pi/2)
         const double s0 = 20.0 * nis_exp(last_dot<WM, WX>(wl, bias, t, a), etab);
-        const double z1 = last_dot<WM, WX>(wl, bias, c.T + t, a);
+        const double z1 = last_dot<WM, WX>(wl, bias, cT + t, a);
         const double u = xb * s0 + (z1 > 0.0 ? z1 : 0.0);
         y = atan(u) / (M_PI / 2);
         jf = s0 * (1.0 / (u * u + 1.0));
@@ -588,24 +604,24 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
         y = qn * alpha + below / tot;                                                 // :123,136-139
         jf = qn;                                                                      // :141
       }
-      if (fz.write_planes) col[c.out_off + i] = y;
+      if (wplanes) col[out_off + i] = y;
       jprod *= jf;
-      if (KIND != NIS_AFFINE && bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
+      if (KIND != NIS_AFFINE && bins_o && g == 0) bins_o[(size_t)(c.bins_row + t) * ld + i] = bin;
       if (next) {
 #pragma unroll
         for (int f = 0; f < NF; ++f)
-          if (c.next_src[f] == c.P + t) nv[f] = y;
+          if (c.next_src[f] == cP + t) nv[f] = y;
       }
       if (fuse) {
-        if (fz.loc0 == c.P + t) c0 = y;
-        if (fz.loc1 == c.P + t) c1 = y;
-        if (fz.kind == NIS_F_NORMAL) nsum += ((y - fz.p[0]) * (y - fz.p[0])) / (2 * fz.p[1] * fz.p[1]);
+        if (fz.loc0 == cP + t) c0 = y;
+        if (fz.loc1 == cP + t) c1 = y;
+        if (fkind == NIS_F_NORMAL) nsum += ((y - fz.p[0]) * (y - fz.p[0])) / (2 * fz.p[1] * fz.p[1]);
       }
     }
     double* jp = planes + (size_t)c.jplane * ld;
     if (KIND == NIS_AFFINE) jprod *= 1.0 / (M_PI / 2);          // the reference applies 2/pi ONCE per cell (:68)
     const double jout = (c.first ? 1.0 : jp[i]) * jprod;
-    if (fz.write_planes) jp[c.out_off + i] = jout;
+    if (wplanes) jp[out_off + i] = jout;
     if (next) {
       if (firstit) {
 #pragma unroll
@@ -623,16 +639,16 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
     }
     if (fuse) {
       double fv = 1.0;
-      if (fz.kind == NIS_F_CAMEL) {                                                   // README.md:35-36
+      if (fkind == NIS_F_CAMEL) {                                                   // README.md:35-36
         const double is2 = fz.p[3];                                                   // host: 1 / s^2
         const double e1 = -((c0 - fz.p[0]) * (c0 - fz.p[0]) + (c1 - fz.p[0]) * (c1 - fz.p[0])) * is2;
         const double e2 = -((c0 - fz.p[1]) * (c0 - fz.p[1]) + (c1 - fz.p[1]) * (c1 - fz.p[1])) * is2;
         fv = nis_exp(e1, etab) + nis_exp(e2, etab);
-      } else if (fz.kind == NIS_F_NORMAL) {                                           // manager.py:39-40
+      } else if (fkind == NIS_F_NORMAL) {                                           // manager.py:39-40
         fv = nis_exp(-nsum, etab) / (fz.p[1] * sqrt(pow(2 * M_PI, (double)c.d)));
       }
       const double v = fv * jout;
-      if (fz.fres) fz.fres[(size_t)g * fz.fres_gs + i] = v;
+      if (fres) fres[(size_t)g * fz.fres_gs + i] = v;
       if (firstit) fshift = wave_first(v);
       const double t = v - fshift;
       fS1 += t;
@@ -643,7 +659,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
     firstit = false;
   }
   if (next)
-    emit_records<NF, NW>(nS1, nS2, cnt, wshift, wmom, c.next_P, c.next_partials + ((size_t)g * c.maxb + blockIdx.x) * c.next_wm * 3);
+    emit_records<NF, NW>(nS1, nS2, cnt, wshift, wmom, SP ? 1 : c.next_P, c.next_partials + ((size_t)g * c.maxb + blockIdx.x) * c.next_wm * 3);
   if (fuse) block_record<NW>(fshift, fS1, fS2, cnt, fmax_, fmom, fz.partials + ((size_t)g * fz.maxb + blockIdx.x) * 4);
 }
 

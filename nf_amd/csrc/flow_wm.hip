@@ -137,6 +137,28 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
 #if NIS_WM == 4
 #define NIS_APPLY3(KIND, KMV, EX) \
   hipLaunchKernelGGL((k_cell_apply<KIND, NIS_WM, KMV, EX, 3>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
+#define NIS_APPLY3S(KMV, SP) \
+  hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
+  if (c.wx == 3 && c.kind == NIS_PWQUAD && km < 0 && c.P == 1 && c.T == 1 && c.fold && c.out_off == 0 && !bins && !fz.fres) {
+    // the two cells of a d = 2 chain: every wave-uniform switch resolved at compile time (k_cell_apply, SPEC)
+    const int spec = (c.next_P == 1 && fz.kind < 0 && fz.write_planes) ? 1
+                     : (c.next_P == 0 && fz.kind == NIS_F_CAMEL && !fz.write_planes) ? 2 : 0;
+    if (spec == 1) {
+      switch (km) {
+        case -4: NIS_APPLY3S(4, 1); return hipGetLastError();
+        case -8: NIS_APPLY3S(8, 1); return hipGetLastError();
+        case -16: NIS_APPLY3S(16, 1); return hipGetLastError();
+        default: break;
+      }
+    } else if (spec == 2) {
+      switch (km) {
+        case -4: NIS_APPLY3S(4, 2); return hipGetLastError();
+        case -8: NIS_APPLY3S(8, 2); return hipGetLastError();
+        case -16: NIS_APPLY3S(16, 2); return hipGetLastError();
+        default: break;
+      }
+    }
+  }
   if (c.wx == 3) {
     if (c.kind == NIS_PWLIN) {
       NIS_APPLY3(NIS_PWLIN, 4, false);
