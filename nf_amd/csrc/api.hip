@@ -727,7 +727,7 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
       NisProfScope ps(NIS_K_STATS, s);
       HIP_OK(launch_stats<WM>(c, planes, ld, N, 0, grid_stats, s));
     }
-    if (c.G > 1) HIP_OK(launch_finalize<WM>(c, 0, s));
+    if (!c.pmerge) HIP_OK(launch_finalize<WM>(c, 0, s));
     for (int l = 1; l <= c.L; ++l) {
       if (l == 1 && c.derive1) continue;                       // BN_1 was derived from BN_0 (single pass-through column)
       {
@@ -737,7 +737,7 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
         else
           HIP_OK(launch_stats<WM>(c, planes, ld, N, l, grid_stats, s));
       }
-      if (c.G > 1) HIP_OK(launch_finalize<WM>(c, l, s));
+      if (!c.pmerge) HIP_OK(launch_finalize<WM>(c, l, s));
     }
   }
   {
@@ -880,6 +880,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     // (needs the layer-1 statistics launch to be gone: train mode with derive1, or eval mode)
     c.fold = (cd.P == 1 && !mfma && (c.derive1 || !train) && !env_int("NIS_NO_FOLD", 0)) ? 1 : 0;
     c.wx = cell_wx(cd, L.WM);
+    c.pmerge = (G == 1 || !env_int("NIS_FINALIZE_KERNEL", 0)) ? 1 : 0;   // a launch costs >= 4.3 us, the prologue merge ~1 us
     c.out_off = o.hist ? plane_gs : 0;
     c.bnsave = (o.hist && o.bnsave && train) ? o.bnsave + bn_off : nullptr;
     bn_off += (size_t)(cd.n_hidden + 1) * 4 * L.WM;

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
   const int g = blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   // G == 1: the previous layer's records are merged here; G > 1: k_bn_finalize already published the coefficients
-  load_coefs<WM, TPB>(c, g, layer, c.G == 1 ? cellk_fresh(c, layer) : -1, blockIdx.x == 0, lds_coef, red);
+  load_coefs<WM, TPB>(c, g, layer, c.pmerge ? cellk_fresh(c, layer) : -1, blockIdx.x == 0, lds_coef, red);
   fold_coefs<WM>(c, lds_coef, layer);
   const bool fold = c.fold && layer >= 2;
 
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   const int g = blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   nis_exp_init(etab);
-  load_coefs<WM, NIS_TPB>(c, g, c.L + 1, (bn_train && c.G == 1) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red);
+  load_coefs<WM, NIS_TPB>(c, g, c.L + 1, (bn_train && c.pmerge) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red);
   fold_coefs<WM>(c, lds_coef, c.L + 1);
   const bool fold = SP ? true : c.fold != 0;
   const int cP = SP ? 1 : c.P, cT = SP ? 1 : c.T;

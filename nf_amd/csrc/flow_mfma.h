@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NIS_MF_TPB) void k_bn_stats_mfma(CellK c, const dou
   const int g = blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   if (tid < NIS_MAX_DIM) lds_plane[tid] = c.in_plane[tid];
-  load_coefs<WM, NIS_MF_TPB>(c, g, layer, c.G == 1 ? cellk_fresh(c, layer) : -1, blockIdx.x == 0, lds_coef, red);
+  load_coefs<WM, NIS_MF_TPB>(c, g, layer, c.pmerge ? cellk_fresh(c, layer) : -1, blockIdx.x == 0, lds_coef, red);
 
   double S1[JT][4], S2[JT][4], shf[JT][4];
 #pragma unroll
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
   planes += (size_t)g * c.plane_gs;
   if (tid < NIS_MAX_DIM) lds_plane[tid] = c.in_plane[tid];
   nis_exp_init(etab);
-  load_coefs<WM, NIS_MF_TPB>(c, g, c.L + 1, (bn_train && c.G == 1) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red);
+  load_coefs<WM, NIS_MF_TPB>(c, g, c.L + 1, (bn_train && c.pmerge) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red);
   const int out = c.out;
   double* ring = mf_dyn + (size_t)wave * NCB * out * 16;
   const int Kq = KEXACT ? KM : c.K;

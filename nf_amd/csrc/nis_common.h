@@ -131,6 +131,8 @@ struct CellK {
   int G;                                 // number of batches in this launch set
   int coef_gs;                           // doubles between the coefficient sets of consecutive g: (L+1)*2*WM
   long plane_gs;                         // doubles between the plane sets of consecutive g: (d+1)*ld
+  int pmerge;                            // 1: consumers merge the records of the freshest BN layer in their prologue (every workgroup of
+                                         //    batch g redoes the small tree merge); 0: k_bn_finalize launches publish the coefficients
   double* gstat;                         // G > 1: (L+1) x G x 2 x WM  batch mean | unbiased var for k_running_update
   // ---- training history (for the adjoint kernels): outputs go to the NEXT plane set, BN statistics are kept
   int derive1;                           // 1 (P == 1): BN_1's batch statistics follow analytically from BN_0's

@@ -13,7 +13,7 @@ f = integrands.Camel()
 L = _lib.lib()
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 K = {"apply": 0, "stats": 1, "ingest": 2}
-for N in (100_000, 300_000, 1_000_000, 3_000_000):
+for N in (1_000, 10_000, 100_000, 1_000_000):
     w = torch.rand(G, N, 2, dtype=torch.float32, device=dev)
     out = torch.zeros(G, 4, dtype=torch.double, device=dev)
     tok = eng.pack_token()
