@@ -285,9 +285,9 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
   fold_coefs<WM>(c, lds_coef, layer);
   const bool fold = c.fold && layer >= 2;
 
-  double S1[WM], S2[WM];
+  double S1[WM], S2[WM], shf[WM];
 #pragma unroll
-  for (int j = 0; j < WM; ++j) S1[j] = S2[j] = 0.0;
+  for (int j = 0; j < WM; ++j) S1[j] = S2[j] = shf[j] = 0.0;
   double cnt = 0.0;
   const long stride = (long)gridDim.x * TPB;
   constexpr int U = WM <= 8 ? 4 : 1;           // samples in flight per thread: the loop is load-latency bound
@@ -318,14 +318,14 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
         if (firstit) {                  // wave-uniform shift = lane 0's first value (lane 0 owns the lowest index)
 #pragma unroll
           for (int j = 0; j < WM; ++j) {
-            const double s0 = wave_first(a[j]);
-            if (lane == 0) wshift[wave][j] = s0;
+            shf[j] = wave_first(a[j]);  // kept in registers (scalar after readfirstlane): no LDS read per sample
+            if (lane == 0) wshift[wave][j] = shf[j];
           }
           firstit = false;
         }
 #pragma unroll
         for (int j = 0; j < WX; ++j) {
-          const double t = a[j] - wshift[wave][j];
+          const double t = a[j] - shf[j];
           S1[j] += t;
           S2[j] = fma(t, t, S2[j]);
         }
@@ -514,9 +514,9 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   const int fkind = SPEC == 2 ? (int)NIS_F_CAMEL : fz.kind;
   const bool wplanes = SPEC == 1 ? true : SPEC == 2 ? false : fz.write_planes != 0;
   double* const fres = SP ? nullptr : fz.fres;
-  double nS1[NF], nS2[NF];
+  double nS1[NF], nS2[NF], nsh[NF];
 #pragma unroll
-  for (int f = 0; f < NF; ++f) nS1[f] = nS2[f] = 0.0;
+  for (int f = 0; f < NF; ++f) nS1[f] = nS2[f] = nsh[f] = 0.0;
   double cnt = 0.0, fS1 = 0.0, fS2 = 0.0, fmax_ = -__builtin_huge_val(), fshift = 0.0;
   bool firstit = true;
   const long stride = (long)gridDim.x * NIS_TPB;
@@ -626,13 +626,13 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
       if (firstit) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-          const double s0 = wave_first(nv[f]);
-          if (lane == 0) wshift[wave][f] = s0;
+          nsh[f] = wave_first(nv[f]);
+          if (lane == 0) wshift[wave][f] = nsh[f];
         }
       }
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        const double t = nv[f] - wshift[wave][f];
+        const double t = nv[f] - nsh[f];
         nS1[f] += t;
         nS2[f] = fma(t, t, nS2[f]);
       }
