@@ -389,7 +389,7 @@ __device__ __forceinline__ double lerp_torch(double a, double b, double w) {
 // -- probability ~1e-15 per bin -- the true division decides.  One division yields the selected left edge.
 // Ties (equal Wsum for consecutive bins, i.e. widths that vanish in the cumsum) resolve to the first bin, as argmax does.
 template <int KM, bool KEXACT>
-__device__ __forceinline__ void pwquad_bin(double xb, int Krt, const double (&W)[KM], double wn, int* idx_out, double* left_out) {
+__device__ __forceinline__ void pwquad_bin_raw(double xb, int Krt, const double (&W)[KM], double wn, int* idx_out, double* run_out) {
   const int K = KEXACT ? KM : Krt;
   const double q = xb * wn;
   const double qlo = q * (1.0 - 0x1p-50), qhi = q * (1.0 + 0x1p-50);
@@ -422,21 +422,34 @@ __device__ __forceinline__ void pwquad_bin(double xb, int Krt, const double (&W)
       idx = up ? k + 1 : idx;
     }
   }
-  double left = bestrun / wn;                            // Wsum2[idx]  (:186, :198)
-  const bool none = !(left > 1e-30);                     // the 1e-30 sentinel wins: bin 0, left edge 0
+  // Wsum2[idx] = bestrun / wn (:186, :198) must exceed the 1e-30 sentinel, else bin 0 with left edge 0 wins; tested on
+  // the raw sum (equivalent unless the quotient is within an ulp of 1e-30)
+  const bool none = !(bestrun > 1e-30 * wn);
   idx = none ? 0 : idx;
-  left = none ? 0.0 : left;
+  bestrun = none ? 0.0 : bestrun;
   idx = (idx > K - 1) ? K - 1 : idx;
   *idx_out = idx;
-  *left_out = left;
+  *run_out = bestrun;                                    // raw cumulative width left of the bin
+}
+
+// same, returning the normalised left edge Wsum2[idx] (used by the adjoint kernels)
+template <int KM, bool KEXACT>
+__device__ __forceinline__ void pwquad_bin(double xb, int Krt, const double (&W)[KM], double wn, int* idx_out, double* left_out) {
+  double run;
+  pwquad_bin_raw<KM, KEXACT>(xb, Krt, W, wn, idx_out, &run);
+  *left_out = run / wn;
 }
 
 // Piecewise-quadratic transform of one column (coupling_cells.py:167-225).  V: K+1 vertex heights
 // (raw exp), W: K bin widths (raw exp).  Returns y; *jf = d y / d x; *bin = bin index.
-// The bin is selected with the reference's exact semantics (pwquad_bin); the remaining normalisations multiply by a
-// reciprocal (<= 1 ulp from a division).
+// The bin is selected with the reference's exact semantics (pwquad_bin_raw).  The value is formed from RAW sums: with
+// S_k = (V_k + V_{k+1}) W_k, A = sum_k S_k and wn = sum_k W_k the reference's normalisations (:184-197) amount to
+// widths W/wn and heights V 2wn/A, hence
+//   alpha = (x wn - run_b) / W_b,   y = ((alpha^2/2 (V_{b+1} - V_b) + alpha V_b) 2 W_b + sum_{k<b} S_k) / A,
+//   dy/dx = lerp(V_b, V_{b+1}, alpha) 2 wn / A
+// -- two divisions per column instead of four, no normalised copies of V and W (<= few ulp from the reference's order).
 template <int KM, bool KEXACT>
-__device__ __forceinline__ double pwquad_column(double xb, int Krt, double (&V)[KM + 1], double (&W)[KM], double* jf, int* bin) {
+__device__ __forceinline__ double pwquad_column(double xb, int Krt, const double (&V)[KM + 1], const double (&W)[KM], double* jf, int* bin) {
   const int K = KEXACT ? KM : Krt;
   xb = (xb > 1.0 - 1e-6) ? 1.0 - 1e-6 : xb;                       // :167
   double wn = 0.0;
@@ -444,37 +457,25 @@ __device__ __forceinline__ double pwquad_column(double xb, int Krt, double (&V)[
   for (int k = 0; k < KM; ++k)
     if (k < K) wn += W[k];                                        // Wsum[-1]  :180-182
   int idx;
-  double left;
-  pwquad_bin<KM, KEXACT>(xb, Krt, W, wn, &idx, &left);
-  const double iwn = 1.0 / wn;
-  double area = 0.0;
-#pragma unroll
-  for (int k = 0; k < KM; ++k)
-    if (k < K) {
-      W[k] = W[k] * iwn;                                          // :184
-      area += (V[k] + V[k + 1]) / 2 * W[k];                       // :194
-    }
-  const double iarea = 1.0 / area;
-#pragma unroll
-  for (int k = 0; k < KM + 1; ++k)
-    if (k <= K) V[k] = V[k] * iarea;                              // :196-197
-  double vw = 0.0, shift = 0.0, Wb = 1.0, Vb = 0.0, Vb1 = 0.0;
+  double run;
+  pwquad_bin_raw<KM, KEXACT>(xb, Krt, W, wn, &idx, &run);
+  double A = 0.0, pre = 0.0, Wb = 1.0, Vb = 0.0, Vb1 = 0.0;
 #pragma unroll
   for (int k = 0; k < KM; ++k)
     if (k < K) {
       const bool hit = k == idx;
-      shift = hit ? vw : shift;                                   // VW[idx]  :209-211
+      pre = hit ? A : pre;                                        // VW[idx] A  :209-211
       Wb = hit ? W[k] : Wb;
       Vb = hit ? V[k] : Vb;
       Vb1 = hit ? V[k + 1] : Vb1;
-      vw += (V[k] + V[k + 1]) / 2 * W[k];
+      A = fma(V[k] + V[k + 1], W[k], A);                          // :194
     }
-  const double alpha = (xb - left) / Wb;                          // :206-207
-  const double y1 = (alpha * alpha) / 2 * ((Vb1 - Vb) * Wb);      // :213-214
-  const double y2 = (alpha * Vb) * Wb;                            // :216-217
-  *jf = lerp_torch(Vb, Vb1, alpha);                               // :224-225
+  const double iA = 1.0 / A;
+  const double alpha = (xb * wn - run) / Wb;                      // :206-207
+  const double num = ((alpha * alpha) / 2 * (Vb1 - Vb) + alpha * Vb) * (2 * Wb) + pre;   // :213-220
+  *jf = lerp_torch(Vb, Vb1, alpha) * ((2 * wn) * iA);             // :224-225
   *bin = idx;
-  return y1 + y2 + shift;                                         // :220
+  return num * iA;
 }
 
 // Full cell: conditioner with finalised BN + bijector, in place on the transformed planes.  Optional riders:
