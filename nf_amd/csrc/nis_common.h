@@ -88,7 +88,7 @@ __device__ __forceinline__ double nis_exp(double x, const double* lds_tab) {
 static inline int nis_pick_wm(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 16 ? 16 : m <= 32 ? 32 : m <= 64 ? 64 : -1; }
 static inline int nis_pick_km(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : -1; }
 // workgroup size of the statistics kernel: as many waves as the register budget of width WM allows
-__host__ __device__ constexpr int nis_stats_tpb(int wm) { return wm <= 8 ? 1024 : wm <= 16 ? 512 : 256; }
+__host__ __device__ constexpr int nis_stats_tpb(int wm) { return wm <= 8 ? 512 : wm <= 16 ? 512 : 256; }
 
 // Built-in integrand evaluated inside the last apply kernel (f(X)*J never leaves the chip).
 struct FuseF {
