@@ -7,6 +7,7 @@
 // :134-146 (lab boost), :151-187 (pseudo-rapidity, delta-phi, delta-R).  pdf == None (density 1).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "nis_common.h"
@@ -109,13 +110,17 @@ __device__ __forceinline__ double rb_delphi(const V4& a, const V4& b) {         
   return r;
 }
 
+#ifndef RB_TPB
 #define RB_TPB 128      // threads (= samples) per tile: bounds the LDS staging area to 128*(4(n+2)+1)*8 B
+#endif
 
 // Row-major I/O goes through LDS: a tile's (RB_TPB x ncol) inputs are copied with contiguous 8-byte-per-lane
 // loads, each thread then reads its own row; the (RB_TPB x 4(n+2)) momenta are written to a padded LDS image and
 // stored as contiguous 16-byte-per-lane streams.  Without staging every lane touches its own cache line per
 // instruction (row stride 64-256 B).
-template <int NF>
+// PLAIN: compile-time copy of the switches of the plain 2 -> n map (no PDF sampling, no lab boost, no cuts, Newton
+// solver, contiguous row-major input): the generic kernel carries all of them as scalar branches and their registers.
+template <int NF, bool PLAIN = false>
 #ifdef RB_WAVES
 __global__ __launch_bounds__(RB_TPB, RB_WAVES)
 #else
@@ -126,9 +131,14 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
   extern __shared__ double rb_lds[];
   constexpr int LM = 4 * (NF + 2);                   // doubles of one sample's momenta
   const int tid = threadIdx.x;
-  const bool pdf_active = k.d.flags & NIS_RAMBO_PDF_ACTIVE;
-  const bool use_tau = k.d.flags & NIS_RAMBO_TAU;
-  const bool lab_boost = k.d.flags & NIS_RAMBO_LAB_BOOST;
+  const bool pdf_active = PLAIN ? false : (k.d.flags & NIS_RAMBO_PDF_ACTIVE) != 0;
+  const bool use_tau = PLAIN ? false : (k.d.flags & NIS_RAMBO_TAU) != 0;
+  const bool lab_boost = PLAIN ? false : (k.d.flags & NIS_RAMBO_LAB_BOOST) != 0;
+  const int bisect_levels = PLAIN ? 0 : k.d.bisect_levels;
+  const double pT_mincut = PLAIN ? -1.0 : k.d.pT_mincut, delR_mincut = PLAIN ? -1.0 : k.d.delR_mincut,
+               rap_maxcut = PLAIN ? -1.0 : k.d.rap_maxcut;
+  const bool col_major = PLAIN ? false : k.col_major != 0;
+  const bool flat_rows = PLAIN ? true : k.r_ld == k.ncol;
   constexpr int NPS = 3 * NF - 4;                    // phase-space columns; +2 (tau, ycm | x2, x1) with PDFs
   const long ntiles = (N + RB_TPB - 1) / RB_TPB;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -138,8 +148,8 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     const bool live = tid < ns;
     double rv[NPS + 2];
     bool nan_in = false;
-    if (!k.col_major) {
-      if (k.r_ld == k.ncol) {                         // contiguous rows: one flat copy of the tile
+    if (!col_major) {
+      if (flat_rows) {                         // contiguous rows: one flat copy of the tile
         const int tot = ns * k.ncol;
         const double* src = r + (size_t)i0 * k.ncol;
         for (int e = tid; e < tot; e += RB_TPB) rb_lds[e] = src[e];
@@ -190,11 +200,11 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
       const int e = NF - 2 - c;
       const double v = rv[c];
       double u;
-      if (k.d.bisect_levels > 0) {
+      if (bisect_levels > 0) {
         // the reference's integer-lattice bisection, fixed depth (bit-compatible path, ~14 VALU per level)
         double left = 0.0, right = 1.0, scale = 0.5;
         u = -1.0;
-        for (int level = 0; level < k.d.bisect_levels; ++level) {
+        for (int level = 0; level < bisect_levels; ++level) {
           u = (left + right) * scale;
           const double chk = rb_ipow(u, e) * ((double)(e + 1) - (double)e * u);      // massless_map :101-103
           left *= 2.;
@@ -298,31 +308,31 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
 
     // ---- cuts (:285-301)
     double factor = 1.0;
-    if (k.d.pT_mincut > 0.) {                         // min pT >= 0 can never be below a cut <= 0 (:285-288)
+    if (pT_mincut > 0.) {                         // min pT >= 0 can never be below a cut <= 0 (:285-288)
       double ptmin = RB_HUGE;
 #pragma unroll
       for (int l = 0; l < NF; ++l) ptmin = fmin(ptmin, fabs(sqrt(mom[2 + l].x * mom[2 + l].x + mom[2 + l].y * mom[2 + l].y)));
-      factor = (ptmin < k.d.pT_mincut) ? 0.0 : 1.0;
+      factor = (ptmin < pT_mincut) ? 0.0 : 1.0;
     }
-    const bool need_eta = (k.d.delR_mincut > 0.) || (k.d.rap_maxcut > 0.);
+    const bool need_eta = (delR_mincut > 0.) || (rap_maxcut > 0.);
     if (need_eta) {
       double eta[NF];
 #pragma unroll
       for (int l = 0; l < NF; ++l) eta[l] = rb_pseudorap(mom[2 + l]);
-      if (k.d.delR_mincut > 0.) {
+      if (delR_mincut > 0.) {
 #pragma unroll
         for (int a = 1; a < NF; ++a)
 #pragma unroll
           for (int b = 0; b < a; ++b) {
             const double de = eta[a] - eta[b], dp = rb_delphi(mom[2 + a], mom[2 + b]);
-            if (fabs(sqrt(de * de + dp * dp)) < k.d.delR_mincut) factor = 0.0;
+            if (fabs(sqrt(de * de + dp * dp)) < delR_mincut) factor = 0.0;
           }
       }
-      if (k.d.rap_maxcut > 0.) {
+      if (rap_maxcut > 0.) {
         double emax = eta[0];
 #pragma unroll
         for (int l = 1; l < NF; ++l) emax = fmax(emax, eta[l]);
-        if (k.d.rap_maxcut < fabs(emax)) factor = 0.0;                              // |max eta|, not max |eta| (:298-301)
+        if (rap_maxcut < fabs(emax)) factor = 0.0;                              // |max eta|, not max |eta| (:298-301)
       }
     }
     wtot *= factor;
@@ -370,10 +380,16 @@ extern "C" int nis_rambo_forward(const nis_rambo_desc* dh, const double* r, int6
   const int LMh = 4 * (n + 2);
   const size_t lds_bytes = (size_t)RB_TPB * std::max(LMh + 1, k.ncol) * sizeof(double);
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * 256 * 2, (N + RB_TPB - 1) / RB_TPB));
-#define RB_CASE(NFV)                                                                                              \
-  case NFV:                                                                                                       \
-    hipLaunchKernelGGL(k_rambo<NFV>, dim3(grid), dim3(RB_TPB), lds_bytes, s, k, r, (long)N, momenta, weight, (int*)status); \
+  static const int mult = getenv("NIS_RAMBO_GRID_MULT") ? atoi(getenv("NIS_RAMBO_GRID_MULT")) : 2;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * 256 * mult, (N + RB_TPB - 1) / RB_TPB));
+  const bool plain = !(dh->flags & (NIS_RAMBO_PDF_ACTIVE | NIS_RAMBO_LAB_BOOST)) && dh->bisect_levels <= 0 &&   // TAU only matters with PDFs
+                     !(dh->pT_mincut > 0.) && !(dh->delR_mincut > 0.) && !(dh->rap_maxcut > 0.) && !r_col_major && r_ld == k.ncol;
+#define RB_CASE(NFV)                                                                                                        \
+  case NFV:                                                                                                                 \
+    if (plain)                                                                                                              \
+      hipLaunchKernelGGL((k_rambo<NFV, true>), dim3(grid), dim3(RB_TPB), lds_bytes, s, k, r, (long)N, momenta, weight, (int*)status); \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((k_rambo<NFV, false>), dim3(grid), dim3(RB_TPB), lds_bytes, s, k, r, (long)N, momenta, weight, (int*)status); \
     break;
   NisProfScope ps(NIS_K_RAMBO, s);
   switch (n) {
