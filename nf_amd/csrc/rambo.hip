@@ -118,9 +118,11 @@ __device__ __forceinline__ double rb_delphi(const V4& a, const V4& b) {         
 // loads, each thread then reads its own row; the (RB_TPB x 4(n+2)) momenta are written to a padded LDS image and
 // stored as contiguous 16-byte-per-lane streams.  Without staging every lane touches its own cache line per
 // instruction (row stride 64-256 B).
-// PLAIN: compile-time copy of the switches of the plain 2 -> n map (no PDF sampling, no lab boost, no cuts, Newton
-// solver, contiguous row-major input): the generic kernel carries all of them as scalar branches and their registers.
-template <int NF, bool PLAIN = false>
+// MODE: compile-time copy of the feature switches, because the generic kernel (every switch a scalar branch, the union
+// of all live ranges) needs 256 VGPRs = one wave per SIMD:
+//   0 plain 2 -> n map | 1 + PDF sampling (tau/y or x1,x2), x cut, lab boost | 2 + pT / delta-R / eta cuts
+//   3 + the reference's fixed-depth lattice bisection and strided row-major input
+template <int NF, int MODE = 3>
 #ifdef RB_WAVES
 __global__ __launch_bounds__(RB_TPB, RB_WAVES)
 #else
@@ -131,14 +133,15 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
   extern __shared__ double rb_lds[];
   constexpr int LM = 4 * (NF + 2);                   // doubles of one sample's momenta
   const int tid = threadIdx.x;
-  const bool pdf_active = PLAIN ? false : (k.d.flags & NIS_RAMBO_PDF_ACTIVE) != 0;
-  const bool use_tau = PLAIN ? false : (k.d.flags & NIS_RAMBO_TAU) != 0;
-  const bool lab_boost = PLAIN ? false : (k.d.flags & NIS_RAMBO_LAB_BOOST) != 0;
-  const int bisect_levels = PLAIN ? 0 : k.d.bisect_levels;
-  const double pT_mincut = PLAIN ? -1.0 : k.d.pT_mincut, delR_mincut = PLAIN ? -1.0 : k.d.delR_mincut,
-               rap_maxcut = PLAIN ? -1.0 : k.d.rap_maxcut;
-  const bool col_major = PLAIN ? false : k.col_major != 0;
-  const bool flat_rows = PLAIN ? true : k.r_ld == k.ncol;
+  constexpr bool HAS_PDF = MODE >= 1, HAS_CUTS = MODE >= 2, GEN = MODE >= 3;
+  const bool pdf_active = HAS_PDF ? (k.d.flags & NIS_RAMBO_PDF_ACTIVE) != 0 : false;
+  const bool use_tau = HAS_PDF ? (k.d.flags & NIS_RAMBO_TAU) != 0 : false;
+  const bool lab_boost = HAS_PDF ? (k.d.flags & NIS_RAMBO_LAB_BOOST) != 0 : false;
+  const int bisect_levels = GEN ? k.d.bisect_levels : 0;
+  const double pT_mincut = HAS_CUTS ? k.d.pT_mincut : -1.0, delR_mincut = HAS_CUTS ? k.d.delR_mincut : -1.0,
+               rap_maxcut = HAS_CUTS ? k.d.rap_maxcut : -1.0;
+  const bool col_major = k.col_major != 0;
+  const bool flat_rows = GEN ? k.r_ld == k.ncol : true;
   constexpr int NPS = 3 * NF - 4;                    // phase-space columns; +2 (tau, ycm | x2, x1) with PDFs
   const long ntiles = (N + RB_TPB - 1) / RB_TPB;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -382,14 +385,22 @@ extern "C" int nis_rambo_forward(const nis_rambo_desc* dh, const double* r, int6
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
   static const int mult = getenv("NIS_RAMBO_GRID_MULT") ? atoi(getenv("NIS_RAMBO_GRID_MULT")) : 2;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * 256 * mult, (N + RB_TPB - 1) / RB_TPB));
-  const bool plain = !(dh->flags & (NIS_RAMBO_PDF_ACTIVE | NIS_RAMBO_LAB_BOOST)) && dh->bisect_levels <= 0 &&   // TAU only matters with PDFs
-                     !(dh->pT_mincut > 0.) && !(dh->delR_mincut > 0.) && !(dh->rap_maxcut > 0.) && !r_col_major && r_ld == k.ncol;
-#define RB_CASE(NFV)                                                                                                        \
-  case NFV:                                                                                                                 \
-    if (plain)                                                                                                              \
-      hipLaunchKernelGGL((k_rambo<NFV, true>), dim3(grid), dim3(RB_TPB), lds_bytes, s, k, r, (long)N, momenta, weight, (int*)status); \
-    else                                                                                                                    \
-      hipLaunchKernelGGL((k_rambo<NFV, false>), dim3(grid), dim3(RB_TPB), lds_bytes, s, k, r, (long)N, momenta, weight, (int*)status); \
+  const bool has_pdf = (dh->flags & (NIS_RAMBO_PDF_ACTIVE | NIS_RAMBO_LAB_BOOST)) != 0;          // TAU only matters with PDFs
+  const bool has_cuts = dh->pT_mincut > 0. || dh->delR_mincut > 0. || dh->rap_maxcut > 0.;
+  const bool need_gen = dh->bisect_levels > 0 || (!r_col_major && r_ld != k.ncol);
+  const int mode = need_gen ? 3 : has_cuts ? 2 : has_pdf ? 1 : 0;
+#define RB_LAUNCH(NFV, M) \
+  hipLaunchKernelGGL((k_rambo<NFV, M>), dim3(grid), dim3(RB_TPB), lds_bytes, s, k, r, (long)N, momenta, weight, (int*)status)
+#define RB_CASE(NFV)                   \
+  case NFV:                            \
+    if (mode == 0)                     \
+      RB_LAUNCH(NFV, 0);               \
+    else if (mode == 1)                \
+      RB_LAUNCH(NFV, 1);               \
+    else if (mode == 2)                \
+      RB_LAUNCH(NFV, 2);               \
+    else                               \
+      RB_LAUNCH(NFV, 3);               \
     break;
   NisProfScope ps(NIS_K_RAMBO, s);
   switch (n) {
@@ -397,5 +408,6 @@ extern "C" int nis_rambo_forward(const nis_rambo_desc* dh, const double* r, int6
     default: return NIS_E_UNSUPPORTED;
   }
 #undef RB_CASE
+#undef RB_LAUNCH
   return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
 }
