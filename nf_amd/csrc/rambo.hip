@@ -152,17 +152,21 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     double rv[NPS + 2];
     bool nan_in = false;
     if (!col_major) {
+      const int rs = k.ncol | 1;               // odd LDS row stride: the per-thread row reads below are bank-conflict free
       if (flat_rows) {                         // contiguous rows: one flat copy of the tile
         const int tot = ns * k.ncol;
         const double* src = r + (size_t)i0 * k.ncol;
-        for (int e = tid; e < tot; e += RB_TPB) rb_lds[e] = src[e];
+        for (int e = tid; e < tot; e += RB_TPB) {
+          const int s_ = e / k.ncol;
+          rb_lds[s_ * rs + (e - s_ * k.ncol)] = src[e];
+        }
       } else {
         for (int s_ = 0; s_ < ns; ++s_)
-          for (int c = tid; c < k.ncol; c += RB_TPB) rb_lds[s_ * k.ncol + c] = r[(size_t)(i0 + s_) * k.r_ld + c];
+          for (int c = tid; c < k.ncol; c += RB_TPB) rb_lds[s_ * rs + c] = r[(size_t)(i0 + s_) * k.r_ld + c];
       }
       __syncthreads();
 #pragma unroll
-      for (int c = 0; c < NPS + 2; ++c) rv[c] = (live && c < k.ncol) ? rb_lds[tid * k.ncol + c] : 0.5;
+      for (int c = 0; c < NPS + 2; ++c) rv[c] = (live && c < k.ncol) ? rb_lds[tid * rs + c] : 0.5;
       __syncthreads();
     } else {
 #pragma unroll
@@ -381,7 +385,7 @@ extern "C" int nis_rambo_forward(const nis_rambo_desc* dh, const double* r, int6
   k.tau_min = base * base;
   hipStream_t s = (hipStream_t)stream;
   const int LMh = 4 * (n + 2);
-  const size_t lds_bytes = (size_t)RB_TPB * std::max(LMh + 1, k.ncol) * sizeof(double);
+  const size_t lds_bytes = (size_t)RB_TPB * std::max(LMh + 1, k.ncol | 1) * sizeof(double);
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
   static const int mult = getenv("NIS_RAMBO_GRID_MULT") ? atoi(getenv("NIS_RAMBO_GRID_MULT")) : 2;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * 256 * mult, (N + RB_TPB - 1) / RB_TPB));
