@@ -114,14 +114,13 @@ __device__ __forceinline__ double rb_delphi(const V4& a, const V4& b) {         
 #define RB_TPB 128      // threads (= samples) per tile: bounds the LDS staging area to 128*(4(n+2)+1)*8 B
 #endif
 
-// Row-major I/O goes through LDS: a tile's (RB_TPB x ncol) inputs are copied with contiguous 8-byte-per-lane
-// loads, each thread then reads its own row; the (RB_TPB x 4(n+2)) momenta are written to a padded LDS image and
-// stored as contiguous 16-byte-per-lane streams.  Without staging every lane touches its own cache line per
-// instruction (row stride 64-256 B).
+// The row-major OUTPUT goes through LDS: the (RB_TPB x 4(n+2)) momenta are written to a padded LDS image and stored as
+// contiguous 8-byte-per-lane streams; without staging every lane would write 16 bytes into its own 128-byte line per
+// instruction (row stride 128-384 B).  Inputs are prefetched into registers one tile ahead (see `fetch`).
 // MODE: compile-time copy of the feature switches, because the generic kernel (every switch a scalar branch, the union
 // of all live ranges) needs 256 VGPRs = one wave per SIMD:
 //   0 plain 2 -> n map | 1 + PDF sampling (tau/y or x1,x2), x cut, lab boost | 2 + pT / delta-R / eta cuts
-//   3 + the reference's fixed-depth lattice bisection and strided row-major input
+//   3 + the reference's fixed-depth lattice bisection
 template <int NF, int MODE = 3>
 #ifdef RB_WAVES
 __global__ __launch_bounds__(RB_TPB, RB_WAVES)
@@ -141,9 +140,24 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
   const double pT_mincut = HAS_CUTS ? k.d.pT_mincut : -1.0, delR_mincut = HAS_CUTS ? k.d.delR_mincut : -1.0,
                rap_maxcut = HAS_CUTS ? k.d.rap_maxcut : -1.0;
   const bool col_major = k.col_major != 0;
-  const bool flat_rows = GEN ? k.r_ld == k.ncol : true;
   constexpr int NPS = 3 * NF - 4;                    // phase-space columns; +2 (tau, ycm | x2, x1) with PDFs
   const long ntiles = (N + RB_TPB - 1) / RB_TPB;
+  // Inputs: every thread reads its own row (64-208 contiguous bytes; the lanes of a wave cover one contiguous block, so
+  // the cache lines are fully used) or its element of each column plane, one tile AHEAD: the loads of the next tile are
+  // in flight while the current one is computed.  PDF columns only exist in the PDF modes.
+  constexpr int NIN = HAS_PDF ? NPS + 2 : NPS;
+  auto fetch = [&](long t, double (&dst)[NPS + 2]) {
+    const long ii = t * RB_TPB + tid;
+    const bool ok = ii < N;
+#pragma unroll
+    for (int c = 0; c < NPS + 2; ++c) {
+      double v = 0.5;
+      if (c < NIN && ok && c < k.ncol) v = col_major ? r[(size_t)k.cols[c] * k.r_ld + ii] : r[(size_t)ii * k.r_ld + c];
+      dst[c] = v;
+    }
+  };
+  double rvn[NPS + 2];
+  if ((long)blockIdx.x < ntiles) fetch(blockIdx.x, rvn);
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long i0 = tile * RB_TPB;
     const int ns = (int)min((long)RB_TPB, N - i0);
@@ -151,27 +165,9 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     const bool live = tid < ns;
     double rv[NPS + 2];
     bool nan_in = false;
-    if (!col_major) {
-      const int rs = k.ncol | 1;               // odd LDS row stride: the per-thread row reads below are bank-conflict free
-      if (flat_rows) {                         // contiguous rows: one flat copy of the tile
-        const int tot = ns * k.ncol;
-        const double* src = r + (size_t)i0 * k.ncol;
-        for (int e = tid; e < tot; e += RB_TPB) {
-          const int s_ = e / k.ncol;
-          rb_lds[s_ * rs + (e - s_ * k.ncol)] = src[e];
-        }
-      } else {
-        for (int s_ = 0; s_ < ns; ++s_)
-          for (int c = tid; c < k.ncol; c += RB_TPB) rb_lds[s_ * rs + c] = r[(size_t)(i0 + s_) * k.r_ld + c];
-      }
-      __syncthreads();
 #pragma unroll
-      for (int c = 0; c < NPS + 2; ++c) rv[c] = (live && c < k.ncol) ? rb_lds[tid * rs + c] : 0.5;
-      __syncthreads();
-    } else {
-#pragma unroll
-      for (int c = 0; c < NPS + 2; ++c) rv[c] = (live && c < k.ncol) ? r[(size_t)k.cols[c] * k.r_ld + i] : 0.5;
-    }
+    for (int c = 0; c < NPS + 2; ++c) rv[c] = rvn[c];
+    if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, rvn);
 #pragma unroll
     for (int c = 0; c < NPS + 2; ++c) nan_in |= (rv[c] != rv[c]);
     if (nan_in && live) atomicOr(status, 2);                  // the reference raises PhaseSpaceGeneratorError (:147-149)
@@ -385,13 +381,13 @@ extern "C" int nis_rambo_forward(const nis_rambo_desc* dh, const double* r, int6
   k.tau_min = base * base;
   hipStream_t s = (hipStream_t)stream;
   const int LMh = 4 * (n + 2);
-  const size_t lds_bytes = (size_t)RB_TPB * std::max(LMh + 1, k.ncol | 1) * sizeof(double);
+  const size_t lds_bytes = (size_t)RB_TPB * (LMh + 1) * sizeof(double);      // output staging only
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
   static const int mult = getenv("NIS_RAMBO_GRID_MULT") ? atoi(getenv("NIS_RAMBO_GRID_MULT")) : 2;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * 256 * mult, (N + RB_TPB - 1) / RB_TPB));
   const bool has_pdf = (dh->flags & (NIS_RAMBO_PDF_ACTIVE | NIS_RAMBO_LAB_BOOST)) != 0;          // TAU only matters with PDFs
   const bool has_cuts = dh->pT_mincut > 0. || dh->delR_mincut > 0. || dh->rap_maxcut > 0.;
-  const bool need_gen = dh->bisect_levels > 0 || (!r_col_major && r_ld != k.ncol);
+  const bool need_gen = dh->bisect_levels > 0;
   const int mode = need_gen ? 3 : has_cuts ? 2 : has_pdf ? 1 : 0;
 #define RB_LAUNCH(NFV, M) \
   hipLaunchKernelGGL((k_rambo<NFV, M>), dim3(grid), dim3(RB_TPB), lds_bytes, s, k, r, (long)N, momenta, weight, (int*)status)
