@@ -159,6 +159,12 @@ int nis_integrand_moments(const double* planes, int64_t ld, int64_t N, int32_t d
                           int32_t f_kind, const double* f_params_host, double* fres_out, double* out4,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* f(x_i) of a built-in integrand for the rows of a row-major (N, d) matrix with row stride `row_stride` doubles: what
+ * the training loop evaluates as f(X) on the model output (manager.py:241-246; README.md:35-36 camel, manager.py:39-40
+ * normal).  f_params_host: 4 doubles (camel: a, b, s; normal: mu, sigma). */
+int nis_integrand_eval(int32_t f_kind, const double* f_params_host, const double* x, int64_t row_stride, int64_t N,
+                       int32_t d, double* out, void* stream);
+
 /* Streaming moments of a vector (optionally of the product a[i]*b[i], b may be NULL). */
 size_t nis_moments_workspace_bytes(void);
 int nis_moments(const double* a, const double* b, int64_t N, double* out4,

@@ -26,7 +26,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libn
 
 EXPORTS = ["nis_cell_param_count", "nis_cell_running_count", "nis_flow_create", "nis_flow_destroy",
            "nis_flow_workspace_bytes", "nis_flow_forward", "nis_integrate_steps", "nis_flow_backward_supported",
-           "nis_flow_bnsave_count", "nis_flow_forward_train", "nis_flow_backward_workspace_bytes", "nis_flow_backward", "nis_integrand_moments", "nis_moments_workspace_bytes",
+           "nis_flow_bnsave_count", "nis_flow_forward_train", "nis_flow_backward_workspace_bytes", "nis_flow_backward", "nis_integrand_moments", "nis_integrand_eval",
+           "nis_moments_workspace_bytes",
            "nis_moments", "nis_rambo_forward", "nis_prof_enable", "nis_prof_read", "nis_prof_disable", "nis_last_error", "nis_version", "nis_device_count"]
 
 
@@ -86,6 +87,8 @@ def lib():
     L.nis_flow_backward_workspace_bytes.argtypes = [vp, i64]
     L.nis_flow_backward.restype = i32
     L.nis_flow_backward.argtypes = [vp, vp, i64, i64, i32, C.POINTER(vp), vp, vp, C.POINTER(vp), vp, vp, sz, vp]
+    L.nis_integrand_eval.restype = i32
+    L.nis_integrand_eval.argtypes = [i32, C.POINTER(C.c_double), vp, i64, i64, i32, vp, vp]
     L.nis_integrand_moments.restype = i32
     L.nis_integrand_moments.argtypes = [vp, i64, i64, i32, C.POINTER(i32), i32, C.POINTER(C.c_double), vp, vp, vp, sz, vp]
     L.nis_moments_workspace_bytes.restype = sz

@@ -513,9 +513,10 @@ struct IntegrandArgs {
   double p[4];
 };
 
-__device__ __forceinline__ double eval_integrand(const IntegrandArgs& a, const double* planes, long ld, long i) {
+// element (column c, sample i) at base[c * cs + i * ss]: column planes (cs = ld, ss = 1) or row-major rows (cs = 1, ss = row stride)
+__device__ __forceinline__ double eval_integrand_at(const IntegrandArgs& a, const double* base, long cs, long ss, long i) {
   if (a.kind == NIS_F_CAMEL) {                                                  // README.md:35-36
-    const double x0 = planes[(size_t)a.out_col[0] * ld + i], x1 = planes[(size_t)a.out_col[1] * ld + i];
+    const double x0 = base[(size_t)a.out_col[0] * cs + i * ss], x1 = base[(size_t)a.out_col[1] * cs + i * ss];
     const double s2 = a.p[2] * a.p[2];
     const double e1 = -((x0 - a.p[0]) * (x0 - a.p[0]) + (x1 - a.p[0]) * (x1 - a.p[0])) / s2;
     const double e2 = -((x0 - a.p[1]) * (x0 - a.p[1]) + (x1 - a.p[1]) * (x1 - a.p[1])) / s2;
@@ -524,12 +525,22 @@ __device__ __forceinline__ double eval_integrand(const IntegrandArgs& a, const d
     const double mu = a.p[0], sg = a.p[1];
     double s = 0.0;
     for (int c = 0; c < a.d; ++c) {
-      const double x = planes[(size_t)a.out_col[c] * ld + i] - mu;
+      const double x = base[(size_t)a.out_col[c] * cs + i * ss] - mu;
       s += (x * x) / (2 * sg * sg);
     }
     return exp(-s) / (sg * sqrt(pow(2 * M_PI, (double)a.d)));
   }
   return 1.0;
+}
+__device__ __forceinline__ double eval_integrand(const IntegrandArgs& a, const double* planes, long ld, long i) {
+  return eval_integrand_at(a, planes, ld, 1, i);
+}
+
+// f(x) of a built-in integrand for the rows of a row-major (N, d) matrix (the training loop's f(X), manager.py:241-246)
+__global__ __launch_bounds__(NIS_TPB) void k_integrand_rows(const double* __restrict__ x, long rs, long N, IntegrandArgs a,
+                                                            double* __restrict__ out) {
+  const long stride = (long)gridDim.x * NIS_TPB;
+  for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < N; i += stride) out[i] = eval_integrand_at(a, x, 1, rs, i);
 }
 
 __global__ __launch_bounds__(NIS_TPB) void k_integrand_moments(const double* __restrict__ planes, long ld, long N, IntegrandArgs a,
@@ -644,6 +655,22 @@ extern "C" int nis_integrand_moments(const double* planes, int64_t ld, int64_t N
   }
   HIP_OK(hipGetLastError());
   hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(NIS_TPB), 0, s, (const double*)workspace, grid, out4, 0);
+  HIP_OK(hipGetLastError());
+  return NIS_OK;
+}
+
+extern "C" int nis_integrand_eval(int32_t f_kind, const double* f_params_host, const double* x, int64_t row_stride, int64_t N,
+                                  int32_t d, double* out, void* stream) {
+  if (!x || !out || N < 1 || d < 1 || d > NIS_MAX_DIM || row_stride < d) return NIS_E_ARG;
+  if (f_kind == NIS_F_CAMEL && d < 2) return NIS_E_ARG;
+  if (f_kind != NIS_F_CAMEL && f_kind != NIS_F_NORMAL && f_kind != NIS_F_ONE) return NIS_E_ARG;
+  IntegrandArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int c = 0; c < d; ++c) a.out_col[c] = c;
+  a.d = d;
+  a.kind = f_kind;
+  for (int k = 0; k < 4; ++k) a.p[k] = f_params_host ? f_params_host[k] : 0.0;
+  hipLaunchKernelGGL(k_integrand_rows, dim3(stream_grid(N)), dim3(NIS_TPB), 0, (hipStream_t)stream, x, (long)row_stride, (long)N, a, out);
   HIP_OK(hipGetLastError());
   return NIS_OK;
 }

@@ -35,24 +35,33 @@ __device__ __forceinline__ void bw_block_reduce(const double (&acc)[NACC], doubl
   }
 }
 
-// records -> one summed record per y-slice (one workgroup each, fixed order)
+// records -> one summed record per y-slice: a workgroup owns 4 elements and sums 64 interleaved slices of the records,
+// then an LDS tree -- fixed order (bitwise reproducible).  grid: (ceil(nacc / 4), y-slices).
 __global__ __launch_bounds__(NIS_TPB) void k_bwd_reduce(const double* __restrict__ part, int nparts, int nacc, double* __restrict__ out,
                                                         long part_ystride) {
-  __shared__ double sm[NIS_TPB];
+  __shared__ double sm[64][4];
+  const int el = threadIdx.x & 3, slice = threadIdx.x >> 2;
+  const int e = blockIdx.x * 4 + el;
   part += (size_t)blockIdx.y * part_ystride;
   out += (size_t)blockIdx.y * BNACC;
-  for (int a = 0; a < nacc; ++a) {
-    double t = 0.0;
-    for (int b = threadIdx.x; b < nparts; b += NIS_TPB) t += part[(size_t)b * BNACC + a];
-    sm[threadIdx.x] = t;
-    __syncthreads();
-    for (int s = NIS_TPB / 2; s > 0; s >>= 1) {
-      if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-      __syncthreads();
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  if (e < nacc) {
+    int b = slice;
+    for (; b + 192 < nparts; b += 256) {
+      t0 += part[(size_t)b * BNACC + e];
+      t1 += part[(size_t)(b + 64) * BNACC + e];
+      t2 += part[(size_t)(b + 128) * BNACC + e];
+      t3 += part[(size_t)(b + 192) * BNACC + e];
     }
-    if (threadIdx.x == 0) out[a] = sm[0];
+    for (; b < nparts; b += 64) t0 += part[(size_t)b * BNACC + e];
+  }
+  sm[slice][el] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  for (int h = 32; h > 0; h >>= 1) {
+    if (slice < h) sm[slice][el] += sm[slice + h][el];
     __syncthreads();
   }
+  if (slice == 0 && e < nacc) out[e] = sm[0][el];
 }
 
 // forward recompute of the hidden stack with the SAVED statistics; returns for layer `upto` (1..L):
@@ -422,12 +431,12 @@ static int bwd_run(const CellK& c, BwdK k, double* ws, double* gparams, hipStrea
     hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 8>), dim3(grid), dim3(NIS_TPB), 0, s, k);
   else
     hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 16>), dim3(grid), dim3(NIS_TPB), 0, s, k);
-  hipLaunchKernelGGL(k_bwd_reduce, dim3(1, 1), dim3(NIS_TPB), 0, s, (const double*)part, grid, 2 * WM, sums, 0L);
+  hipLaunchKernelGGL(k_bwd_reduce, dim3((2 * WM + 3) / 4, 1), dim3(NIS_TPB), 0, s, (const double*)part, grid, 2 * WM, sums, 0L);
   // last-layer weight / bias gradients (its own records, reduced per chunk)
   {
     const int gw = std::max(1, std::min(grid, 256));
     hipLaunchKernelGGL((k_bwd_wlast<WM>), dim3(gw, (unsigned)nch), dim3(NIS_TPB), 0, s, k);
-    hipLaunchKernelGGL(k_bwd_reduce, dim3(1, (unsigned)nch), dim3(NIS_TPB), 0, s, (const double*)part, gw, BRC * (WM + 1), wsum,
+    hipLaunchKernelGGL(k_bwd_reduce, dim3((BRC * (WM + 1) + 3) / 4, (unsigned)nch), dim3(NIS_TPB), 0, s, (const double*)part, gw, BRC * (WM + 1), wsum,
                        (long)BMAXB * BNACC);
   }
   for (int l = L; l >= 1; --l) {
@@ -435,7 +444,7 @@ static int bwd_run(const CellK& c, BwdK k, double* ws, double* gparams, hipStrea
     k.sums = sums + (size_t)(pass - 1) * BNACC;
     const int soff = (pass == 1) ? 0 : WM * WM;
     hipLaunchKernelGGL((k_cell_bwd_layer<WM>), dim3(grid), dim3(NIS_TPB), 0, s, k, l, soff);
-    hipLaunchKernelGGL(k_bwd_reduce, dim3(1, 1), dim3(NIS_TPB), 0, s, (const double*)part, grid, WM * WM + 2 * WM,
+    hipLaunchKernelGGL(k_bwd_reduce, dim3((WM * WM + 2 * WM + 3) / 4, 1), dim3(NIS_TPB), 0, s, (const double*)part, grid, WM * WM + 2 * WM,
                        sums + (size_t)pass * BNACC, 0L);
   }
   k.sums = sums + (size_t)L * BNACC;

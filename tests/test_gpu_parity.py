@@ -704,3 +704,22 @@ def test_affine_manager_trains_and_integrates():
     NF.sample_hook = None
     sig, err = NF.integrate(f, 5, 100000)
     assert np.isfinite(float(sig)) and float(err) > 0
+
+
+def test_builtin_integrands_on_rows_match_the_torch_expression_and_the_oracle():
+    """`nis_integrand_eval` (what the training loop's f(X) runs on) against the same formula in torch ops and NumPy, on
+    the strided view XJ[:, :-1] the manager passes."""
+    from nf_amd import integrands
+    torch.manual_seed(3)
+    for f, d in ((integrands.Camel(), 2), (integrands.Camel(0.7, 0.2, 0.3), 5), (integrands.Normal(0.5, 0.1, 8), 8),
+                 (integrands.Normal(0.4, 0.3, 3), 3)):
+        XJ = torch.rand(10007, d + 1, dtype=torch.double, device=dev())
+        x = XJ[:, :-1]
+        y = f(x)                                   # HIP kernel (float64 CUDA input, no grad)
+        xr = x.clone().requires_grad_(True)
+        y_t = f(xr)                                # differentiable input -> the torch expression
+        assert y_t.requires_grad and not y.requires_grad
+        np.testing.assert_allclose(t2n(y), t2n(y_t), rtol=1e-13, atol=1e-300)
+        ref = oflow.camel(t2n(x)) if isinstance(f, integrands.Camel) and d == 2 else None
+        if ref is not None:
+            np.testing.assert_allclose(t2n(y), ref, rtol=1e-13, atol=1e-300)

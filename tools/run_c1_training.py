@@ -23,4 +23,4 @@ print(f"training: {dt:.2f} s, {len(NF.history)} epochs, returned {res}, best_los
 t0 = time.perf_counter()
 sig, err = NF.integrate(f, 10, 100000, 0)
 torch.cuda.synchronize()
-print(f"integrate(10, 1e5): {float(sig):.6f} +- {float(err):.2e}  ({time.perf_counter() - t0:.3f} s)   truth 0.232279")
+print(f"integrate(10, 1e5): {float(sig):.6f} +- {float(err):.2e}  ({time.perf_counter() - t0:.3f} s)   truth 0.2323236")
