@@ -723,3 +723,40 @@ def test_builtin_integrands_on_rows_match_the_torch_expression_and_the_oracle():
         ref = oflow.camel(t2n(x)) if isinstance(f, integrands.Camel) and d == 2 else None
         if ref is not None:
             np.testing.assert_allclose(t2n(y), ref, rtol=1e-13, atol=1e-300)
+
+
+@pytest.mark.parametrize("kind,K,NN", [("pwquad", 4, [3, 3, 3]), ("pwquad", 16, [8, 8]), ("pwlin", 12, [5]), ("pwquad", 9, [32, 32])])
+def test_cell_is_a_monotone_bijection_of_the_unit_interval(kind, K, NN):
+    """Known answers that need no reference: for a FIXED conditioner input every transformed column
+    is a monotone map of [0,1) onto [0,1) whose derivative is the Jacobian factor, and the value at a bin edge is the
+    cumulative area up to that bin."""
+    from nf_amd.normalizing_flows.layers.coupling_cells import PWLin, PWQuad
+    torch.manual_seed(K)
+    cell = (PWQuad if kind == "pwquad" else PWLin)(2, 1, K, list(NN)).double()
+    with torch.no_grad():
+        for p in cell.parameters():
+            p.add_(0.4 * torch.randn_like(p))
+    cell = cell.to(dev()).eval()                                   # eval BN: the conditioner sees only xA
+    N = 20001
+    x = torch.empty(N, 3, dtype=torch.double, device=dev())
+    x[:, 0] = 0.3712                                               # fixed pass-through value -> one fixed spline
+    x[:, 1] = torch.linspace(0.0, 1.0 - 1e-6 if kind == "pwquad" else 1.0 - 1e-12, N, dtype=torch.double)
+    x[:, 2] = 1.0
+    y = cell(x)
+    yb, jf = t2n(y[:, 1]), t2n(y[:, 2])
+    xb = t2n(x[:, 1])
+    assert yb[0] == 0.0 and abs(yb[-1] - 1.0) < 2e-5
+    assert np.all(np.diff(yb) >= -1e-15) and np.all(jf > 0)
+    # dy/dx == Jacobian factor (central differences away from the knots of the spline)
+    num = (yb[2:] - yb[:-2]) / (xb[2:] - xb[:-2])
+    rel = np.abs(num - jf[1:-1]) / jf[1:-1]
+    assert np.quantile(rel, 0.98) < 5e-4
+    # integral of the Jacobian over the column = 1 (trapezoid rule on the fine grid)
+    # (PWLin's Jacobian is piecewise constant: the rule misplaces each of its K jumps by up to one grid step)
+    assert abs(np.trapezoid(jf, xb) - yb[-1]) < (1e-6 if kind == "pwquad" else 1e-3)
+    if kind == "pwlin":                                            # equal-width bins: the value at an edge k/K is the normalised prefix sum
+        params = {"c." + k_: t2n(v) for k_, v in cell.state_dict().items()}
+        Z = oflow.conditioner(np.array([[0.3712]]), params, "c", False).reshape(1, 1, K)
+        Q = np.exp(Z[0, 0])
+        edges = torch.tensor([[0.3712, k_ / K, 1.0] for k_ in range(K)], dtype=torch.double, device=dev())
+        np.testing.assert_allclose(t2n(cell(edges)[:, 1]), np.concatenate([[0.0], np.cumsum(Q)[:-1]]) / Q.sum(), rtol=1e-12, atol=1e-15)
