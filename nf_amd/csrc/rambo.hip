@@ -95,10 +95,15 @@ __device__ __forceinline__ void rb_boost(V4& p, double bx, double by, double bz)
   p.e = gamma * (p.e + bp);
 }
 
-__device__ __forceinline__ double rb_pseudorap(const V4& p) {                                                               // utils.py:151-157
-  const double pt = sqrt(p.x * p.x + p.y * p.y);
-  const double th = atan2(pt, p.z);
-  return (pt < RB_EPS && fabs(p.z) < RB_EPS) ? RB_HUGE : -log(tan(th / 2.));
+// eta = -log(tan(theta/2)), theta = atan2(pt, pz) (utils.py:151-157).  tan(theta/2) = pt / (|p| + pz) = (|p| - pz) / pt: the
+// form without cancellation is taken per sign of pz -- same value to ~1 ulp without atan2 and tan (~200 VALU instructions).
+__device__ __forceinline__ double rb_pseudorap(const V4& p) {
+  const double pt2 = p.x * p.x + p.y * p.y;
+  const double pt = sqrt(pt2);
+  const double pa = sqrt(pt2 + p.z * p.z);
+  double th2 = p.z >= 0.0 ? pt / (pa + p.z) : (pa - p.z) / pt;
+  th2 = fmin(fmax(th2, 6.123e-17), 1.633e16);               // pt == 0 exactly: the reference's tan(atan2(0, pz) / 2) stays finite too
+  return (pt < RB_EPS && fabs(p.z) < RB_EPS) ? RB_HUGE : -log(th2);
 }
 
 __device__ __forceinline__ double rb_delphi(const V4& a, const V4& b) {                                                     // utils.py:170-180
