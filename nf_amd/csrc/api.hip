@@ -1160,7 +1160,7 @@ extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t
     c.gb = gb;
     c.coef = coef;
     hipLaunchKernelGGL(k_pack, dim3(WM >= 16 ? 32 : 1), dim3(NIS_TPB), 0, s, c, (int)WM, params[ci], (const double*)nullptr, 0, wp, wlast,
-                       bias, gb, (double*)nullptr, 0);
+                       bias, gb, (double*)nullptr, cell_hidden_bias(cd) ? 1 : 0);
     HIP_OK(hipGetLastError());
     MfmaW mw;
     mw.wm_all = mw.wm_last = mw.bias_pad = nullptr;

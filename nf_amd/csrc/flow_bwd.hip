@@ -218,6 +218,24 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
 #pragma unroll
             for (int j = 0; j < WM; ++j) da[j] = fma(wl[(size_t)(row0 + K + 1 + q) * WM + j], dz, da[j]);
           }
+      } else if (KIND == NIS_AFFINE) {
+        // AffineCoupling (coupling_cells.py:56-68): rows [scale | shift][T]; u = 20 e^z0 x + relu(z1), y = atan(u) 2/pi,
+        // jf = 20 e^z0 / (u^2 + 1)  (the cell-wide factor 2/pi of the Jacobian is applied once, below)
+        const int rs = t, rh = c.T + t;
+        const double z1 = last_dot<WM>(wl, bias, rh, aL);
+        const double s0 = 20.0 * nis_exp(last_dot<WM>(wl, bias, rs, aL), etab);
+        const double u = xraw * s0 + (z1 > 0.0 ? z1 : 0.0);
+        const double q = 1.0 / (u * u + 1.0);
+        jf = s0 * q;
+        const double gjf = gJ * Jout / jf;
+        const double gu = gy * (q / (M_PI / 2)) - gjf * (2.0 * u * s0 * q * q);
+        gx = gu * s0;
+        const double dz0 = (gu * xraw + gjf * q) * s0;
+        const double dz1 = z1 > 0.0 ? gu : 0.0;
+        k.dzp[(size_t)rs * k.ld + i] = dz0;
+        k.dzp[(size_t)rh * k.ld + i] = dz1;
+#pragma unroll
+        for (int j = 0; j < WM; ++j) da[j] = fma(wl[(size_t)rs * WM + j], dz0, fma(wl[(size_t)rh * WM + j], dz1, da[j]));
       } else {
         // PWLin: Q_q = K e_q / tot, y = Q_b alpha + sum_{q<b} e_q / tot, jf = Q_b, alpha = x - b/K  (two streamed passes)
         const double ak = xraw * K;
@@ -250,6 +268,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
       k.g[(size_t)colp * k.ld + i] = gx;
       jfprod *= jf;
     }
+    if (KIND == NIS_AFFINE) jfprod *= 1.0 / (M_PI / 2);
     k.g[(size_t)c.jplane * k.ld + i] = gJ * jfprod;              // dL/dJ_in = dL/dJ_out * prod_t dy_t/dx_t
     // ---- through ReLU to BN_L's output; sums for BN_L
 #pragma unroll
@@ -357,7 +376,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_input(BwdK k, int sums_off
 //   sums: [pass 0 = head (BN_L sums) | pass 1 = layer L | ... | pass L = layer 1], each BNACC doubles;
 //   wsum: one BNACC record per chunk of BRC last-layer rows, [r][WM weights | bias].
 __global__ void k_bwd_scatter(CellK c, int WM, const double* __restrict__ sums, const double* __restrict__ wsum,
-                              double* __restrict__ gparams) {
+                              double* __restrict__ gparams, int hidden_bias) {
   const int L = c.L;
   size_t off = 0;
   const int tid = threadIdx.x, nth = blockDim.x;
@@ -375,6 +394,9 @@ __global__ void k_bwd_scatter(CellK c, int WM, const double* __restrict__ sums, 
     if (l < L) {                       // dW_l from layer pass l+1 (pass index L-l)
       const double* w = sums + (size_t)(L - l) * BNACC;
       for (int e = tid; e < O * F; e += nth) gparams[off + e] = w[(e / F) * WM + (e % F)];
+      if (hidden_bias) {                 // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0
+        for (int e = tid; e < O; e += nth) gparams[off + (size_t)O * F + e] = 0.0;
+      }
     } else {
       for (int e = tid; e < O * F; e += nth) {
         const int r = e / F, q = e % F;
@@ -382,13 +404,14 @@ __global__ void k_bwd_scatter(CellK c, int WM, const double* __restrict__ sums, 
       }
     }
     off += (size_t)O * F;
+    if (hidden_bias && l < L) off += O;
   }
   for (int r = tid; r < c.R; r += nth) gparams[off + r] = wsum[(size_t)(r / BRC) * BNACC + (r % BRC) * (WM + 1) + WM];
 }
 
 // ---------------------------------------------------------------------------------------------
 bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm) {
-  if (cd.kind == NIS_AFFINE) return false;       // AffineCoupling differentiates through the PyTorch re-evaluation for now
+  if (cd.kind == NIS_AFFINE) return wm == 4 || wm == 8;   // narrow AffineCoupling: fp64 VALU adjoint; wider: PyTorch re-evaluation
   if (wm == 16) return bwd_wide_supported<16>(cd);
   if (wm == 32) return bwd_wide_supported<32>(cd);
   if (wm == 64) return bwd_wide_supported<64>(cd);
@@ -404,7 +427,7 @@ size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N
   if (wm == 32) return bwd_wide_workspace_doubles<32>(cd, N);
   if (wm == 64) return bwd_wide_workspace_doubles<64>(cd, N);
   const int T = cd.d - cd.P;
-  const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.K);
+  const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K);
   const size_t nch = bwd_chunks(R);
   return (size_t)(2 * wm + R) * N + std::max<size_t>(1, nch) * BMAXB * BNACC + (size_t)(cd.n_hidden + 2) * BNACC + nch * BNACC;
 }
@@ -425,6 +448,8 @@ static int bwd_run(const CellK& c, BwdK k, double* ws, double* gparams, hipStrea
   const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : 16;
   if (c.kind == NIS_PWLIN)
     hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWLIN, WM, 4>), dim3(grid), dim3(NIS_TPB), 0, s, k);
+  else if (c.kind == NIS_AFFINE)
+    hipLaunchKernelGGL((k_cell_bwd_head<NIS_AFFINE, WM, 4>), dim3(grid), dim3(NIS_TPB), 0, s, k);
   else if (km == 4)
     hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 4>), dim3(grid), dim3(NIS_TPB), 0, s, k);
   else if (km == 8)
@@ -449,7 +474,8 @@ static int bwd_run(const CellK& c, BwdK k, double* ws, double* gparams, hipStrea
   }
   k.sums = sums + (size_t)L * BNACC;
   hipLaunchKernelGGL((k_cell_bwd_input<WM>), dim3(grid), dim3(NIS_TPB), 0, s, k, WM * WM);
-  hipLaunchKernelGGL(k_bwd_scatter, dim3(1), dim3(NIS_TPB), 0, s, c, WM, (const double*)sums, (const double*)wsum, gparams);
+  hipLaunchKernelGGL(k_bwd_scatter, dim3(1), dim3(NIS_TPB), 0, s, c, WM, (const double*)sums, (const double*)wsum, gparams,
+                     c.kind == NIS_AFFINE ? 1 : 0);
   return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
 }
 

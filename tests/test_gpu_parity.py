@@ -760,3 +760,41 @@ def test_cell_is_a_monotone_bijection_of_the_unit_interval(kind, K, NN):
         Q = np.exp(Z[0, 0])
         edges = torch.tensor([[0.3712, k_ / K, 1.0] for k_ in range(K)], dtype=torch.double, device=dev())
         np.testing.assert_allclose(t2n(cell(edges)[:, 1]), np.concatenate([[0.0], np.cumsum(Q)[:-1]]) / Q.sum(), rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("d,P,NN,n_cells", [(2, 1, [3, 3, 3], 2), (5, 2, [8, 8], 3), (6, 4, [4], 2), (4, 1, [7, 5], 3)])
+def test_hip_backward_affine_matches_torch_adjoint(d, P, NN, n_cells, monkeypatch):
+    """Narrow AffineCoupling models: hand-written adjoint (hidden-layer biases, [scale|shift][T] head) against autograd
+    through the stock-PyTorch re-evaluation."""
+    from nf_amd.normalizing_flows.manager import AffineManager
+    torch.manual_seed(d * 11 + P)
+    NF = AffineManager(n_flow=d)
+    NF.create_model(P, n_cells, list(NN), 1)
+    model = NF._model.train()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    assert model.engine().backward_supported()
+    N = 2777
+    x0 = torch.rand(N, d + 1, dtype=torch.double, device=dev())
+    x0[:, d] += 0.5
+    R = torch.randn(N, d + 1, dtype=torch.double, device=dev())
+
+    def grads(force_torch):
+        if force_torch:
+            monkeypatch.setenv("NF_AMD_TORCH_ADJOINT", "1")
+        else:
+            monkeypatch.delenv("NF_AMD_TORCH_ADJOINT", raising=False)
+        for p in model.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        out = model(x)
+        (out * R).sum().backward()
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in model.parameters()]
+
+    o_h, gx_h, gp_h = grads(False)
+    o_t, gx_t, gp_t = grads(True)
+    np.testing.assert_allclose(t2n(o_h), t2n(o_t), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(t2n(gx_h), t2n(gx_t), rtol=1e-7, atol=1e-9 * float(gx_t.abs().max()))
+    for (name, _), a, b in zip(model.named_parameters(), gp_h, gp_t):
+        np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-7, atol=1e-9 * max(1.0, float(b.abs().max())), err_msg=name)
