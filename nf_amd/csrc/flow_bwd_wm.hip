@@ -171,7 +171,7 @@ __device__ __forceinline__ void bww_stage(const BwdK& k, double* lds_bn, int* ld
 // ---------------------------------------------------------------------------------------------
 // head: recompute the cell, bijector adjoint -> dZ planes, d a_L = W_L^T dZ, dy_L, sums of BN_L, a_L planes
 template <int KIND, int KM, bool KEXACT>
-__global__ __launch_bounds__(TPB, WPS) void k_bwd_head_w(BwdK k, BwdW w) {
+__global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, BwdW w) {
   extern __shared__ double mf_dyn[];                 // per wave: [NCB*out rows][16 samples] of exp(Z)
   __shared__ double lds_bn[BNLDS];
   __shared__ int lds_plane[NIS_MAX_DIM];
@@ -718,7 +718,7 @@ Plan plan_for(int R, long N) {
 template <>
 bool bwd_wide_supported<NIS_WM>(const nis_cell_desc& cd) {
   const int out = cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.K;
-  if (cd.kind == NIS_PWQUAD && cd.K > BKMAX) return false;
+  if (cd.kind == NIS_PWQUAD && cd.K > 32) return false;        // the in-place dZ arrays (2K + 1 doubles) stay in registers
   const size_t fixed = (size_t)(BNLDS + NW * SREC + 64) * sizeof(double) + NIS_MAX_DIM * sizeof(int) + 1024;   // static LDS of the head
   return ring_bytes(out) + fixed <= 160 * 1024;
 }
@@ -752,7 +752,7 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   double* ghid = glast + (size_t)p.ngl * GREC;
   k.part = part;
   const size_t ring = ring_bytes(c.out);
-  const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : 16;
+  const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : c.K <= 16 ? 16 : 32;
 #define NIS_HEAD(KIND, KMV, EX) hipLaunchKernelGGL((k_bwd_head_w<KIND, KMV, EX>), dim3(p.nb), dim3(TPB), ring, s, k, w)
   if (c.kind == NIS_PWLIN)
     NIS_HEAD(NIS_PWLIN, 4, false);
@@ -766,8 +766,10 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
     NIS_HEAD(NIS_PWQUAD, 4, false);
   else if (km == 8)
     NIS_HEAD(NIS_PWQUAD, 8, false);
-  else
+  else if (km == 16)
     NIS_HEAD(NIS_PWQUAD, 16, false);
+  else
+    NIS_HEAD(NIS_PWQUAD, 32, false);
 #undef NIS_HEAD
   hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + 3) / 4, 1), dim3(TPB), 0, s, (const double*)part, p.nb, SREC, sums);
   // dW_L = dZ a_L^T, db_L = row sums of dZ

@@ -177,7 +177,9 @@ WIDE_BWD_CASES = [("pwquad", dict(d=16, n_cells=8, K=16, NN=[32, 32, 32])),     
                   ("pwquad", dict(d=6, n_cells=3, K=7, NN=[16, 12])),
                   ("pwquad", dict(d=5, n_cells=2, K=3, NN=[20])),
                   ("pwlin", dict(d=7, P=3, n_cells=3, K=21, NN=[64, 48], roll=2)),
-                  ("pwquad", dict(d=4, n_cells=2, K=9, NN=[40, 64, 33]))]
+                  ("pwquad", dict(d=4, n_cells=2, K=9, NN=[40, 64, 33])),
+                  ("pwquad", dict(d=8, n_cells=2, K=32, NN=[32, 32, 32])),            # golden cell shape (8, 4, 32, [32]*3)
+                  ("pwquad", dict(d=5, n_cells=2, K=23, NN=[16]))]
 
 
 @pytest.mark.parametrize("kind,c", WIDE_BWD_CASES, ids=[f"{k}-d{c['d']}-K{c['K']}-NN{'x'.join(map(str, c['NN']))}" for k, c in WIDE_BWD_CASES])
