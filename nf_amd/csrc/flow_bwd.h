@@ -6,7 +6,7 @@
 #define BNACC 80              // record length (>= WM*WM + 2*WM for WM = 8, >= BRC*(WM+1))
 #define BRC 8                 // rows of the last layer per wlast chunk
 #define BMAXB 1024            // max workgroups of an adjoint launch
-#define BKMAX 16              // max PWQuad bins handled here
+#define BKMAX 32              // max PWQuad bins of the adjoint kernels (2K + 1 in-place dZ values per lane)
 
 struct BwdK {
   CellK c;                    // same per-cell view as the forward (in_plane, sizes, packed weights)

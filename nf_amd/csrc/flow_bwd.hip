@@ -169,43 +169,47 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
         const double galpha = gy * jf * Wb + gjf * D;
         gx = clamped ? 0.0 : galpha / Wb;
         const double gleft = -galpha / Wb;
-        // gradients w.r.t. the normalised heights v (kept in gv) and widths w (in gw)
-        double gv[KM + 1], gw[KM];
-#pragma unroll
-        for (int q = 0; q < KM + 1; ++q) gv[q] = 0.0;
-#pragma unroll
-        for (int q = 0; q < KM; ++q) {
-          gw[q] = 0.0;
-          if (q < K) {
-            const bool below = q < b, hit = q == b;
-            // shift = sum_{q<b} (v_q + v_{q+1})/2 w_q ;  left = sum_{q<b} w_q
-            gw[q] += below ? gy * (V[q] + V[q + 1]) / 2 + gleft : 0.0;
-            gv[q] += below ? gy * W[q] / 2 : 0.0;
-            gv[q + 1] += below ? gy * W[q] / 2 : 0.0;
-            // the bin itself: y = a^2/2 D w_b + a v_b w_b + shift,  jf = v_b + a D,  a = (x - left)/w_b
-            gw[q] += hit ? gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb : 0.0;
-            gv[q] += hit ? gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha) : 0.0;
-            gv[q + 1] += hit ? gy * alpha * alpha / 2 * Wb + gjf * alpha : 0.0;
-          }
-        }
-        // through v = eV/area(eV, w) and w = softmax(zW)
-        double S = 0.0;
-#pragma unroll
-        for (int q = 0; q < KM + 1; ++q)
-          if (q <= K) S += gv[q] * V[q];
-        double Sw = 0.0;
-#pragma unroll
-        for (int q = 0; q < KM; ++q)
-          if (q < K) {
-            gw[q] -= S * (V[q] + V[q + 1]) / 2;
-            Sw += gw[q] * W[q];
-          }
+        // Gradients w.r.t. the normalised heights v_q and widths w_q are sparse in q (bins below the hit, the hit, its
+        // right edge): re-formed on the fly in each of the three passes instead of being kept in arrays
+        //   gv(q) = [q-1 < b] gy w_{q-1}/2 + [q < b] gy w_q/2 + [q == b] A0 + [q == b+1] A1
+        //   gw0(q) = [q < b] (gy (v_q + v_{q+1})/2 + gleft) + [q == b] B0
+        const double hgy = gy / 2;
+        const double A0 = gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha);
+        const double A1 = gy * alpha * alpha / 2 * Wb + gjf * alpha;
+        const double B0 = gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb;
+#define NIS_GV(q, wm1, wq) (((q) >= 1 && (q) - 1 < b ? hgy * (wm1) : 0.0) + ((q) < b ? hgy * (wq) : 0.0) + ((q) == b ? A0 : 0.0) + ((q) == b + 1 ? A1 : 0.0))
+#define NIS_GW0(q) (((q) < b ? hgy * (V[q] + V[(q) + 1]) + gleft : 0.0) + ((q) == b ? B0 : 0.0))
+        double S = 0.0;                                    // through v = eV / area: S = sum_q gv(q) v_q
 #pragma unroll
         for (int q = 0; q < KM + 1; ++q)
           if (q <= K) {
-            const double wl_ = (q >= 1) ? W[q >= 1 ? q - 1 : 0] : 0.0;
-            const double wr_ = (q < K && q < KM) ? W[q < KM ? q : 0] : 0.0;
-            const double dz = gv[q] * V[q] - S * V[q] * (wl_ + wr_) / 2;
+            const double wm1 = q >= 1 ? W[q >= 1 ? q - 1 : 0] : 0.0;
+            const double wq = (q < KM && q < K) ? W[q < KM ? q : 0] : 0.0;
+            S += NIS_GV(q, wm1, wq) * V[q];
+          }
+        double Sw = 0.0;                                   // through w = softmax: Sw = sum_q gw(q) w_q
+#pragma unroll
+        for (int q = 0; q < KM; ++q)
+          if (q < K) Sw += (NIS_GW0(q) - S * (V[q] + V[q + 1]) / 2) * W[q];
+        // dZ in place (height rows into V, width rows into W), then rows -> planes and d a_L += W_L^T dZ
+        double wprev = 0.0;
+#pragma unroll
+        for (int q = 0; q < KM + 1; ++q)
+          if (q <= K) {
+            const bool hasw = q < KM && q < K;
+            const double wq = hasw ? W[q < KM ? q : 0] : 0.0;
+            const double vq = V[q];
+            const double dzv = NIS_GV(q, wprev, wq) * vq - S * vq * (wprev + wq) / 2;
+            if (hasw) W[q < KM ? q : 0] = wq * (NIS_GW0(q) - S * (vq + V[q + 1]) / 2 - Sw);
+            V[q] = dzv;
+            wprev = wq;
+          }
+#undef NIS_GV
+#undef NIS_GW0
+#pragma unroll
+        for (int q = 0; q < KM + 1; ++q)
+          if (q <= K) {
+            const double dz = V[q];
             k.dzp[(size_t)(row0 + q) * k.ld + i] = dz;
 #pragma unroll
             for (int j = 0; j < WM; ++j) da[j] = fma(wl[(size_t)(row0 + q) * WM + j], dz, da[j]);
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
 #pragma unroll
         for (int q = 0; q < KM; ++q)
           if (q < K) {
-            const double dz = W[q] * (gw[q] - Sw);
+            const double dz = W[q];
             k.dzp[(size_t)(row0 + K + 1 + q) * k.ld + i] = dz;
 #pragma unroll
             for (int j = 0; j < WM; ++j) da[j] = fma(wl[(size_t)(row0 + K + 1 + q) * WM + j], dz, da[j]);
@@ -416,7 +420,7 @@ bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm) {
   if (wm == 32) return bwd_wide_supported<32>(cd);
   if (wm == 64) return bwd_wide_supported<64>(cd);
   if (wm != 4 && wm != 8) return false;
-  if (cd.kind == NIS_PWQUAD) return cd.K <= BKMAX;
+  if (cd.kind == NIS_PWQUAD) return cd.K <= 32;
   return cd.K <= NIS_MAX_BINS;
 }
 
@@ -445,7 +449,7 @@ static int bwd_run(const CellK& c, BwdK k, double* ws, double* gparams, hipStrea
   k.part = part;
   const int grid = (int)std::max<long>(1, std::min<long>(BMAXB, (N + NIS_TPB - 1) / NIS_TPB));
   const int L = c.L;
-  const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : 16;
+  const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : c.K <= 16 ? 16 : 32;
   if (c.kind == NIS_PWLIN)
     hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWLIN, WM, 4>), dim3(grid), dim3(NIS_TPB), 0, s, k);
   else if (c.kind == NIS_AFFINE)
@@ -454,8 +458,10 @@ static int bwd_run(const CellK& c, BwdK k, double* ws, double* gparams, hipStrea
     hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 4>), dim3(grid), dim3(NIS_TPB), 0, s, k);
   else if (km == 8)
     hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 8>), dim3(grid), dim3(NIS_TPB), 0, s, k);
-  else
+  else if (km == 16)
     hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 16>), dim3(grid), dim3(NIS_TPB), 0, s, k);
+  else
+    hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 32>), dim3(grid), dim3(NIS_TPB), 0, s, k);
   hipLaunchKernelGGL(k_bwd_reduce, dim3((2 * WM + 3) / 4, 1), dim3(NIS_TPB), 0, s, (const double*)part, grid, 2 * WM, sums, 0L);
   // last-layer weight / bias gradients (its own records, reduced per chunk)
   {

@@ -132,6 +132,7 @@ def test_hip_backward_general_narrow_models(monkeypatch):
     """Adjoint kernels on manager-built models with several transformed columns, masks, width-8 conditioners."""
     from nf_amd.normalizing_flows.manager import PWLinManager, PWQuadManager
     cases = [("pwquad", dict(d=5, n_cells=2, K=6, NN=[8, 8])), ("pwquad", dict(d=7, n_cells=3, K=16, NN=[6])),
+             ("pwquad", dict(d=2, n_cells=2, K=32, NN=[3, 3, 3])), ("pwquad", dict(d=4, n_cells=4, K=27, NN=[8])),
              ("pwquad", dict(d=9, n_cells=4, K=5, NN=[7, 4])), ("pwlin", dict(d=3, P=1, n_cells=3, K=33, NN=[5, 5], roll=1)),
              ("pwlin", dict(d=6, P=4, n_cells=2, K=128, NN=[8], roll=2))]
     for kind, c in cases:
