@@ -133,7 +133,7 @@ int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_b
 
 /* Training forward + hand-written adjoint (replaces loss.backward() through the flow, manager.py:275-278, for the
  * cell class the adjoint kernels cover: conditioner widths and pass-through size <= 64 (<= 8: fp64 VALU kernels,
- * wider: v_mfma_f64_16x16x4_f64 kernels), PWQuad n_bins <= 16 (<= 32 on the wide kernels), PWLin any n_bins whose LDS
+ * wider: v_mfma_f64_16x16x4_f64 kernels), PWQuad n_bins <= 32, PWLin any n_bins whose LDS
  * image fits, any number of
  * transformed columns; nis_flow_backward_supported tells).
  *   nis_flow_forward_train: train-mode forward that keeps every cell's input: planes_hist holds n_cells+1 plane

@@ -1,5 +1,5 @@
 // Hand-written adjoint (backward) of a coupling cell with a narrow conditioner (register width WM = 4 or 8, any
-// number of transformed columns, PWQuad n_bins <= 16, PWLin any n_bins), train-mode BatchNorm.  Wider conditioners
+// number of transformed columns, PWQuad n_bins <= 32, PWLin any n_bins, AffineCoupling), train-mode BatchNorm.  Wider conditioners
 // (WM = 16 / 32 / 64) run the same chain on the f64 matrix cores: flow_bwd_wm.hip.
 //
 // Reverse of:  BN_0 -> Lin_0 -> [BN_l -> ReLU -> Lin_l]_{l=1..L} -> exp / normalise -> quadratic (linear) CDF, J *= dy/dx

@@ -3,7 +3,7 @@
 Forward values ALWAYS come from the HIP kernels.  Gradients (needed only by
 `_train_variance_forward_seq`, /root/reference/nisrep/normalizing_flows/manager.py:275-280):
   * models whose cells are all in the class the adjoint kernels cover (nf_amd/csrc/flow_bwd.hip: conditioner widths and
-    pass-through size <= 8 on the fp64 VALU; flow_bwd_wm.hip: widths 9..64 on the f64 matrix cores, PWQuad n_bins <= 32; narrow: PWQuad n_bins <= 16,
+    pass-through size <= 8 on the fp64 VALU; flow_bwd_wm.hip: widths 9..64 on the f64 matrix cores; PWQuad n_bins <= 32,
     PWLin any n_bins whose LDS image fits) use the hand-written HIP backward (`nis_flow_forward_train` +
     `nis_flow_backward`);
   * every other model (PWQuad n_bins > 16, AffineCoupling wider than 8) re-evaluates the same cells with stock PyTorch-ROCm ops on the GPU inside
