@@ -801,3 +801,28 @@ def test_hip_backward_affine_matches_torch_adjoint(d, P, NN, n_cells, monkeypatc
     np.testing.assert_allclose(t2n(gx_h), t2n(gx_t), rtol=1e-7, atol=1e-9 * float(gx_t.abs().max()))
     for (name, _), a, b in zip(model.named_parameters(), gp_h, gp_t):
         np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-7, atol=1e-9 * max(1.0, float(b.abs().max())), err_msg=name)
+
+
+def test_experiment_driver_reports_like_the_reference(tmp_path, monkeypatch):
+    """`nisrep.utils.experiment_mg.pro(para)` (experiment_mg.py:12-124): same para keys, queue tuple and log.txt lines."""
+    import queue as queue_mod
+    from nf_amd import integrands
+    from nisrep.utils import experiment_mg
+    monkeypatch.setattr(experiment_mg, "epoch_length", 12, raising=False)
+    import nf_amd.utils.experiment_mg as impl
+    monkeypatch.setattr(impl, "epoch_length", 12)
+    q = queue_mod.Queue()
+    torch.manual_seed(1)
+    para = dict(n_flow=2, n_bins=4, NN_width=3, NN_length=3, dev=0, lr=2e-3, weight_decay=1e-4, var_n=20000, batch_size=4000, pt=3,
+                q=q, id=7, f=integrands.Camel(), logdir=str(tmp_path), log=True)
+    impl.pro(para)
+    res = q.get_nowait()
+    assert len(res) == 14 and res[8] == "NIS" and res[10] == 7 and res[1] is None
+    assert np.isfinite(res[11]) and np.isfinite(res[12]) and res[13] > 0
+    text = (tmp_path / "7" / "log.txt").read_text()
+    for needle in ("Started", "Create Model", "Start training", "End training", "Final Variance:", "Post training integrate:",
+                   "Unweighting efficiency:", "Initial loss", "Best loss relative", "Evaluations", "Epoch"):
+        assert needle in text, needle
+    eff = float(text.split("Unweighting efficiency: ")[1].split("\n")[0])
+    assert 0.0 < eff <= 1.0
+    assert (tmp_path / "7" / "torch").exists() and (tmp_path / "7" / "torch_int").exists()     # the manager's checkpoints

@@ -144,6 +144,11 @@ def test_affine_cell_param_count_matches_abi():
     assert L.nis_cell_running_count(ctypes.byref(d)) == sum(getattr(bn, n).numel() for bn, n in rs)
 
 
+def test_experiment_driver_import_path():
+    from nisrep.utils.experiment_mg import epoch_length, pro
+    assert callable(pro) and epoch_length == 800
+
+
 def test_nisrep_import_paths():
     import importlib
     mgr = importlib.import_module("nisrep.normalizing_flows.manager")
