@@ -116,7 +116,15 @@ class BasicManager(ModelAPI):
             return self.sample_hook(n, self.n_flow, dtype, stage).to(dev)
         return torch.rand(n, self.n_flow, dtype=dtype, device=dev)
 
+    def _stock_input(self):
+        """True when `format_input` is the stock AddJacobian with a unit Jacobian: the HIP forward then implies that
+        column instead of receiving an (N, d+1) tensor whose last column was copied from the host (layers.py:75-77)."""
+        fi = self.format_input
+        return type(fi) is AddJacobian and fi.jacobian_value.numel() == 1 and float(fi.jacobian_value) == 1.0
+
     def _forward(self, w, dev):
+        if self._stock_input() and isinstance(self.model, FlowSequential):
+            return self.model.forward_raw(w.to(dev))
         return self.model(self.format_input(w, dev))
 
     # ------------------------------------------------------------------ training
@@ -393,7 +401,10 @@ class BasicManager(ModelAPI):
                 out[i] = hip_moments(f.from_planes(res["planes"], eng.out_col, neval), res["planes"][eng.d])
                 continue
             with torch.no_grad():
-                XJ = model(self.format_input(w, dev)).detach()
+                if self._stock_input() and isinstance(model, FlowSequential):
+                    XJ = model.flow_forward(w, want_xj=True)["xj"]
+                else:
+                    XJ = model(self.format_input(w, dev)).detach()
                 out[i] = hip_moments(f(XJ[:, :-1]), XJ[:, -1])
         return out
 

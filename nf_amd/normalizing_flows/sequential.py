@@ -53,6 +53,11 @@ class FlowSequential(torch.nn.Sequential):
         """x = format_input(w): (N, d+1) with the Jacobian column last -> XJ (N, d+1)."""
         return run_flow(self.engine(), list(self.children()), x, has_jac=True, train=self.training)
 
+    def forward_raw(self, w):
+        """XJ for raw samples w (N, d) with the unit Jacobian of AddJacobian implied (layers.py:75-77): same result as
+        `self(format_input(w))` without assembling the (N, d+1) input; differentiable like `forward`."""
+        return run_flow(self.engine(), list(self.children()), w, has_jac=False, train=self.training)
+
     def flow_forward(self, w, want_xj=False, want_bins=False):
         """No-grad fast path on raw samples w (N,d): skips the AddJacobian concat, leaves the result in
         column planes.  Returns the engine's dict (planes / xj / bins / status)."""

@@ -19,7 +19,7 @@ for mode in ("hip", "torch"):
     def step():
         for p in NF._model.parameters():
             p.grad = None
-        XJ = NF._model(NF.format_input(w, dev))
+        XJ = NF._forward(w, dev)                       # what _train_variance_forward_seq calls
         fres = f(XJ[:, :-1].detach()) * XJ[:, -1]
         loss = hip_var(fres)
         loss.backward()

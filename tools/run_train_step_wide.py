@@ -39,7 +39,7 @@ for name in which:
         def step():
             for p in NF._model.parameters():
                 p.grad = None
-            XJ = NF._model(NF.format_input(w, dev))
+            XJ = NF._forward(w, dev)                       # what _train_variance_forward_seq calls
             fres = torch.exp(-((XJ[:, :-1].detach() - 0.5) ** 2).sum(-1) / 0.5) * XJ[:, -1]
             loss = hip_var(fres)
             loss.backward()
