@@ -465,7 +465,7 @@ static int bwd_run(const CellK& c, BwdK k, double* ws, double* gparams, hipStrea
   hipLaunchKernelGGL(k_bwd_reduce, dim3((2 * WM + 3) / 4, 1), dim3(NIS_TPB), 0, s, (const double*)part, grid, 2 * WM, sums, 0L);
   // last-layer weight / bias gradients (its own records, reduced per chunk)
   {
-    const int gw = std::max(1, std::min(grid, 256));
+    const int gw = grid;                 // as many workgroups as the chain kernels: the reduction is issue- and latency-bound
     hipLaunchKernelGGL((k_bwd_wlast<WM>), dim3(gw, (unsigned)nch), dim3(NIS_TPB), 0, s, k);
     hipLaunchKernelGGL(k_bwd_reduce, dim3((BRC * (WM + 1) + 3) / 4, (unsigned)nch), dim3(NIS_TPB), 0, s, (const double*)part, gw, BRC * (WM + 1), wsum,
                        (long)BMAXB * BNACC);
