@@ -826,3 +826,43 @@ def test_experiment_driver_reports_like_the_reference(tmp_path, monkeypatch):
     eff = float(text.split("Unweighting efficiency: ")[1].split("\n")[0])
     assert 0.0 < eff <= 1.0
     assert (tmp_path / "7" / "torch").exists() and (tmp_path / "7" / "torch_int").exists()     # the manager's checkpoints
+
+
+@pytest.mark.parametrize("K,NN", [(4, [3, 3, 3]), (8, [3, 3]), (16, [2]), (5, [3, 3, 3]), (4, [4, 4])])
+def test_batched_integrate_small_ragged_batches(K, NN):
+    """Tiny / ragged batch sizes through the batched integrate path (two-column ingest, folded + 3-wide + compile-time
+    specialised kernels, record merge in the consumers' prologue) against the oracle: moments of every batch and the
+    running statistics after G train-mode batches applied in order."""
+    from nf_amd import integrands
+    from nf_amd.normalizing_flows.manager import PWQuadManager
+    torch.manual_seed(K)
+    NF = PWQuadManager(n_flow=2)
+    NF.create_model(2, K, list(NN))
+    with torch.no_grad():
+        for p in NF._model.parameters():
+            p.add_(0.2 * torch.randn_like(p))
+    f = integrands.Camel()
+    steps = oflow.plan_pwquad(2, 2, K)
+    for train in (True, False):
+        NF.best_model.train(train)
+        for N in (2, 3, 63, 65, 257, 513, 1025, 4099):
+            for G in (1, 3, 16):
+                sd0 = {k: v.clone() for k, v in NF.best_model.state_dict().items()}
+                cur = {k: t2n(v) for k, v in sd0.items()}
+                w = torch.rand(G, N, 2, device=dev()).to(torch.float32)
+                out = torch.zeros(G, 4, dtype=torch.double, device=dev())
+                NF.best_model.engine().integrate_steps(w, train, f.nis_kind, f.nis_params, out)
+                got = t2n(out)
+                for g in range(G):
+                    upd = {}
+                    XJ = oflow.model_forward(t2n(w[g]).astype(np.float64), cur, steps, train, upd)
+                    cur.update(upd)
+                    v = oflow.camel(XJ[:, :2]) * XJ[:, 2]
+                    ref = np.array([N, v.mean(), ((v - v.mean()) ** 2).sum(), v.max()])
+                    np.testing.assert_allclose(got[g], ref, rtol=2e-9, atol=1e-12, err_msg=f"train={train} N={N} G={G} g={g}")
+                if train:
+                    sd1 = NF.best_model.state_dict()
+                    for k_, v_ in cur.items():
+                        if "running" in k_:
+                            np.testing.assert_allclose(t2n(sd1[k_]), v_, rtol=1e-9, atol=1e-13, err_msg=f"{k_} N={N} G={G}")
+                NF.best_model.load_state_dict(sd0)
