@@ -866,3 +866,25 @@ def test_batched_integrate_small_ragged_batches(K, NN):
                         if "running" in k_:
                             np.testing.assert_allclose(t2n(sd1[k_]), v_, rtol=1e-9, atol=1e-13, err_msg=f"{k_} N={N} G={G}")
                 NF.best_model.load_state_dict(sd0)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 127, 128, 129, 257, 1001])
+def test_rambo_small_and_ragged_batches_every_kernel_mode(N):
+    """The four compile-time modes of k_rambo (plain, PDF, PDF + cuts, lattice bisection) and column-plane input on batch
+    sizes around the 128-sample tile (never 4: reference quirk Q15) against the oracle."""
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    rng = np.random.default_rng(100 + N)
+    for n, final, pdf, cuts, levels in ((4, [100.] * 4, False, (-1, -1, -1), 0), (4, [30., 10., 0., 5.], True, (0, 0, -1), 0),
+                                        (5, [0.] * 5, True, (15., 0.4, 3.0), 0), (3, [20.] * 3, False, (-1, -1, -1), 120)):
+        init = [0., 0.] if pdf else [100., 100.]
+        E = 13000. if pdf else 1000.
+        r = rng.random((N, 3 * n - 4 + (2 if pdf else 0)))
+        ref_m, ref_w = orambo.generate_kinematics(init, final, E, r, *cuts, pdf_active=pdf, tau=True)
+        gen = FlatInvertiblePhasespace(init, final, pdf=None, pdf_active=pdf, tau=True)
+        gen.bisect_levels = levels
+        mom, wgt = gen.generateKinematics_batch(E, torch.as_tensor(r).to(dev()), *cuts)
+        assert mom.shape == (N, n + 2, 4) and wgt.shape == (N,)
+        same = (t2n(wgt) == 0) == (ref_w == 0)
+        assert same.all() or N > 100 and (~same).sum() <= 1
+        np.testing.assert_allclose(t2n(mom), ref_m, rtol=1e-8, atol=1e-9 * E, err_msg=f"n={n} pdf={pdf}")
+        np.testing.assert_allclose(t2n(wgt)[same], ref_w[same], rtol=1e-8, err_msg=f"n={n} pdf={pdf}")
