@@ -243,7 +243,17 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     double wtot = wgt * w_ps;
 
     // ---- sequential two-body decays (:223-278)
-    V4 mom[NF + 2];
+    // MODE 0 hands every finished leg straight to the LDS output image (nothing reads the momenta again: no lab boost, no
+    // cuts), which frees ~8 (n + 2) registers; the other modes keep them for the lab boost / cut observables.
+    constexpr bool STREAM = MODE == 0;
+    double* const row = rb_lds + tid * (LM + 1);     // +1: odd row stride -> conflict-free column writes
+    auto put_leg = [&](int l, const V4& v) {
+      row[4 * l + 0] = v.e;
+      row[4 * l + 1] = v.x;
+      row[4 * l + 2] = v.y;
+      row[4 * l + 3] = v.z;
+    };
+    V4 mom[STREAM ? 1 : NF + 2];
     V4 Q = {M[0], 0., 0., 0.};
     M[NF - 1] = k.d.final_masses[NF - 1];
     bool bad_boost = false;
@@ -263,36 +273,48 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
       const double iQe = 1.0 / Q.e;                                                 // boostVector_t: Q_space / Q_0 (utils.py:36)
       rb_boost(p, Q.x * iQe, Q.y * iQe, Q.z * iQe);
       rb_set_square(p, m2);
-      mom[2 + c] = p;
+      if (STREAM) {
+        if (momenta) put_leg(2 + c, p);
+      } else {
+        mom[2 + c] = p;
+      }
       Q.e -= p.e;
       Q.x -= p.x;
       Q.y -= p.y;
       Q.z -= p.z;
       rb_set_square(Q, M[c + 1] * M[c + 1]);
     }
-    mom[NF + 1] = Q;
+    if (STREAM) {
+      if (momenta) put_leg(NF + 1, Q);
+    } else {
+      mom[NF + 1] = Q;
+    }
     if (bad_boost && live) atomicOr(status, 8);
 
     // ---- initial state (:408-441)
+    V4 in0, in1;
     if (k.d.initial_masses[0] == 0. || k.d.initial_masses[1] == 0.) {
-      mom[0] = {E / 2.0, 0., 0., E / 2.0};
-      mom[1] = {E / 2.0, 0., 0., -(E / 2.0)};
+      in0 = {E / 2.0, 0., 0., E / 2.0};
+      in1 = {E / 2.0, 0., 0., -(E / 2.0)};
     } else {
       const double M1 = k.d.initial_masses[0] * k.d.initial_masses[0], M2 = k.d.initial_masses[1] * k.d.initial_masses[1];
       const double E2_ = E * E;
       const double E1 = (E2_ + M1 - M2) / E, E2 = (E2_ - M1 + M2) / E;
       const double Z = sqrt(E2_ * E2_ - 2 * E2_ * M1 - 2 * E2_ * M2 + M1 * M1 - 2 * M1 * M2 + M2 * M2) / E;
-      mom[0] = {E1 / 2.0, 0., 0., Z / 2.0};
-      mom[1] = {E2 / 2.0, 0., 0., -(Z / 2.0)};
+      in0 = {E1 / 2.0, 0., 0., Z / 2.0};
+      in1 = {E2 / 2.0, 0., 0., -(Z / 2.0)};
+    }
+    if (!STREAM) {
+      mom[0] = in0;
+      mom[1] = in1;
     }
     if (momenta) {                                   // COM-frame copy is what the reference returns (:282,308)
-      double* row = rb_lds + tid * (LM + 1);         // +1: odd row stride -> conflict-free column writes
+      if (STREAM) {
+        put_leg(0, in0);
+        put_leg(1, in1);
+      } else {
 #pragma unroll
-      for (int l = 0; l < NF + 2; ++l) {
-        row[4 * l + 0] = mom[l].e;
-        row[4 * l + 1] = mom[l].x;
-        row[4 * l + 2] = mom[l].y;
-        row[4 * l + 3] = mom[l].z;
+        for (int l = 0; l < NF + 2; ++l) put_leg(l, mom[l]);
       }
       __syncthreads();
       double* dst = momenta + (size_t)i0 * LM;
@@ -305,7 +327,7 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     }
 
     // ---- lab frame (utils.py:134-146); the batch-global "any zero reference" test is the caller's
-    if (lab_boost) {
+    if constexpr (HAS_PDF) if (lab_boost) {
       const double rx = mom[0].x * x1 + mom[1].x * x2, ry = mom[0].y * x1 + mom[1].y * x2, rz = mom[0].z * x1 + mom[1].z * x2;
       const double re = mom[0].e * x1 + mom[1].e * x2;
       if (live && rx * rx + ry * ry + rz * rz == 0.) atomicOr(status, 4);
@@ -316,6 +338,7 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
 
     // ---- cuts (:285-301)
     double factor = 1.0;
+    if constexpr (HAS_CUTS) {
     if (pT_mincut > 0.) {                         // min pT >= 0 can never be below a cut <= 0 (:285-288)
       double ptmin = RB_HUGE;
 #pragma unroll
@@ -342,6 +365,7 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
         for (int l = 1; l < NF; ++l) emax = fmax(emax, eta[l]);
         if (rap_maxcut < fabs(emax)) factor = 0.0;                              // |max eta|, not max |eta| (:298-301)
       }
+    }
     }
     wtot *= factor;
     const double shat = x1 * x2 * (k.d.E_cm * k.d.E_cm);
