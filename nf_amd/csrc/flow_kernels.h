@@ -270,7 +270,8 @@ __device__ __forceinline__ void fold_coefs(const CellK& c, double* lds_coef, int
 
 // ---------------------------------------------------------------------------------------------
 // Batch statistics of BN layer `layer` (0..L): partial (count, mean, M2) per workgroup & feature.
-template <int WM, int TPB, int WX = WM>
+// P1: the launch is known to have a single pass-through column (one plane load per sample instead of WM guarded ones)
+template <int WM, int TPB, int WX = WM, bool P1 = false>
 __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restrict__ planes, long ld, long N, int layer) {
   constexpr int NW = TPB / NIS_WAVE;
   __shared__ double lds_coef[NIS_MAX_HIDDEN * 2 * WM];
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
   double cnt = 0.0;
   const long stride = (long)gridDim.x * TPB;
   constexpr int U = WM <= 8 ? 4 : 1;           // samples in flight per thread: the loop is load-latency bound
-  constexpr int PU = WM <= 8 ? WM : 1;
+  constexpr int PU = P1 ? 1 : WM <= 8 ? WM : 1;
+  const int cP = P1 ? 1 : c.P;
   bool firstit = true;
   for (long i0 = (long)blockIdx.x * TPB + tid; i0 < N; i0 += stride * U) {
     double pre[U][PU];
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
       for (int u = 0; u < U; ++u) {
         const long i = i0 + u * stride;
 #pragma unroll
-        for (int p = 0; p < PU; ++p) pre[u][p] = (p < c.P && i < N) ? planes[(size_t)c.in_plane[p] * ld + i] : 0.0;
+        for (int p = 0; p < PU; ++p) pre[u][p] = (p < cP && i < N) ? planes[(size_t)c.in_plane[p] * ld + i] : 0.0;
       }
     }
 #pragma unroll

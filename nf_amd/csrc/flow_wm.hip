@@ -15,7 +15,10 @@ hipError_t launch_stats<NIS_WM>(const CellK& c, const double* planes, long ld, l
   constexpr int TPB = nis_stats_tpb(NIS_WM);
 #if NIS_WM == 4
   if (c.wx == 3) {                       // every layer at most 3 wide (README / C1 / C2 nets): 3x3 blocks instead of 4x4
-    hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB, 3>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N, layer);
+    if (c.P == 1)
+      hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB, 3, true>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N, layer);
+    else
+      hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB, 3>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N, layer);
     return hipGetLastError();
   }
 #endif
