@@ -92,6 +92,11 @@ int nis_flow_create(const nis_cell_desc* cells, int32_t n_cells, int32_t d, cons
                     nis_flow** out);
 void nis_flow_destroy(nis_flow* f);
 
+/* Exchange hook of nis_flow_forward_sync: `records` holds `world` slots of `doubles_per_rank` float64; slot `rank` has
+ * just been written by work enqueued on `stream`.  The hook must leave every rank's slot filled in on every rank (an
+ * in-place all-gather enqueued on, or ordered after, `stream`). */
+typedef void (*nis_sync_fn)(void* ctx, double* records, int32_t doubles_per_rank, void* stream);
+
 /* Bytes of device workspace for n_batches batched iterations (1 for nis_flow_forward); independent of N. */
 size_t nis_flow_workspace_bytes(const nis_flow* f, int64_t n_batches);
 
@@ -130,6 +135,17 @@ int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_b
                         int32_t bn_mode, int64_t pack_token, int32_t f_kind, const double* f_params_host,
                         double* planes, int64_t ld, int32_t keep_planes, double* fres_out, double* out4,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Train-mode forward whose BatchNorm statistics are those of the batch that is SHARDED over `world` ranks (SURVEY.md 8(e)
+ * option 1, "SyncBN-exact": every rank passes its N rows; results equal the reference's single-batch forward of the
+ * concatenated batch up to summation order).  After each launch that produces BatchNorm records the rank's records are
+ * reduced to one (count, mean, M2) record per feature, `sync_fn` gathers the ranks' records into `sync_buf`
+ * (>= world * 64 * 3 doubles of device memory), and the consumers merge those.  Other arguments as nis_flow_forward. */
+int nis_flow_forward_sync(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N,
+                          const double* const* params, double* const* running, long long* const* tracked,
+                          int64_t pack_token, double* planes, int64_t ld, double* xj_out, void* workspace,
+                          size_t workspace_bytes, void* stream, nis_sync_fn sync_fn, void* sync_ctx, double* sync_buf,
+                          int32_t world, int32_t rank);
 
 /* Training forward + hand-written adjoint (replaces loss.backward() through the flow, manager.py:275-278, for the
  * cell class the adjoint kernels cover: conditioner widths and pass-through size <= 64 (<= 8: fp64 VALU kernels,

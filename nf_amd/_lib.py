@@ -25,10 +25,13 @@ ERRORS = {-1: "invalid argument", -2: "configuration outside the compiled kernel
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnis_hip.so")
 
 EXPORTS = ["nis_cell_param_count", "nis_cell_running_count", "nis_flow_create", "nis_flow_destroy",
-           "nis_flow_workspace_bytes", "nis_flow_forward", "nis_integrate_steps", "nis_flow_backward_supported",
+           "nis_flow_workspace_bytes", "nis_flow_forward", "nis_flow_forward_sync", "nis_integrate_steps", "nis_flow_backward_supported",
            "nis_flow_bnsave_count", "nis_flow_forward_train", "nis_flow_backward_workspace_bytes", "nis_flow_backward", "nis_integrand_moments", "nis_integrand_eval",
            "nis_moments_workspace_bytes",
            "nis_moments", "nis_rambo_forward", "nis_prof_enable", "nis_prof_read", "nis_prof_disable", "nis_last_error", "nis_version", "nis_device_count"]
+
+
+SYNC_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)       # nis_sync_fn
 
 
 class CellDesc(C.Structure):
@@ -87,6 +90,9 @@ def lib():
     L.nis_flow_backward_workspace_bytes.argtypes = [vp, i64]
     L.nis_flow_backward.restype = i32
     L.nis_flow_backward.argtypes = [vp, vp, i64, i64, i32, C.POINTER(vp), vp, vp, C.POINTER(vp), vp, vp, sz, vp]
+    L.nis_flow_forward_sync.restype = i32
+    L.nis_flow_forward_sync.argtypes = [vp, vp, i32, i32, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64, vp, i64, vp, vp, sz, vp,
+                                        SYNC_FN, vp, vp, i32, i32]
     L.nis_integrand_eval.restype = i32
     L.nis_integrand_eval.argtypes = [i32, C.POINTER(C.c_double), vp, i64, i64, i32, vp, vp]
     L.nis_integrand_moments.restype = i32

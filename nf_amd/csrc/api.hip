@@ -422,6 +422,40 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest2(const TIN* __restrict__ w, 
   if (st.P > 0) emit_records<NF, NW>(S1, S2, cnt, wshift, wmom, st.P, st.partials + ((size_t)g * st.maxb + blockIdx.x) * st.wm * 3);
 }
 
+// Multi-rank exact BatchNorm: merge this rank's workgroup records of one BN layer into ONE record per feature
+// (count, mean, M2) -- shifted sums like load_coefs, fixed order -- written to out[j*3 ..]; the caller's exchange hook then
+// gathers the ranks' records, and the consumers merge those instead of the local workgroup records.
+__global__ __launch_bounds__(NIS_TPB) void k_sync_reduce(const double* __restrict__ part, int nparts, int WM, double* __restrict__ out) {
+  __shared__ double red[3 * NIS_TPB];
+  const int tid = threadIdx.x;
+  const int S = NIS_TPB / WM;                 // slices per feature (WM <= 64 -> S >= 4, a power of two)
+  const int j = tid % WM, sl = tid / WM;
+  const double ref = part[j * 3 + 1];
+  double an = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int b = sl; b < nparts; b += S) {
+    const double* q = part + ((size_t)b * WM + j) * 3;
+    const double n = q[0], dl = q[1] - ref;
+    an += n;
+    a1 = fma(n, dl, a1);
+    a2 += fma(n * dl, dl, q[2]);
+  }
+  red[(sl * WM + j) * 3 + 0] = an;
+  red[(sl * WM + j) * 3 + 1] = a1;
+  red[(sl * WM + j) * 3 + 2] = a2;
+  __syncthreads();
+  for (int h = S / 2; h > 0; h >>= 1) {
+    if (sl < h)
+      for (int q = 0; q < 3; ++q) red[(sl * WM + j) * 3 + q] += red[((sl + h) * WM + j) * 3 + q];
+    __syncthreads();
+  }
+  if (sl == 0) {
+    const double n = red[j * 3 + 0], s1 = red[j * 3 + 1], s2 = red[j * 3 + 2];
+    out[j * 3 + 0] = n;
+    out[j * 3 + 1] = n > 0.0 ? ref + s1 / n : 0.0;
+    out[j * 3 + 2] = n > 0.0 ? fmax(s2 - s1 * s1 / n, 0.0) : 0.0;
+  }
+}
+
 // inverse of k_emit: column c of the row-major (N, cols) matrix goes to plane m.col[c]
 __global__ __launch_bounds__(NIS_TPB) void k_scatter_rows(const double* __restrict__ src, long N, int cols, ColMap m,
                                                           double* __restrict__ planes, long ld) {
@@ -733,6 +767,12 @@ struct RunOpts {
   int keep_planes = 1;             // 0 with f_kind >= 0: X / J are not stored
   int hist = 0;                    // 1: `planes` holds n_cells+1 plane sets; cell c reads set c and writes set c+1
   double* bnsave = nullptr;        // hist: per cell (L+1) x 4 x WM saved BN scale | shift | mean | rstd
+  // multi-rank exact BatchNorm (nis_flow_forward_sync): after every record-producing launch the rank's reduced record goes
+  // to sync_buf[rank] and `sync_fn` gathers all ranks' records into sync_buf (world x 64 x 3 doubles)
+  nis_sync_fn sync_fn = nullptr;
+  void* sync_ctx = nullptr;
+  double* sync_buf = nullptr;
+  int sync_world = 1, sync_rank = 0;
 };
 
 // declared in flow_bwd.hip
@@ -746,13 +786,24 @@ static bool use_mfma() {
   return !off;
 }
 
+// multi-rank exact BatchNorm: local records -> one record per feature in this rank's slot -> exchange hook
+static int sync_records(const RunOpts& o, const double* records, int nparts, int WM, hipStream_t s) {
+  if (!o.sync_fn) return NIS_OK;
+  hipLaunchKernelGGL(k_sync_reduce, dim3(1), dim3(NIS_TPB), 0, s, records, nparts, WM, o.sync_buf + (size_t)o.sync_rank * WM * 3);
+  HIP_OK(hipGetLastError());
+  o.sync_fn(o.sync_ctx, o.sync_buf, WM * 3, (void*)s);
+  return NIS_OK;
+}
+
 template <int WM>
 static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, long ld, long N, int bn_mode, int km, int* bins,
-                    const FuseF& fz, bool need_stats0, int grid_stats, int grid_apply, int grid_mf, hipStream_t s) {
+                    const FuseF& fz, bool need_stats0, int grid_stats, int grid_apply, int grid_mf, hipStream_t s,
+                    const RunOpts& o) {
   if (bn_mode == NIS_BN_TRAIN) {
     if (need_stats0) {
       NisProfScope ps(NIS_K_STATS, s);
       HIP_OK(launch_stats<WM>(c, planes, ld, N, 0, grid_stats, s));
+      if (int rc = sync_records(o, c.partials, c.nparts[0], WM, s)) return rc;
     }
     if (!c.pmerge) HIP_OK(launch_finalize<WM>(c, 0, s));
     for (int l = 1; l <= c.L; ++l) {
@@ -763,6 +814,7 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
           HIP_OK(launch_stats_mfma<WM>(c, mw, planes, ld, N, l, grid_mf, s));
         else
           HIP_OK(launch_stats<WM>(c, planes, ld, N, l, grid_stats, s));
+        if (int rc = sync_records(o, c.partials + (size_t)l * c.G * c.maxb * WM * 3, c.nparts[l], WM, s)) return rc;
       }
       if (!c.pmerge) HIP_OK(launch_finalize<WM>(c, l, s));
     }
@@ -839,6 +891,11 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
                        ist);
   nis_prof_mark(NIS_K_INGEST, 0, s);
   HIP_OK(hipGetLastError());
+  if (o.sync_fn) {
+    if (G != 1 || !train || o.hist) return NIS_E_UNSUPPORTED;
+    if (ingest_stats)
+      if (int rc = sync_records(o, ist.partials, tgrid, lay[0].WM, s)) return rc;
+  }
 
   int prev_records = tgrid;           // records of BN_0 of the current cell written by the previous launch
   bool have_stats0 = ingest_stats;
@@ -907,6 +964,8 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     // (needs the layer-1 statistics launch to be gone: train mode with derive1, or eval mode)
     c.fold = (cd.P == 1 && !mfma && (c.derive1 || !train) && !env_int("NIS_NO_FOLD", 0)) ? 1 : 0;
     c.wx = cell_wx(cd, L.WM);
+    c.sync_part = o.sync_fn ? o.sync_buf : nullptr;
+    c.sync_world = o.sync_world;
     c.pmerge = (G == 1 || !env_int("NIS_FINALIZE_KERNEL", 0)) ? 1 : 0;   // a launch costs >= 4.3 us, the prologue merge ~1 us
     c.out_off = o.hist ? plane_gs : 0;
     c.bnsave = (o.hist && o.bnsave && train) ? o.bnsave + bn_off : nullptr;
@@ -972,16 +1031,18 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     int rc;
     const bool need0 = !have_stats0;
     switch (L.WM) {
-      case 4: rc = run_cell<4>(c, mw, false, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, s); break;
-      case 8: rc = run_cell<8>(c, mw, false, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, s); break;
-      case 16: rc = run_cell<16>(c, mw, mfma, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, s); break;
-      case 32: rc = run_cell<32>(c, mw, mfma, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, s); break;
-      case 64: rc = run_cell<64>(c, mw, mfma, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, s); break;
+      case 4: rc = run_cell<4>(c, mw, false, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, s, o); break;
+      case 8: rc = run_cell<8>(c, mw, false, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, s, o); break;
+      case 16: rc = run_cell<16>(c, mw, mfma, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, s, o); break;
+      case 32: rc = run_cell<32>(c, mw, mfma, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, s, o); break;
+      case 64: rc = run_cell<64>(c, mw, mfma, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, s, o); break;
       default: rc = NIS_E_UNSUPPORTED;
     }
     if (rc != NIS_OK) return rc;
     have_stats0 = next_rider;
     prev_records = grid_apply;
+    if (next_rider)
+      if (int rc2 = sync_records(o, c.next_partials, grid_apply, c.next_wm, s)) return rc2;
     if (last && o.f_kind >= 0) {
       if (fused_f) {
         NisProfScope ps(NIS_K_MOMENTS, s);
@@ -1022,6 +1083,26 @@ extern "C" int nis_flow_forward(nis_flow* f, const void* w, int32_t w_dtype, int
   o.tracked = tracked;
   o.xj_out = xj_out;
   o.bins_out = bins_out;
+  return flow_run(f, w, w_dtype, N, params, running, planes, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
+}
+
+extern "C" int nis_flow_forward_sync(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N,
+                                     const double* const* params, double* const* running, long long* const* tracked,
+                                     int64_t pack_token, double* planes, int64_t ld, double* xj_out, void* workspace,
+                                     size_t workspace_bytes, void* stream, nis_sync_fn sync_fn, void* sync_ctx, double* sync_buf,
+                                     int32_t world, int32_t rank) {
+  if (!sync_fn || !sync_buf || world < 1 || rank < 0 || rank >= world) return NIS_E_ARG;
+  RunOpts o;
+  o.w_has_jac = w_has_jac;
+  o.bn_mode = NIS_BN_TRAIN;
+  o.pack_token = pack_token;
+  o.tracked = tracked;
+  o.xj_out = xj_out;
+  o.sync_fn = sync_fn;
+  o.sync_ctx = sync_ctx;
+  o.sync_buf = sync_buf;
+  o.sync_world = world;
+  o.sync_rank = rank;
   return flow_run(f, w, w_dtype, N, params, running, planes, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
 }
 

@@ -32,8 +32,8 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
   if (fresh >= 0 && fresh < upto) {
     constexpr int S = TPB / WM;              // slices of partial records per feature (power of two)
     const int j = tid % WM, s = tid / WM;
-    const double* part = c.partials + ((size_t)fresh * c.G + g) * c.maxb * WM * 3;
-    const int np = c.nparts[fresh];
+    const double* part = c.sync_part ? c.sync_part : c.partials + ((size_t)fresh * c.G + g) * c.maxb * WM * 3;
+    const int np = c.sync_part ? c.sync_world : c.nparts[fresh];
     const double ref = part[j * 3 + 1];      // mean of record 0 (workgroup 0 always owns samples)
     double an = 0.0, a1 = 0.0, a2 = 0.0;
     for (int b = s; b < np; b += S) {

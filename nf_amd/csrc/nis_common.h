@@ -131,6 +131,8 @@ struct CellK {
   int G;                                 // number of batches in this launch set
   int coef_gs;                           // doubles between the coefficient sets of consecutive g: (L+1)*2*WM
   long plane_gs;                         // doubles between the plane sets of consecutive g: (d+1)*ld
+  const double* sync_part;               // non-null (multi-rank exact BatchNorm): the freshest layer's records are the `sync_world` per-rank
+  int sync_world;                        //   records gathered here (one record per rank) instead of this launch set's workgroup records
   int pmerge;                            // 1: consumers merge the records of the freshest BN layer in their prologue (every workgroup of
                                          //    batch g redoes the small tree merge); 0: k_bn_finalize launches publish the coefficients
   double* gstat;                         // G > 1: (L+1) x G x 2 x WM  batch mean | unbiased var for k_running_update

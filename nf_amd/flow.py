@@ -187,6 +187,43 @@ class FlowEngine:
         self._raise_on_status(status)
         return dict(planes=planes, xj=xj, bins=bins, status=status, ws=ws)
 
+    def forward_sync(self, w, has_jac=False, want_xj=True, group=None):
+        """Train-mode forward of THIS RANK'S rows of a batch that is sharded over the ranks of `group`, with the BatchNorm
+        statistics of the whole batch (SURVEY.md 8(e) option 1): `nis_flow_forward_sync`, whose exchange hook is one
+        in-place all-gather (RCCL on GPUs) of `world` x (3 x width) doubles per BatchNorm layer.  Returns the same dict as
+        `forward`; concatenating the ranks' results reproduces the single-process forward of the concatenated batch."""
+        import torch.distributed as dist
+        w = self._check_input(w, self.d + (1 if has_jac else 0), False)      # a shard may hold a single row
+        N, dev = w.shape[0], w.device
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        pp, rp, tp = self._pointers(dev)
+        ws, wsb = self._workspace(dev)
+        planes = torch.empty((self.d + 1, N), dtype=torch.double, device=dev)
+        xj = torch.empty((N, self.d + 1), dtype=torch.double, device=dev) if want_xj else None
+        buf = torch.zeros(world * 64 * 3, dtype=torch.double, device=dev)
+
+        failure = []
+
+        def exchange(ctx, records, count, stream):
+            try:                                             # an exception must not vanish inside the ctypes callback
+                flat = buf[:world * count]
+                dist.all_gather_into_tensor(flat, flat[rank * count:(rank + 1) * count].clone(), group=group)
+            except BaseException as exc:                     # noqa: BLE001 - re-raised after the library call returns
+                failure.append(exc)
+
+        hook = _lib.SYNC_FN(exchange)
+        rc = self.L.nis_flow_forward_sync(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
+                                          1 if has_jac else 0, N, pp, rp, tp, self.pack_token(), planes.data_ptr(), N,
+                                          xj.data_ptr() if want_xj else None, ws.data_ptr(), wsb, _lib.stream_ptr(), hook, None,
+                                          buf.data_ptr(), world, rank)
+        if failure:
+            raise failure[0]
+        _lib.check(rc, "nis_flow_forward_sync")
+        self._stats_epoch += 1
+        status = ws[:4].view(torch.int32)
+        self._raise_on_status(status)
+        return dict(planes=planes, xj=xj, bins=None, status=status, ws=ws)
+
     def _raise_on_status(self, status):
         """PWLin with x == 1.0 indexes bin n_bins: the reference's torch.gather raises (coupling_cells.py:136); the kernel
         flags it instead.  Only models with a PWLin cell pay the device->host read of the status word."""

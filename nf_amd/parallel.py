@@ -83,16 +83,41 @@ def shard_size(total, rank, ws):
     return base + (1 if rank < rem else 0)
 
 
-def integrate_sharded(manager, f, nitn, neval, dev=None):
+def moments_batches_syncbn(manager, f, nitn, n_local, dev):
+    """Per-iteration moment records of this rank's shard with EXACT batch statistics (SURVEY.md 8(e) option 1): every
+    BatchNorm layer sees the statistics of the whole sharded batch (`FlowEngine.forward_sync`), so the shards together
+    reproduce the reference's single-batch iteration.  One small all-gather per BatchNorm layer and cell."""
+    from .flow import moments as hip_moments, moments_of
+    model = manager.best_model
+    model.to(dev)
+    eng = model.engine()
+    out = torch.empty((nitn, 4), dtype=torch.double, device=dev)
+    for i in range(nitn):
+        w = manager._uniform(n_local, dev, torch.float32, "integrate")
+        res = eng.forward_sync(w, want_xj=not hasattr(f, "nis_kind"))
+        if hasattr(f, "nis_kind"):
+            out[i] = moments_of(res["planes"], eng.d, eng.out_col, f.nis_kind, f.nis_params)[0]
+        else:
+            XJ = res["xj"]
+            out[i] = hip_moments(f(XJ[:, :-1]), XJ[:, -1])
+    return out
+
+
+def integrate_sharded(manager, f, nitn, neval, dev=None, sync_bn=False):
     """`BasicManager.integrate` with the neval points of every iteration split across the ranks of the
-    default process group.  Same return convention (two 0-d float32 CPU tensors), same on every rank."""
+    default process group.  Same return convention (two 0-d float32 CPU tensors), same on every rank.
+    sync_bn=False: every shard is its own train-mode BatchNorm batch (independent batches, no collective on the data
+    path); sync_bn=True: exact whole-batch statistics (`moments_batches_syncbn`)."""
     rank, ws = world()
     if manager.best_model is None:
         print("No model has been trained")
         return (0, 0)
     dev = manager._device(dev if dev is not None else manager._model_device())
     n_local = shard_size(neval, rank, ws)
-    local = manager.moments_batches(f, int(nitn), n_local, dev)
+    if sync_bn and ws > 1 and manager.best_model.training:
+        local = moments_batches_syncbn(manager, f, int(nitn), n_local, dev)
+    else:
+        local = manager.moments_batches(f, int(nitn), n_local, dev)
     mom = allreduce_moments(local).cpu()
     var = (mom[:, 2] / (mom[:, 0] - 1.0)).to(torch.float32)
     mean = mom[:, 1].to(torch.float32)

@@ -888,3 +888,23 @@ def test_rambo_small_and_ragged_batches_every_kernel_mode(N):
         assert same.all() or N > 100 and (~same).sum() <= 1
         np.testing.assert_allclose(t2n(mom), ref_m, rtol=1e-8, atol=1e-9 * E, err_msg=f"n={n} pdf={pdf}")
         np.testing.assert_allclose(t2n(wgt)[same], ref_w[same], rtol=1e-8, err_msg=f"n={n} pdf={pdf}")
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_exact_batchnorm_sharding_matches_the_whole_batch(ranks):
+    """SURVEY.md 8(e) option 1: `FlowEngine.forward_sync` on the shards of a batch (torch.distributed.run, gloo, all ranks on
+    this GPU) reproduces the single-process train-mode forward of the whole batch -- values and running statistics --
+    for narrow, multi-column, PWLin and matrix-core models; `integrate_sharded(sync_bn=True)` agrees on every rank."""
+    import socket
+    import subprocess
+    import sys
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NIS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "syncbn_check.py")],
+                       env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0 and "SYNCBN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
