@@ -177,24 +177,26 @@ def bench_rambo(args, rank, ws, dev):
 
 def cpu_baseline(NF):
     """The NumPy oracle (oracle/flow.py, pinned to the reference's golden vectors) on ONE host core:
-    3 integrate-iterations of 1e6 samples of the same C2 workload (~15 s), plus 2e5 RAMBO points."""
+    10 integrate-iterations of 1e6 samples of the same C2 workload (~8 s), plus 1e6 RAMBO points (~4 s)."""
     from oracle import flow as oflow
     from oracle import rambo as orambo
     params = {k: v.detach().cpu().numpy() for k, v in NF.best_model.state_dict().items()}
     steps = oflow.plan_pwquad(2, 2, 4)
     rng = np.random.default_rng(0)
-    draws = [rng.random((BATCH, 2), dtype=np.float32) for _ in range(3)]
+    n_it = 10
+    draws = [rng.random((BATCH, 2), dtype=np.float32) for _ in range(n_it)]
     t0 = time.perf_counter()
     sig, sig_err, *_ = oflow.integrate(oflow.camel, params, steps, draws)
     dt = time.perf_counter() - t0
-    r = rng.random((200_000, 8))
+    n_rb = 1_000_000
+    r = rng.random((n_rb, 8))
     t1 = time.perf_counter()
     orambo.generate_kinematics([100.] * 2, [100.] * 4, 1000., r, 0, 0, -1)
     dtr = time.perf_counter() - t1
-    return {"value": 3 * BATCH / dt, "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": "oracle.flow.integrate: 3 iterations x 1e6 samples, C2 model, NumPy float64, 1 thread",
+    return {"value": n_it * BATCH / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"oracle.flow.integrate: {n_it} iterations x 1e6 samples, C2 model, NumPy float64, 1 thread ({dt:.1f} s)",
             "integral": float(sig), "sigma": float(sig_err),
-            "rambo": {"value": 200_000 / dtr, "unit": "samples/s", "sample": "oracle.rambo 2->4 massive, 2e5 points"},
+            "rambo": {"value": n_rb / dtr, "unit": "samples/s", "sample": f"oracle.rambo 2->4 massive, 1e6 points ({dtr:.1f} s)"},
             "host_cpus": os.cpu_count()}
 
 
