@@ -908,3 +908,66 @@ def test_exact_batchnorm_sharding_matches_the_whole_batch(ranks):
                         "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "syncbn_check.py")],
                        env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0 and "SYNCBN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", ["C3", "C4", "C5"])
+def test_wide_configs_full_batch_properties(name):
+    """BASELINE configs C3 / C4 / C5 at their per-GPU batch sizes: every X in [0,1), J > 0 and finite,
+    bitwise determinism in eval mode, shard / merge == whole batch (eval), and -- C4 / C5 -- the flow -> RAMBO weight
+    integrand evaluated from the column planes equals `generateKinematics_batch` on the materialised X."""
+    from nf_amd import integrands
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    from nf_amd.flow import moments as hip_moments, moments_of
+    from nf_amd.normalizing_flows.manager import PWLinManager, PWQuadManager
+    from nf_amd.parallel import merge_moments
+    torch.manual_seed(3)
+    if name == "C3":
+        d, N = 8, 4_000_000
+        NF = PWLinManager(n_flow=8)
+        NF.create_model(4, 4, 64, [32] * 3, 4)
+    elif name == "C4":
+        d, N = 10, 500_000
+        NF = PWQuadManager(n_flow=10)
+        NF.create_model(5, 16, [32] * 3)
+    else:
+        d, N = 16, 1_000_000
+        NF = PWQuadManager(n_flow=16)
+        NF.create_model(8, 16, [32] * 3)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w = torch.rand(N, d, dtype=torch.double, device=dev(), generator=g) * (1 - 1e-12)
+    model = NF._model.train()
+    a = model.flow_forward(w, want_xj=True)["xj"]
+    assert float(a[:, :d].min()) >= 0.0 and float(a[:, :d].max()) <= 1.0
+    assert bool(torch.isfinite(a).all()) and float(a[:, d].min()) > 0.0
+    del a
+    model.eval()
+    e1 = model.flow_forward(w, want_xj=True)
+    e2 = model.flow_forward(w, want_xj=True)
+    assert torch.equal(e1["xj"], e2["xj"])
+    eng = model.engine()
+    f = integrands.Normal(0.5, 0.25, d)
+    whole = t2n(moments_of(e1["planes"], d, eng.out_col, f.nis_kind, f.nis_params)[0])
+    parts = []
+    q = N // 4
+    for s in range(4):
+        res = model.flow_forward(w[s * q:(s + 1) * q])
+        parts.append(t2n(moments_of(res["planes"], d, eng.out_col, f.nis_kind, f.nis_params)[0]))
+    merged = merge_moments(np.stack(parts))
+    np.testing.assert_allclose(merged[:3], whole[:3], rtol=1e-10)
+    assert merged[3] == whole[3]
+    if name in ("C4", "C5"):
+        if name == "C4":
+            gen = FlatInvertiblePhasespace([0., 0.], [100.] * 4, pdf=None, pdf_active=True)
+            fw = integrands.RamboWeight(gen, 13000., 0, 0, -1, [2, -1])
+        else:
+            gen = FlatInvertiblePhasespace([0., 0.], [0.] * 6, pdf=None, pdf_active=True)
+            fw = integrands.RamboWeight(gen, 13000., 20, 0.4, 2.5, [21, 21])
+        assert gen.nDimPhaseSpace() + 2 == d
+        from_planes = fw.from_planes(e1["planes"], eng.out_col, N)
+        from_rows = fw(e1["xj"][:, :d].contiguous())
+        assert torch.equal(from_planes, from_rows)               # same kernel, column-plane vs row-major input
+        m = t2n(hip_moments(from_planes, e1["planes"][d]))
+        assert np.isfinite(m).all() and m[0] == N and m[1] > 0
+        if name == "C5":
+            passed = float((from_planes > 0).double().mean())
+            assert 0.05 < passed < 0.98                           # the cuts act (70.7 % pass for uniform points)
