@@ -971,3 +971,42 @@ def test_wide_configs_full_batch_properties(name):
         if name == "C5":
             passed = float((from_planes > 0).double().mean())
             assert 0.05 < passed < 0.98                           # the cuts act (70.7 % pass for uniform points)
+
+
+@pytest.mark.parametrize("G,N", [(1, 10000), (10, 200000)])
+def test_integrate_steps_can_be_captured_in_a_hip_graph(G, N):
+    """the entry points only enqueue on the caller's stream (no allocation, no host synchronisation), so a
+    call can be captured into a hipGraph and replayed: bit-identical moments and running statistics."""
+    from nf_amd import integrands
+    from nf_amd.normalizing_flows.manager import PWQuadManager
+    torch.manual_seed(0)
+    NF = PWQuadManager(n_flow=2)
+    NF.create_model(2, 4, [3] * 3)
+    eng = NF.best_model.train().engine()
+    f = integrands.Camel()
+    w = torch.rand(G, N, 2, device=dev())
+    out = torch.zeros(G, 4, dtype=torch.double, device=dev())
+    ref = torch.zeros(G, 4, dtype=torch.double, device=dev())
+    sd0 = {k: v.clone() for k, v in NF.best_model.state_dict().items()}
+    tok = eng.pack_token()
+    eng.integrate_steps(w, True, f.nis_kind, f.nis_params, ref, token=tok)          # eager reference (and cache warm-up)
+    sd1 = {k: v.clone() for k, v in NF.best_model.state_dict().items()}
+    NF.best_model.load_state_dict(sd0)
+    tok = eng.pack_token()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eng.integrate_steps(w, True, f.nis_kind, f.nis_params, out, token=tok)
+    torch.cuda.current_stream().wait_stream(side)
+    NF.best_model.load_state_dict(sd0)
+    tok = eng.pack_token()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        eng.integrate_steps(w, True, f.nis_kind, f.nis_params, out, token=tok)
+    NF.best_model.load_state_dict(sd0)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    sd2 = NF.best_model.state_dict()
+    assert all(torch.equal(sd1[k], sd2[k]) for k in sd1)
