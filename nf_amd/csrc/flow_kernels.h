@@ -480,6 +480,41 @@ __device__ __forceinline__ double pwquad_column(double xb, int Krt, const double
   return num * iA;
 }
 
+// Same transform with the raw heights / widths in an LDS image (element k of the column at zr[k * ZS]: rows 0..K heights,
+// K+1..2K widths), as the matrix-core kernels keep them: the widths are streamed for the bin search, the trapezoid sums
+// stream the heights, and V_b, V_{b+1}, W_b are read BY INDEX instead of through K-long select chains.
+template <int KM, bool KEXACT, int ZS>
+__device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const double* zr, double* jf, int* bin) {
+  const int K = KEXACT ? KM : Krt;
+  xb = (xb > 1.0 - 1e-6) ? 1.0 - 1e-6 : xb;                       // :167
+  double W[KM];
+  double wn = 0.0;
+#pragma unroll
+  for (int k = 0; k < KM; ++k) {
+    W[k] = (KEXACT || k < K) ? zr[(K + 1 + k) * ZS] : 0.0;
+    if (KEXACT || k < K) wn += W[k];                              // Wsum[-1]  :180-182
+  }
+  int idx;
+  double run;
+  pwquad_bin_raw<KM, KEXACT>(xb, Krt, W, wn, &idx, &run);
+  double A = 0.0, pre = 0.0, vk = zr[0];
+#pragma unroll
+  for (int k = 0; k < KM; ++k)
+    if (KEXACT || k < K) {
+      const double vn = zr[(k + 1) * ZS];
+      pre = (k == idx) ? A : pre;                                 // VW[idx] A  :209-211
+      A = fma(vk + vn, W[k], A);                                  // :194
+      vk = vn;
+    }
+  const double Vb = zr[idx * ZS], Vb1 = zr[(idx + 1) * ZS], Wb = zr[(K + 1 + idx) * ZS];
+  const double iA = 1.0 / A;
+  const double alpha = (xb * wn - run) / Wb;                      // :206-207
+  const double num = ((alpha * alpha) / 2 * (Vb1 - Vb) + alpha * Vb) * (2 * Wb) + pre;   // :213-220
+  *jf = lerp_torch(Vb, Vb1, alpha) * ((2 * wn) * iA);             // :224-225
+  *bin = idx;
+  return num * iA;
+}
+
 // Full cell: conditioner with finalised BN + bijector, in place on the transformed planes.  Optional riders:
 //   * BN_0 records of the NEXT cell (its pass-through columns are all in this thread's registers),
 //   * a built-in integrand f(X)*J with its moment records (last cell), optionally without storing X, J.

@@ -267,12 +267,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
           double y, jf;
           int bin;
           if (KIND == NIS_PWQUAD) {
-            double V[KM + 1], W[KM];
-#pragma unroll
-            for (int k = 0; k < KM + 1; ++k) V[k] = (KEXACT || k <= c.K) ? zr[k * 16] : 0.0;
-#pragma unroll
-            for (int k = 0; k < KM; ++k) W[k] = (KEXACT || k < c.K) ? zr[(Kq + 1 + k) * 16] : 0.0;
-            y = pwquad_column<KM, KEXACT>(xb, c.K, V, W, &jf, &bin);
+            y = pwquad_column_lds<KM, KEXACT, 16>(xb, c.K, zr, &jf, &bin);
           } else {
             const double ak = xb * c.K;
             const double bf = floor(ak);
