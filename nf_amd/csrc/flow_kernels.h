@@ -450,18 +450,40 @@ __device__ __forceinline__ void pwquad_bin(double xb, int Krt, const double (&W)
 //   alpha = (x wn - run_b) / W_b,   y = ((alpha^2/2 (V_{b+1} - V_b) + alpha V_b) 2 W_b + sum_{k<b} S_k) / A,
 //   dy/dx = lerp(V_b, V_{b+1}, alpha) 2 wn / A
 // -- two divisions per column instead of four, no normalised copies of V and W (<= few ulp from the reference's order).
+// `gather` (optional): this thread's private LDS column, element e at gather[e * NIS_TPB]: V and W are parked there and the
+// bin's three values are read back by index (LDS pipe) instead of 3 K selects on the VALU pipe the kernel is bound by.
 template <int KM, bool KEXACT>
-__device__ __forceinline__ double pwquad_column(double xb, int Krt, const double (&V)[KM + 1], const double (&W)[KM], double* jf, int* bin) {
+__device__ __forceinline__ double pwquad_column(double xb, int Krt, const double (&V)[KM + 1], const double (&W)[KM], double* jf, int* bin,
+                                                double* gather = nullptr) {
   const int K = KEXACT ? KM : Krt;
   xb = (xb > 1.0 - 1e-6) ? 1.0 - 1e-6 : xb;                       // :167
   double wn = 0.0;
 #pragma unroll
   for (int k = 0; k < KM; ++k)
     if (k < K) wn += W[k];                                        // Wsum[-1]  :180-182
+  if (gather) {
+#pragma unroll
+    for (int k = 0; k < KM + 1; ++k)
+      if (k <= K) gather[k * NIS_TPB] = V[k];
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+      if (k < K) gather[(KM + 1 + k) * NIS_TPB] = W[k];
+  }
   int idx;
   double run;
   pwquad_bin_raw<KM, KEXACT>(xb, Krt, W, wn, &idx, &run);
   double A = 0.0, pre = 0.0, Wb = 1.0, Vb = 0.0, Vb1 = 0.0;
+  if (gather) {
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+      if (k < K) {
+        pre = (k == idx) ? A : pre;
+        A = fma(V[k] + V[k + 1], W[k], A);
+      }
+    Vb = gather[idx * NIS_TPB];
+    Vb1 = gather[(idx + 1) * NIS_TPB];
+    Wb = gather[(KM + 1 + idx) * NIS_TPB];
+  } else {
 #pragma unroll
   for (int k = 0; k < KM; ++k)
     if (k < K) {
@@ -472,6 +494,7 @@ __device__ __forceinline__ double pwquad_column(double xb, int Krt, const double
       Vb1 = hit ? V[k + 1] : Vb1;
       A = fma(V[k] + V[k + 1], W[k], A);                          // :194
     }
+  }
   const double iA = 1.0 / A;
   const double alpha = (xb * wn - run) / Wb;                      // :206-207
   const double num = ((alpha * alpha) / 2 * (Vb1 - Vb) + alpha * Vb) * (2 * Wb) + pre;   // :213-220
@@ -546,6 +569,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   int* const bins_o = SP ? nullptr : bins_out;
   nis_cptr wl = as_const(c.wlast);
   nis_cptr bias = as_const(c.bias);
+  __shared__ double lds_gather[SP ? (2 * KM + 1) * NIS_TPB : 1];     // SPEC: per-thread column of V | W for the indexed read-back
   constexpr bool RIDERS = WM <= 8;          // wide conditioners keep their registers for the GEMV
   const bool next = SPEC == 1 ? true : SPEC == 2 ? false : (RIDERS && c.next_P > 0);
   const bool fuse = SPEC == 2 ? true : SPEC == 1 ? false : (RIDERS && fz.kind >= 0);
@@ -609,7 +633,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
 #pragma unroll
         for (int k = 0; k < KM; ++k)
           W[k] = (KEXACT || k < c.K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + Kq + 1 + k, a), etab) : 0.0;             // :175,178
-        y = pwquad_column<KM, KEXACT>(xb, c.K, V, W, &jf, &bin);
+        y = pwquad_column<KM, KEXACT>(xb, c.K, V, W, &jf, &bin, SP ? lds_gather + tid : nullptr);
       } else if (KIND == NIS_AFFINE) {
         // AffineCoupling (coupling_cells.py:56-68): rows [scale | shift][T];  y = atan(20 e^z0 x + relu(z1)) / (pi/2)
         const double s0 = 20.0 * nis_exp(last_dot<WM, WX>(wl, bias, t, a), etab);
