@@ -569,7 +569,8 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   int* const bins_o = SP ? nullptr : bins_out;
   nis_cptr wl = as_const(c.wlast);
   nis_cptr bias = as_const(c.bias);
-  __shared__ double lds_gather[SP ? (2 * KM + 1) * NIS_TPB : 1];     // SPEC: per-thread column of V | W for the indexed read-back
+  constexpr bool GATHER = SP && KM <= 8;    // (2 KM + 1) x 2 KB of LDS per workgroup: 18 KB at KM = 4, 34 KB at KM = 8
+  __shared__ double lds_gather[GATHER ? (2 * KM + 1) * NIS_TPB : 1];   // per-thread column of V | W for the indexed read-back
   constexpr bool RIDERS = WM <= 8;          // wide conditioners keep their registers for the GEMV
   const bool next = SPEC == 1 ? true : SPEC == 2 ? false : (RIDERS && c.next_P > 0);
   const bool fuse = SPEC == 2 ? true : SPEC == 1 ? false : (RIDERS && fz.kind >= 0);
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
 #pragma unroll
         for (int k = 0; k < KM; ++k)
           W[k] = (KEXACT || k < c.K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + Kq + 1 + k, a), etab) : 0.0;             // :175,178
-        y = pwquad_column<KM, KEXACT>(xb, c.K, V, W, &jf, &bin, SP ? lds_gather + tid : nullptr);
+        y = pwquad_column<KM, KEXACT>(xb, c.K, V, W, &jf, &bin, GATHER ? lds_gather + tid : nullptr);
       } else if (KIND == NIS_AFFINE) {
         // AffineCoupling (coupling_cells.py:56-68): rows [scale | shift][T];  y = atan(20 e^z0 x + relu(z1)) / (pi/2)
         const double s0 = 20.0 * nis_exp(last_dot<WM, WX>(wl, bias, t, a), etab);
