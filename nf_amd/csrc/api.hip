@@ -271,10 +271,12 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double*
 
 // k_pack_mfma: padded row-major images -> per-(row tile, k-step) fragments of 64 contiguous doubles, lane l holding
 // W[16 jt + (l & 15)][4 q + (l >> 4)]  (the A operand of v_mfma_f64_16x16x4_f64).
+// affT > 0 (NIS_AFFINE with T transformed columns): the last layer's rows [scale | shift][T] are interleaved to
+// [t][scale, shift], so that a column's outputs are contiguous like those of the piecewise cells.
 __global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int RT, const double* __restrict__ wp,
                                                        const double* __restrict__ wlast, const double* __restrict__ bias,
                                                        double* __restrict__ wm_all, double* __restrict__ wm_last,
-                                                       double* __restrict__ bias_pad) {
+                                                       double* __restrict__ bias_pad, int affT) {
   const size_t tid = (size_t)blockIdx.x * NIS_TPB + threadIdx.x, nth = (size_t)gridDim.x * NIS_TPB;
   const int JT = WM / 16, KQ = WM / 4;
   const size_t nh = (size_t)L * WM * WM;
@@ -291,9 +293,13 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int
     const size_t frag = e >> 6;
     const int q = (int)(frag % KQ), jt = (int)(frag / KQ);
     const int j = 16 * jt + (lane & 15), k = 4 * q + (lane >> 4);
-    wm_last[e] = j < R ? wlast[(size_t)j * WM + k] : 0.0;
+    const int jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;          // packed row j <- blob row jo
+    wm_last[e] = j < R ? wlast[(size_t)jo * WM + k] : 0.0;
   }
-  for (size_t e = tid; e < (size_t)RT * 16; e += nth) bias_pad[e] = e < (size_t)R ? bias[e] : 0.0;
+  for (size_t e = tid; e < (size_t)RT * 16; e += nth) {
+    const int j = (int)e, jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;
+    bias_pad[e] = e < (size_t)R ? bias[jo] : 0.0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1020,7 +1026,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       if (mfma) {
         hipLaunchKernelGGL(k_pack_mfma, dim3(std::max(1, pgrid)), dim3(NIS_TPB), 0, s, L.WM, c.L, c.R, L.RT,
                            (const double*)(body + L.off_wp), (const double*)(body + L.off_wlast), (const double*)(body + L.off_bias),
-                           body + L.off_wm, body + L.off_wmlast, body + L.off_biaspad);
+                           body + L.off_wm, body + L.off_wmlast, body + L.off_biaspad, cd.kind == NIS_AFFINE ? d - cd.P : 0);
         HIP_OK(hipGetLastError());
       }
     }
@@ -1251,7 +1257,7 @@ extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t
       double* wm_last = wm_all + nl * WM * WM;
       double* bias_pad = wm_last + RT * 16 * WM;
       hipLaunchKernelGGL(k_pack_mfma, dim3(32), dim3(NIS_TPB), 0, s, (int)WM, c.L, c.R, (int)RT, (const double*)wp, (const double*)wlast,
-                         (const double*)bias, wm_all, wm_last, bias_pad);
+                         (const double*)bias, wm_all, wm_last, bias_pad, 0);
       HIP_OK(hipGetLastError());
       mw.wm_all = wm_all;
       mw.wm_last = wm_last;

@@ -252,7 +252,8 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int j = 16 * jt + gq + 4 * r - r0;
-            if (j >= 0 && j < NCB * out && 16 * jt + gq + 4 * r < c.R) ring[j * 16 + s] = nis_exp(z[r], etab);
+            if (j >= 0 && j < NCB * out && 16 * jt + gq + 4 * r < c.R)
+              ring[j * 16 + s] = (KIND == NIS_AFFINE && (j & 1)) ? z[r] : nis_exp(z[r], etab);   // affine: odd rows = raw shift
           }
         }
         // (sample s, column t) per lane.  A wave executes in lock step and its LDS operations complete in order:
@@ -268,6 +269,13 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
           int bin;
           if (KIND == NIS_PWQUAD) {
             y = pwquad_column_lds<KM, KEXACT, 16>(xb, c.K, zr, &jf, &bin);
+          } else if (KIND == NIS_AFFINE) {
+            // rows interleaved at pack time: [exp(z0), z1] per column (coupling_cells.py:56-68)
+            const double s0 = 20.0 * zr[0], z1 = zr[16];
+            const double u = xb * s0 + (z1 > 0.0 ? z1 : 0.0);
+            y = atan(u) / (M_PI / 2);
+            jf = s0 * (1.0 / (u * u + 1.0));
+            bin = 0;
           } else {
             const double ak = xb * c.K;
             const double bf = floor(ak);
@@ -291,13 +299,14 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
           }
           col[c.out_off + i] = y;
           jprod *= jf;
-          if (bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
+          if (KIND != NIS_AFFINE && bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
         }
         __builtin_amdgcn_wave_barrier();
       }
       // product over this sample's columns: 4 lanes (row groups) share a sample
       jprod *= __shfl_xor(jprod, 16, 64);
       jprod *= __shfl_xor(jprod, 32, 64);
+      if (KIND == NIS_AFFINE) jprod *= 1.0 / (M_PI / 2);       // the reference applies 2/pi ONCE per cell (:68)
       const long i = base + 16 * st + s;
       if (gq == 0 && i < N) {
         double* jp = planes + (size_t)c.jplane * ld;

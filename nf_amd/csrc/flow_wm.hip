@@ -209,7 +209,6 @@ static size_t mf_ring_bytes(const CellK& c) { return (size_t)(NIS_MF_TPB / 64) *
 
 template <>
 bool mfma_supported<NIS_WM>(const CellK& c) {
-  if (c.kind == NIS_AFFINE) return false;       // rows of one column are not contiguous ([scale|shift][T]): fp64 VALU kernels
   return mf_ring_bytes(c) + 24 * 1024 <= 160 * 1024 && (c.kind == NIS_PWLIN || c.K <= 32);
 }
 
@@ -236,6 +235,8 @@ hipError_t launch_apply_mfma<NIS_WM>(const CellK& c, const MfmaW& w, double* pla
                                      int grid, hipStream_t s) {
   if (c.kind == NIS_PWLIN) {
     NIS_APPLY_MF(NIS_PWLIN, 4, false);
+  } else if (c.kind == NIS_AFFINE) {
+    NIS_APPLY_MF(NIS_AFFINE, 4, false);
   } else {
     switch (km) {
       case 4: NIS_APPLY_MF(NIS_PWQUAD, 4, false); break;
