@@ -1257,7 +1257,7 @@ extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t
       double* wm_last = wm_all + nl * WM * WM;
       double* bias_pad = wm_last + RT * 16 * WM;
       hipLaunchKernelGGL(k_pack_mfma, dim3(32), dim3(NIS_TPB), 0, s, (int)WM, c.L, c.R, (int)RT, (const double*)wp, (const double*)wlast,
-                         (const double*)bias, wm_all, wm_last, bias_pad, 0);
+                         (const double*)bias, wm_all, wm_last, bias_pad, cd.kind == NIS_AFFINE ? d - cd.P : 0);
       HIP_OK(hipGetLastError());
       mw.wm_all = wm_all;
       mw.wm_last = wm_last;

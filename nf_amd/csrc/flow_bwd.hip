@@ -415,7 +415,6 @@ __global__ void k_bwd_scatter(CellK c, int WM, const double* __restrict__ sums, 
 
 // ---------------------------------------------------------------------------------------------
 bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm) {
-  if (cd.kind == NIS_AFFINE) return wm == 4 || wm == 8;   // narrow AffineCoupling: fp64 VALU adjoint; wider: PyTorch re-evaluation
   if (wm == 16) return bwd_wide_supported<16>(cd);
   if (wm == 32) return bwd_wide_supported<32>(cd);
   if (wm == 64) return bwd_wide_supported<64>(cd);

@@ -249,7 +249,8 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int j = 16 * jt + gq + 4 * r - r0;
-            if (j >= 0 && j < NCB * out && 16 * jt + gq + 4 * r < c.R) ring[j * 16 + s] = nis_exp(z[r], etab);
+            if (j >= 0 && j < NCB * out && 16 * jt + gq + 4 * r < c.R)
+              ring[j * 16 + s] = (KIND == NIS_AFFINE && (j & 1)) ? z[r] : nis_exp(z[r], etab);   // affine: odd rows = raw shift
           }
 #pragma unroll
           for (int q = 0; q < KQ; ++q) fa[q] = fb[q];
@@ -361,6 +362,28 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
           }
           bww_da<KM + 1, KEXACT>(wrow, V, K + 1, da);
           bww_da<KM, KEXACT>(wrow + (size_t)(K + 1) * WM, W, K, da);
+        } else if (KIND == NIS_AFFINE) {
+          // AffineCoupling (coupling_cells.py:56-68); the ring holds [20^-1 s0 = exp(z0), z1] per column slot (rows interleaved
+          // at pack time), the dZ planes and W_L^T use the blob's row order [scale | shift][T]
+          const double s0 = 20.0 * (valid ? zr[0] : 1.0), z1 = valid ? zr[16] : 0.0;
+          const double u = xraw * s0 + (z1 > 0.0 ? z1 : 0.0);
+          const double q = 1.0 / (u * u + 1.0);
+          jf = s0 * q;
+          const double gjf = gJv * Jout / jf;
+          const double gu = gy * (q / (M_PI / 2)) - gjf * (2.0 * u * s0 * q * q);
+          gx = gu * s0;
+          const double dz0 = valid ? (gu * xraw + gjf * q) * s0 : 0.0;
+          const double dz1 = (valid && z1 > 0.0) ? gu : 0.0;
+          const int rs = tc, rh = c.T + tc;
+          if (valid) {
+            k.dzp[tmx(c.R, rs, i)] = dz0;
+            k.dzp[tmx(c.R, rh, i)] = dz1;
+          }
+#pragma unroll
+          for (int jt = 0; jt < JT; ++jt) {
+            da[jt] = mfma(c.wlast[(size_t)rs * WM + 16 * jt + s], dz0, da[jt]);
+            da[jt] = mfma(c.wlast[(size_t)rh * WM + 16 * jt + s], dz1, da[jt]);
+          }
         } else {
           // PWLin: Q_q = K e_q / tot, y = Q_b alpha + sum_{q<b} e_q / tot, jf = Q_b  (two streamed passes over the ring)
           const double ak = xraw * K;
@@ -412,6 +435,7 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
       }
       jfprod *= __shfl_xor(jfprod, 16, 64);
       jfprod *= __shfl_xor(jfprod, 32, 64);
+      if (KIND == NIS_AFFINE) jfprod *= 1.0 / (M_PI / 2);
       if (gq == 0 && iv) k.g[(size_t)c.jplane * ld + i] = gJ * jfprod;   // dL/dJ_in = dL/dJ_out prod_t dy_t/dx_t
       // through ReLU to BN_L's output; sums of BN_L; a_L planes for dW_L
 #pragma unroll
@@ -654,7 +678,7 @@ __global__ __launch_bounds__(TPB) void k_bwd_reduce_w(const double* __restrict__
 //   sums : pass p (0 = head, L - l + 1 = layer kernel l) holds the sums of BN_{L-p}: [sum dy | sum dy xhat]
 //   glast: GEMM result of the last Linear (row groups of GREC); ghid + m*ngh*GREC: of hidden Linear m
 __global__ void k_bwd_scatter_w(CellK c, const double* __restrict__ sums, const double* __restrict__ glast,
-                                const double* __restrict__ ghid, int ngh, double* __restrict__ gparams) {
+                                const double* __restrict__ ghid, int ngh, double* __restrict__ gparams, int hidden_bias) {
   const int L = c.L, tid = threadIdx.x, nth = blockDim.x;
   size_t off = 0;
   for (int l = 0; l <= L; ++l) {
@@ -672,6 +696,10 @@ __global__ void k_bwd_scatter_w(CellK c, const double* __restrict__ sums, const 
       gparams[off + e] = src[(size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + q];
     }
     off += (size_t)O * F;
+    if (hidden_bias && l < L) {          // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0
+      for (int e = tid; e < O; e += nth) gparams[off + e] = 0.0;
+      off += O;
+    }
   }
   for (int r = tid; r < c.R; r += nth) gparams[off + r] = glast[(size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + WM];
 }
@@ -717,7 +745,7 @@ Plan plan_for(int R, long N) {
 
 template <>
 bool bwd_wide_supported<NIS_WM>(const nis_cell_desc& cd) {
-  const int out = cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.K;
+  const int out = cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K;
   if (cd.kind == NIS_PWQUAD && cd.K > 32) return false;        // the in-place dZ arrays (2K + 1 doubles) stay in registers
   const size_t fixed = (size_t)(BNLDS + NW * SREC + 64) * sizeof(double) + NIS_MAX_DIM * sizeof(int) + 1024;   // static LDS of the head
   return ring_bytes(out) + fixed <= 160 * 1024;
@@ -726,7 +754,7 @@ bool bwd_wide_supported<NIS_WM>(const nis_cell_desc& cd) {
 template <>
 size_t bwd_wide_workspace_doubles<NIS_WM>(const nis_cell_desc& cd, int64_t N) {
   const int T = cd.d - cd.P;
-  const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.K);
+  const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K);
   const Plan p = plan_for(R, (long)N);
   return (size_t)(3 * WM + R) * ldw_of((long)N) + p.part + (size_t)(cd.n_hidden + 2) * SREC + (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC;
 }
@@ -756,6 +784,8 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
 #define NIS_HEAD(KIND, KMV, EX) hipLaunchKernelGGL((k_bwd_head_w<KIND, KMV, EX>), dim3(p.nb), dim3(TPB), ring, s, k, w)
   if (c.kind == NIS_PWLIN)
     NIS_HEAD(NIS_PWLIN, 4, false);
+  else if (c.kind == NIS_AFFINE)
+    NIS_HEAD(NIS_AFFINE, 4, false);
   else if (c.K == 4)
     NIS_HEAD(NIS_PWQUAD, 4, true);
   else if (c.K == 8)
@@ -793,6 +823,6 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
     hipLaunchKernelGGL(k_bwd_input_w, dim3(gi), dim3(TPB), 0, s, k);
   }
   hipLaunchKernelGGL(k_bwd_scatter_w, dim3(1), dim3(TPB), 0, s, c, (const double*)sums, (const double*)glast, (const double*)ghid, p.ngh,
-                     gparams);
+                     gparams, c.kind == NIS_AFFINE ? 1 : 0);
   return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
 }

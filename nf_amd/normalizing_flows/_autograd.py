@@ -6,7 +6,7 @@ Forward values ALWAYS come from the HIP kernels.  Gradients (needed only by
     pass-through size <= 8 on the fp64 VALU; flow_bwd_wm.hip: widths 9..64 on the f64 matrix cores; PWQuad n_bins <= 32,
     PWLin any n_bins whose LDS image fits) use the hand-written HIP backward (`nis_flow_forward_train` +
     `nis_flow_backward`);
-  * every other model (PWQuad n_bins > 16, AffineCoupling wider than 8) re-evaluates the same cells with stock PyTorch-ROCm ops on the GPU inside
+  * every other model (a PWLin head whose LDS image does not fit) re-evaluates the same cells with stock PyTorch-ROCm ops on the GPU inside
     `backward` and differentiates that graph.  That
     recomputation is a device-side adjoint helper, not a fallback: it never produces a forward result and refuses to run
     without a GPU.  NF_AMD_TORCH_ADJOINT=1 forces it everywhere (A/B checks).

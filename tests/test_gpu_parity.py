@@ -765,9 +765,10 @@ def test_cell_is_a_monotone_bijection_of_the_unit_interval(kind, K, NN):
         np.testing.assert_allclose(t2n(cell(edges)[:, 1]), np.concatenate([[0.0], np.cumsum(Q)[:-1]]) / Q.sum(), rtol=1e-12, atol=1e-15)
 
 
-@pytest.mark.parametrize("d,P,NN,n_cells", [(2, 1, [3, 3, 3], 2), (5, 2, [8, 8], 3), (6, 4, [4], 2), (4, 1, [7, 5], 3)])
+@pytest.mark.parametrize("d,P,NN,n_cells", [(2, 1, [3, 3, 3], 2), (5, 2, [8, 8], 3), (6, 4, [4], 2), (4, 1, [7, 5], 3),
+                                            (8, 4, [32, 32, 32], 4), (7, 3, [16], 2), (9, 2, [20, 64], 3)])
 def test_hip_backward_affine_matches_torch_adjoint(d, P, NN, n_cells, monkeypatch):
-    """Narrow AffineCoupling models: hand-written adjoint (hidden-layer biases, [scale|shift][T] head) against autograd
+    """AffineCoupling models, narrow (fp64 VALU) and wide (matrix cores): hand-written adjoint (hidden-layer biases, [scale|shift][T] head) against autograd
     through the stock-PyTorch re-evaluation."""
     from nf_amd.normalizing_flows.manager import AffineManager
     torch.manual_seed(d * 11 + P)
