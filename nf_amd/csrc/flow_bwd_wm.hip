@@ -296,15 +296,9 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
 #pragma unroll
           for (int q = 0; q < KM + 1; ++q)
             if (q <= K) V[q] = V[q] * iarea;
-          double Wb = 1.0, Vb = 0.0, Vb1 = 0.0;
-#pragma unroll
-          for (int q = 0; q < KM; ++q)
-            if (q < K) {
-              const bool hit = q == b;
-              Wb = hit ? W[q] : Wb;
-              Vb = hit ? V[q] : Vb;
-              Vb1 = hit ? V[q + 1] : Vb1;
-            }
+          // the bin's values by index from the LDS image (raw exponentials, normalised like the arrays) instead of 3 K selects
+          const double Wb = valid ? zr[(K + 1 + b) * 16] * iwn : 1.0;
+          const double Vb = valid ? zr[b * 16] * iarea : 1.0, Vb1 = valid ? zr[(b + 1) * 16] * iarea : 1.0;
           const double alpha = (xb - left) / Wb;
           const double D = Vb1 - Vb;
           jf = lerp_torch(Vb, Vb1, alpha);
