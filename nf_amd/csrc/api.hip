@@ -841,7 +841,8 @@ static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid) {
   *ok = WM >= 16 && use_mfma() && mfma_supported<WM>(c);
   // one wave owns 2 tiles of 16 samples per pass; 4 waves per workgroup
   const int per_wg = 4 * 16 * 2;
-  *grid = *ok ? grid_for(mfma_blocks_per_cu<WM>(c), G, N, per_wg) : 1;
+  static const int bpc = env_int("NIS_MFMA_BPC", 0);          // tuning override
+  *grid = *ok ? grid_for(bpc > 0 ? bpc : mfma_blocks_per_cu<WM>(c), G, N, per_wg) : 1;
 }
 
 static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, const double* const* params, double* const* running,
