@@ -752,9 +752,9 @@ static int cell_wx(const nis_cell_desc& cd, int WM) {
 }
 
 template <int WM>
-static void cell_grids(int kind, int km, int wx, int G, int64_t N, int* gs, int* ga) {
+static void cell_grids(int kind, int km, int wx, bool folded, int G, int64_t N, int* gs, int* ga) {
   static const int bs = env_int("NIS_STATS_BPC", 0), ba = env_int("NIS_APPLY_BPC", 0);   // tuning overrides
-  *gs = grid_for(bs > 0 ? bs : stats_blocks_per_cu<WM>(wx), G, N, nis_stats_tpb(WM));
+  *gs = grid_for(bs > 0 ? bs : stats_blocks_per_cu<WM>(wx, folded), G, N, nis_stats_tpb(WM));
   *ga = grid_for(ba > 0 ? ba : apply_blocks_per_cu<WM>(kind, km, wx), G, N, NIS_TPB);
 }
 
@@ -915,11 +915,13 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     if (!params[ci] || !running[ci]) return NIS_E_ARG;
     int grid_stats = 1, grid_apply = 1;
     switch (L.WM) {
-      case 4: cell_grids<4>(cd.kind, L.KM, cell_wx(cd, L.WM), G, N, &grid_stats, &grid_apply); break;
-      case 8: cell_grids<8>(cd.kind, L.KM, 0, G, N, &grid_stats, &grid_apply); break;
-      case 16: cell_grids<16>(cd.kind, L.KM, 0, G, N, &grid_stats, &grid_apply); break;
-      case 32: cell_grids<32>(cd.kind, L.KM, 0, G, N, &grid_stats, &grid_apply); break;
-      default: cell_grids<64>(cd.kind, L.KM, 0, G, N, &grid_stats, &grid_apply); break;
+      // folded statistics launches (k_bn_stats_fold): train mode, one pass-through column, BN_1 derived
+      case 4: cell_grids<4>(cd.kind, L.KM, cell_wx(cd, L.WM), train && cd.P == 1 && !env_int("NIS_NO_DERIVE1", 0) && !env_int("NIS_NO_FOLD", 0),
+                            G, N, &grid_stats, &grid_apply); break;
+      case 8: cell_grids<8>(cd.kind, L.KM, 0, false, G, N, &grid_stats, &grid_apply); break;
+      case 16: cell_grids<16>(cd.kind, L.KM, 0, false, G, N, &grid_stats, &grid_apply); break;
+      case 32: cell_grids<32>(cd.kind, L.KM, 0, false, G, N, &grid_stats, &grid_apply); break;
+      default: cell_grids<64>(cd.kind, L.KM, 0, false, G, N, &grid_stats, &grid_apply); break;
     }
     CellK c;
     memset(&c, 0, sizeof(c));

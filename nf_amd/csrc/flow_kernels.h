@@ -21,13 +21,29 @@
 // TPB/WM slices per feature, then an LDS tree.  lds_coef: [layer][0: scale, 1: shift][WM];
 // `red`: 3*TPB doubles.  Workgroup 0 publishes the fresh coefficients, applies the running-stat update
 // (momentum 0.1, unbiased variance) and bumps num_batches_tracked.
-template <int WM, int TPB>
-__device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int fresh, bool writer, double* lds_coef, double* red) {
+// `early()` is invoked once, after the prologue's own global loads have been consumed and before its LDS tree: a caller
+// puts the first sample loads there, so that their HBM latency overlaps the merge (the vector-memory counter retires in
+// order: requests issued any earlier would stall the first use of a record instead).
+struct NoEarly {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <int WM, int TPB, class Early = NoEarly>
+__device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int fresh, bool writer, double* lds_coef, double* red,
+                                           Early&& early = Early()) {
   const int tid = threadIdx.x;
   double* coef_g = c.coef + (size_t)g * c.coef_gs;
-  for (int idx = tid; idx < upto * 2 * WM; idx += TPB) {
+  // the first strip of published coefficients travels through a register and is stored behind the record loads (one
+  // round trip instead of two)
+  const int l0 = tid / (2 * WM);
+  const bool c0 = tid < upto * 2 * WM && l0 != fresh && !(fresh == 0 && c.derive1 && l0 == 1);
+  const double v0 = c0 ? coef_g[tid] : 0.0;
+  for (int idx = tid + TPB; idx < upto * 2 * WM; idx += TPB) {
     const int l = idx / (2 * WM);
     if (l != fresh && !(fresh == 0 && c.derive1 && l == 1)) lds_coef[idx] = coef_g[idx];
+  }
+  if (!(fresh >= 0 && fresh < upto)) {
+    early();
+    if (c0) lds_coef[tid] = v0;
   }
   if (fresh >= 0 && fresh < upto) {
     constexpr int S = TPB / WM;              // slices of partial records per feature (power of two)
@@ -35,6 +51,12 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
     const double* part = c.sync_part ? c.sync_part : c.partials + ((size_t)fresh * c.G + g) * c.maxb * WM * 3;
     const int np = c.sync_part ? c.sync_world : c.nparts[fresh];
     const double ref = part[j * 3 + 1];      // mean of record 0 (workgroup 0 always owns samples)
+    // everything the finalisation below needs from global memory is requested here, next to the record loads: the
+    // prologue is a chain of dependent round trips otherwise (~1 us each, and every workgroup of the launch pays it)
+    const bool d1 = fresh == 0 && c.derive1 && upto >= 1;
+    const double gam_e = c.gb[(fresh * 2 + 0) * WM + j], be_e = c.gb[(fresh * 2 + 1) * WM + j];
+    const double be00_e = d1 ? c.gb[1 * WM + 0] : 0.0, w0_e = d1 ? c.wp[(size_t)j * WM + 0] : 0.0;
+    const double gam1_e = d1 ? c.gb[(1 * 2 + 0) * WM + j] : 0.0, be1_e = d1 ? c.gb[(1 * 2 + 1) * WM + j] : 0.0;
     double an = 0.0, a1 = 0.0, a2 = 0.0;
     for (int b = s; b < np; b += S) {
       const double* q = part + ((size_t)b * WM + j) * 3;
@@ -46,6 +68,8 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
     red[(s * WM + j) * 3 + 0] = an;
     red[(s * WM + j) * 3 + 1] = a1;
     red[(s * WM + j) * 3 + 2] = a2;
+    early();
+    if (c0) lds_coef[tid] = v0;
     __syncthreads();
 #pragma unroll
     for (int h = S / 2; h > 0; h >>= 1) {
@@ -64,7 +88,7 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
         const double mean = ref + s1 / n;
         const double m2 = fmax(s2 - s1 * s1 / n, 0.0);
         const double var_b = m2 / n;                             // biased variance normalises the batch
-        const double gam = c.gb[(fresh * 2 + 0) * WM + j], be = c.gb[(fresh * 2 + 1) * WM + j];
+        const double gam = gam_e, be = be_e;
         scale = gam / sqrt(var_b + NIS_BN_EPS);
         shift = be - mean * scale;
         if (writer) {
@@ -106,21 +130,21 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
         red[3 * TPB - 1] = scale;
       }
     }
-    if (fresh == 0 && c.derive1 && upto >= 1) {
+    if (d1) {
       // P == 1: the pre-BN_1 activation h1_j = W0[j][0] * (scale0 * x + shift0) is affine in x, hence
       //   mean(h1_j) = W0[j][0] * (scale0 * mean0 + shift0),   var_b(h1_j) = (W0[j][0] * scale0)^2 * var_b(x)
       __syncthreads();
       if (tid < WM) {
         const double n = red[3 * TPB - 4], mean0 = red[3 * TPB - 3], var0 = red[3 * TPB - 2], scale0 = red[3 * TPB - 1];
-        const double shift0 = c.gb[1 * WM + 0] - mean0 * scale0;
+        const double shift0 = be00_e - mean0 * scale0;      // tid < WM: j == tid, the early loads are this thread's
         const int F1 = cellk_feat(c, 1);
         double scale = 0.0, shift = 0.0, mean1 = 0.0, var1 = 0.0;
         if (tid < F1) {
-          const double a = c.wp[(size_t)tid * WM + 0];
+          const double a = w0_e;
           mean1 = a * fma(scale0, mean0, shift0);
           const double as = a * scale0;
           var1 = as * as * var0;
-          const double gam = c.gb[(1 * 2 + 0) * WM + tid], be = c.gb[(1 * 2 + 1) * WM + tid];
+          const double gam = gam1_e, be = be1_e;
           scale = gam / sqrt(var1 + NIS_BN_EPS);
           shift = be - mean1 * scale;
           if (writer) {
@@ -250,13 +274,18 @@ __device__ __forceinline__ void hidden_stack(const CellK& c, const double* lds_c
 // B_j = sc1_j W0[j][0] sh0 + sh1_j.  The pair replaces BN_1's (scale, shift) in the LDS copy of the coefficients
 // (the published coefficients and the saved statistics stay unfolded); hidden_stack(.., fold = true) then skips
 // BN_0 and Linear_0.  Called by every thread after load_coefs; `upto` = layers present in lds_coef.
+// `w_early` = fold_weight(c), requested before load_coefs so that its round trip overlaps the prologue's.
 template <int WM>
-__device__ __forceinline__ void fold_coefs(const CellK& c, double* lds_coef, int upto) {
+__device__ __forceinline__ double fold_weight(const CellK& c) {
+  return (c.fold && threadIdx.x < WM) ? c.wp[(size_t)threadIdx.x * WM] : 0.0;
+}
+template <int WM>
+__device__ __forceinline__ void fold_coefs(const CellK& c, double* lds_coef, int upto, double w_early) {
   if (!c.fold || upto < 2) return;
   double A = 0.0, B = 0.0;
   const int j = threadIdx.x;
   if (j < WM) {
-    const double w = c.wp[(size_t)j * WM], sc1 = lds_coef[2 * WM + j];
+    const double w = w_early, sc1 = lds_coef[2 * WM + j];
     A = sc1 * (w * lds_coef[0]);
     B = fma(sc1, w * lds_coef[WM], lds_coef[3 * WM + j]);
   }
@@ -282,8 +311,9 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
   const int g = blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   // G == 1: the previous layer's records are merged here; G > 1: k_bn_finalize already published the coefficients
+  const double w_fold = fold_weight<WM>(c);
   load_coefs<WM, TPB>(c, g, layer, c.pmerge ? cellk_fresh(c, layer) : -1, blockIdx.x == 0, lds_coef, red);
-  fold_coefs<WM>(c, lds_coef, layer);
+  fold_coefs<WM>(c, lds_coef, layer, w_fold);
   const bool fold = c.fold && layer >= 2;
 
   double S1[WM], S2[WM], shf[WM];
@@ -336,6 +366,135 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
     }
   }
   emit_records<WM, NW>(S1, S2, cnt, wshift, wmom, WM, c.partials + (((size_t)layer * c.G + g) * c.maxb + blockIdx.x) * WM * 3);
+}
+
+// The same statistics for the folded single-column chain (P == 1, CellK::fold, every layer at most WX wide) with the BN
+// layer a compile-time constant: every coefficient and weight of the stack is hoisted into registers before the sample
+// loop (the generic kernel re-reads them per sample and layer behind s_waitcnt lgkmcnt(0)), whole wave tiles run
+// unguarded with U loads in flight off one scalar base, and the wave's shift enters the last layer's FMA chain as
+// its start value.  PMC on C2: 67 -> ~40 VALU instructions per sample, no scalar-memory or LDS traffic in the loop.
+#ifndef NIS_STATS_U
+#define NIS_STATS_U 4
+#endif
+template <int WM, int TPB, int WX, int LAYER>
+__global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __restrict__ planes, long ld, long N) {
+  static_assert(LAYER >= 2 && LAYER <= NIS_MAX_HIDDEN && WX <= WM, "folded statistics start at BN layer 2");
+  constexpr int NW = TPB / NIS_WAVE;
+  __shared__ double lds_coef[NIS_MAX_HIDDEN * 2 * WM];
+  __shared__ double red[3 * TPB];
+  __shared__ double wshift[NW][WM];
+  __shared__ double wmom[NW][WM][3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.y;
+  planes += (size_t)g * c.plane_gs;
+  // Requests that do not depend on the prologue go out first: the weights (scalar loads), the sample that fixes the
+  // wave's shift and the first U tiles -- their latency overlaps the record merge.
+  const double w_fold = fold_weight<WM>(c);
+  double cs[LAYER][WX], ch[LAYER][WX], W[LAYER][WX][WX];           // rows 1 .. LAYER-1 are used; row 1 of cs/ch holds (A, B)
+  nis_cptr wp = as_const(c.wp);
+#pragma unroll
+  for (int l = 1; l < LAYER; ++l) {
+#pragma unroll
+    for (int j = 0; j < WX; ++j) {
+#pragma unroll
+      for (int i = 0; i < WX; ++i) W[l][j][i] = wp[(size_t)l * WM * WM + j * WM + i];
+    }
+  }
+  constexpr int U = NIS_STATS_U;
+  const double* px = planes + (size_t)c.in_plane[0] * ld;
+  const long stride = (long)gridDim.x * TPB;
+  long wbase = (long)blockIdx.x * TPB + wave * NIS_WAVE;          // wave-uniform: index of lane 0's next sample
+  bool full = wbase + (U - 1) * stride + NIS_WAVE <= N;           // wave-uniform: U whole tiles ahead
+  double x_first = 0.0, x[U];
+  auto first_loads = [&]() {
+    x_first = wbase < N ? px[wbase] : 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = full ? (px + wbase + u * stride)[lane] : 0.0;
+  };
+  load_coefs<WM, TPB>(c, g, LAYER, c.pmerge ? cellk_fresh(c, LAYER) : -1, blockIdx.x == 0, lds_coef, red, first_loads);
+  fold_coefs<WM>(c, lds_coef, LAYER, w_fold);
+#pragma unroll
+  for (int l = 1; l < LAYER; ++l) {
+#pragma unroll
+    for (int j = 0; j < WX; ++j) {
+      cs[l][j] = lds_coef[(l * 2 + 0) * WM + j];
+      ch[l][j] = lds_coef[(l * 2 + 1) * WM + j];
+    }
+  }
+  // pre-BN activations of layer LAYER minus the shift: t_j = h_j - shf_j  (start value of the last FMA chain: -shf_j)
+  auto stack = [&](double x, const double (&nshf)[WX], double (&t)[WX]) {
+    double a[WX];
+#pragma unroll
+    for (int j = 0; j < WX; ++j) a[j] = fmax(fma(x, cs[1][j], ch[1][j]), 0.0);
+#pragma unroll
+    for (int l = 1; l < LAYER; ++l) {
+      double h[WX];
+#pragma unroll
+      for (int j = 0; j < WX; ++j) {
+        double acc = (l == LAYER - 1) ? nshf[j] : 0.0;
+#pragma unroll
+        for (int i = 0; i < WX; ++i) acc = fma(W[l][j][i], a[i], acc);
+        h[j] = acc;
+      }
+#pragma unroll
+      for (int j = 0; j < WX; ++j) {
+        if (l == LAYER - 1) t[j] = h[j];
+        else a[j] = fmax(fma(h[j], cs[l + 1][j], ch[l + 1][j]), 0.0);
+      }
+    }
+  };
+
+  double nshf[WX];
+  {                                                               // shift = the value of the wave's first sample
+    double zero[WX], t0[WX];
+#pragma unroll
+    for (int j = 0; j < WX; ++j) zero[j] = 0.0;
+    stack(x_first, zero, t0);
+#pragma unroll
+    for (int j = 0; j < WX; ++j) nshf[j] = -t0[j];
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < WM; ++j) wshift[wave][j] = j < WX ? t0[j < WX ? j : 0] : 0.0;
+    }
+  }
+  double S1[WM], S2[WM];
+#pragma unroll
+  for (int j = 0; j < WM; ++j) S1[j] = S2[j] = 0.0;
+  double cnt = 0.0;
+  // whole tiles, no guards (U loads of 512 B in flight per wave; the first U were requested above the prologue)
+  while (full) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double t[WX];
+      stack(x[u], nshf, t);
+#pragma unroll
+      for (int j = 0; j < WX; ++j) {
+        S1[j] += t[j];
+        S2[j] = fma(t[j], t[j], S2[j]);
+      }
+    }
+    cnt += (double)U;
+    wbase += U * stride;
+    full = wbase + (U - 1) * stride + NIS_WAVE <= N;
+    if (full) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = (px + wbase + u * stride)[lane];
+    }
+  }
+  for (; wbase < N; wbase += stride) {                                         // the ragged rest, one tile at a time
+    const bool valid = wbase + lane < N;
+    double t[WX];
+    stack(valid ? px[wbase + lane] : 0.0, nshf, t);
+#pragma unroll
+    for (int j = 0; j < WX; ++j) {
+      const double tv = valid ? t[j] : 0.0;
+      S1[j] += tv;
+      S2[j] = fma(tv, tv, S2[j]);
+    }
+    cnt += valid ? 1.0 : 0.0;
+  }
+  emit_records<WM, NW>(S1, S2, cnt, wshift, wmom, WM, c.partials + (((size_t)LAYER * c.G + g) * c.maxb + blockIdx.x) * WM * 3);
 }
 
 // G > 1: one workgroup per batch merges the records of BN layer `layer` and publishes scale / shift (+ the batch
@@ -561,8 +720,25 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   const int g = blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   nis_exp_init(etab);
-  load_coefs<WM, NIS_TPB>(c, g, c.L + 1, (bn_train && c.pmerge) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red);
-  fold_coefs<WM>(c, lds_coef, c.L + 1);
+  const double w_fold = fold_weight<WM>(c);
+  // SPEC kernels keep the inputs of the NEXT sample in flight while the current one is computed (one sample per thread
+  // and iteration: ~0.7 us of arithmetic against ~2 us of HBM latency, 3-4 waves per SIMD); the first request goes out
+  // inside the prologue.  jsrc: a first cell has no Jacobian plane to read -- it re-reads x (same line, L1 hit) so that
+  // the loop's vector-memory sequence is fixed and the compiler's vmcnt bookkeeping stays exact.
+  const double* const P0 = planes + (size_t)c.in_plane[0] * ld;
+  double* const P1 = planes + (size_t)c.in_plane[SP ? 1 : 0] * ld;
+  const double* const jsrc = c.first ? P0 : planes + (size_t)c.jplane * ld;
+  const long i_first = (long)blockIdx.x * NIS_TPB + tid;
+  double xq = 0.0, xbq = 0.0, jq = 0.0;
+  auto first_loads = [&]() {
+    if (SP && i_first < N) {
+      xq = P0[i_first];
+      xbq = P1[i_first];
+      jq = jsrc[i_first];
+    }
+  };
+  load_coefs<WM, NIS_TPB>(c, g, c.L + 1, (bn_train && c.pmerge) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red, first_loads);
+  fold_coefs<WM>(c, lds_coef, c.L + 1, w_fold);
   const bool fold = SP ? true : c.fold != 0;
   const int cP = SP ? 1 : c.P, cT = SP ? 1 : c.T;
   const long out_off = SP ? 0 : c.out_off;
@@ -583,11 +759,16 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   double cnt = 0.0, fS1 = 0.0, fS2 = 0.0, fmax_ = -__builtin_huge_val(), fshift = 0.0;
   bool firstit = true;
   const long stride = (long)gridDim.x * NIS_TPB;
-  for (long i = (long)blockIdx.x * NIS_TPB + tid; i < N; i += stride) {
+  for (long i = i_first; i < N; i += stride) {
     double a[WM];
+    const double x0 = xq, xb0 = xbq, jin = c.first ? 1.0 : jq;      // SPEC: this sample's inputs, requested one iteration ago
     if (SP) {
+      const long ic = i + stride < N ? i + stride : i;              // last round: re-read the current sample (unused)
+      xq = P0[ic];
+      xbq = P1[ic];
+      jq = jsrc[ic];
 #pragma unroll
-      for (int p = 0; p < WM; ++p) a[p] = p == 0 ? planes[(size_t)c.in_plane[0] * ld + i] : 0.0;
+      for (int p = 0; p < WM; ++p) a[p] = p == 0 ? x0 : 0.0;
     } else {
       load_passthrough<WM>(c, planes, ld, i, a);
     }
@@ -604,11 +785,15 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const int src = c.next_src[f];
-        nv[f] = (src >= 0 && src < cP) ? planes[(size_t)c.in_plane[src < 0 ? 0 : src] * ld + i] : 0.0;
+        if (SP) nv[f] = src == 0 ? x0 : 0.0;                        // the one pass-through column is already in a register
+        else nv[f] = (src >= 0 && src < cP) ? planes[(size_t)c.in_plane[src < 0 ? 0 : src] * ld + i] : 0.0;
       }
     }
     if (fuse) {
-      if (fkind == NIS_F_CAMEL) {
+      if (SP) {
+        c0 = fz.loc0 == 0 ? x0 : 0.0;
+        c1 = fz.loc1 == 0 ? x0 : 0.0;
+      } else if (fkind == NIS_F_CAMEL) {
         if (fz.loc0 >= 0 && fz.loc0 < cP) c0 = planes[(size_t)c.in_plane[fz.loc0] * ld + i];
         if (fz.loc1 >= 0 && fz.loc1 < cP) c1 = planes[(size_t)c.in_plane[fz.loc1] * ld + i];
       } else if (fkind == NIS_F_NORMAL) {
@@ -620,8 +805,8 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
     hidden_stack<WM, WX>(c, lds_coef, c.L, true, a, fold);
     double jprod = 1.0;
     for (int t = 0; t < cT; ++t) {
-      double* col = planes + (size_t)c.in_plane[cP + t] * ld;
-      const double xb = col[i];
+      double* col = SP ? P1 : planes + (size_t)c.in_plane[cP + t] * ld;
+      const double xb = SP ? xb0 : col[i];
       const int row0 = t * c.out;
       double y, jf;
       int bin;
@@ -683,7 +868,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
     }
     double* jp = planes + (size_t)c.jplane * ld;
     if (KIND == NIS_AFFINE) jprod *= 1.0 / (M_PI / 2);          // the reference applies 2/pi ONCE per cell (:68)
-    const double jout = (c.first ? 1.0 : jp[i]) * jprod;
+    const double jout = (SP ? jin : c.first ? 1.0 : jp[i]) * jprod;
     if (wplanes) jp[out_off + i] = jout;
     if (next) {
       if (firstit) {
@@ -730,7 +915,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
 // *_blocks_per_cu: resident workgroups per CU of the kernel (occupancy query, cached) -> grids are sized to ONE
 // resident wave of workgroups so that every thread amortises the prologue / epilogue over many samples.
 template <int WM>
-int stats_blocks_per_cu(int wx);
+int stats_blocks_per_cu(int wx, bool folded);
 template <int WM>
 int apply_blocks_per_cu(int kind, int km, int wx);
 template <int WM>
@@ -759,7 +944,7 @@ hipError_t launch_apply_mfma(const CellK& c, const MfmaW& w, double* planes, lon
                              hipStream_t s);
 #define NIS_DECL_WM(W)                                                                                                      \
   template <>                                                                                                               \
-  int stats_blocks_per_cu<W>(int wx);                                                                                          \
+  int stats_blocks_per_cu<W>(int wx, bool folded);                                                                                          \
   template <>                                                                                                               \
   int apply_blocks_per_cu<W>(int kind, int km, int wx);                                                                          \
   template <>                                                                                                               \

@@ -15,7 +15,15 @@ hipError_t launch_stats<NIS_WM>(const CellK& c, const double* planes, long ld, l
   constexpr int TPB = nis_stats_tpb(NIS_WM);
 #if NIS_WM == 4
   if (c.wx == 3) {                       // every layer at most 3 wide (README / C1 / C2 nets): 3x3 blocks instead of 4x4
-    if (c.P == 1)
+    static const bool hoisted = getenv("NIS_NO_STATS_FOLD") == nullptr;
+    if (c.P == 1 && c.fold && hoisted && layer >= 2 && layer <= 5) {     // folded chain, coefficients in registers
+      switch (layer) {
+        case 2: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 2>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
+        case 3: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 3>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
+        case 4: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 4>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
+        default: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 5>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
+      }
+    } else if (c.P == 1)
       hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB, 3, true>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N, layer);
     else
       hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB, 3>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N, layer);
@@ -57,10 +65,13 @@ static int stats_occ_of(K kern) {
 }
 
 template <>
-int stats_blocks_per_cu<NIS_WM>(int wx) {
+int stats_blocks_per_cu<NIS_WM>(int wx, bool folded) {
   static int v[2] = {-1, -1};
   constexpr int TPB = nis_stats_tpb(NIS_WM);
 #if NIS_WM == 4
+  // k_bn_stats_fold keeps NIS_STATS_U loads in flight per wave and pays its prologue once per workgroup: one 512-thread
+  // workgroup per CU measured best (C2 bench: 20.5e9 samples/s at 1, 20.2 at 2, 19.5 at 4)
+  if (wx == 3 && folded && getenv("NIS_NO_STATS_FOLD") == nullptr) return 1;
   if (wx == 3) {
     if (v[1] < 0) v[1] = stats_occ_of(k_bn_stats<NIS_WM, TPB, 3>);
     return v[1];

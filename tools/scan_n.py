@@ -13,7 +13,8 @@ f = integrands.Camel()
 L = _lib.lib()
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 K = {"apply": 0, "stats": 1, "ingest": 2}
-for N in (1_000, 10_000, 100_000, 1_000_000):
+NS = [int(float(v)) for v in os.environ.get("SCAN_N", "1e3,1e4,1e5,3e5,1e6,3e6").split(",")]
+for N in NS:
     w = torch.rand(G, N, 2, dtype=torch.float32, device=dev)
     out = torch.zeros(G, 4, dtype=torch.double, device=dev)
     tok = eng.pack_token()
