@@ -619,11 +619,8 @@ __global__ __launch_bounds__(NIS_TPB) void k_moments(const double* __restrict__ 
 }
 
 // one workgroup: merge the per-workgroup records in a fixed order -> out4 = {n, mean, M2, max}
-__global__ __launch_bounds__(NIS_TPB) void k_moments_final(const double* __restrict__ partials, int nparts, double* __restrict__ out4,
-                                                           int maxb) {
+__device__ __forceinline__ void moments_final_body(const double* __restrict__ partials, int nparts, double* __restrict__ out4) {
   __shared__ double sm[NIS_TPB][4];
-  partials += (size_t)blockIdx.x * maxb * 4;
-  out4 += (size_t)blockIdx.x * 4;
   Mom t = {0.0, 0.0, 0.0};
   double m = -__builtin_huge_val();
   for (int b = threadIdx.x; b < nparts; b += NIS_TPB) {
@@ -654,6 +651,59 @@ __global__ __launch_bounds__(NIS_TPB) void k_moments_final(const double* __restr
     out4[2] = sm[0][2];
     out4[3] = sm[0][3];
   }
+}
+
+__global__ __launch_bounds__(NIS_TPB) void k_moments_final(const double* __restrict__ partials, int nparts, double* __restrict__ out4,
+                                                           int maxb) {
+  moments_final_body(partials + (size_t)blockIdx.x * maxb * 4, nparts, out4 + (size_t)blockIdx.x * 4);
+}
+
+// Batched iterations (G > 1): ONE launch at the end of the launch set applies the G momentum-0.1 running-statistics
+// updates of every BN layer of every cell in batch order (BatchNorm1d semantics) and merges the fused integrand's moment
+// records -- three ~4.5 us launches per C2 launch set otherwise.  Blocks [0, blk_off[ncell]): one per (cell, BN layer);
+// blocks behind them: one per batch for the moment records (when fpart != nullptr).
+#define NIS_EPI_CELLS 16
+struct EpiCell {
+  double* running;
+  const double* gstat;
+  long long* tracked;
+  int L, WM, P;
+  int width[NIS_MAX_HIDDEN];
+};
+struct EpiJob {
+  EpiCell cell[NIS_EPI_CELLS];
+  int blk_off[NIS_EPI_CELLS + 1];
+  int ncell, G;
+  const double* fpart;
+  double* out4;
+  int fparts, maxb;
+};
+__global__ __launch_bounds__(NIS_TPB) void k_group_epilogue(EpiJob job) {
+  const int b = blockIdx.x;
+  const int nupd = job.blk_off[job.ncell];
+  if (b >= nupd) {
+    const int g = b - nupd;
+    moments_final_body(job.fpart + (size_t)g * job.maxb * 4, job.fparts, job.out4 + (size_t)g * 4);
+    return;
+  }
+  int ci = 0;
+  while (ci + 1 < job.ncell && b >= job.blk_off[ci + 1]) ++ci;
+  const EpiCell& c = job.cell[ci];
+  const int l = b - job.blk_off[ci], j = threadIdx.x;
+  const int F = l == 0 ? c.P : c.width[l - 1];
+  int off = 0;
+  for (int i = 0; i < l; ++i) off += 2 * (i == 0 ? c.P : c.width[i - 1]);
+  if (j < F) {
+    double* run = c.running + off;
+    double rm = run[j], rv = run[F + j];
+    for (int g = 0; g < job.G; ++g) {
+      rm = (1.0 - NIS_BN_MOM) * rm + NIS_BN_MOM * c.gstat[(((size_t)l * job.G + g) * 2 + 0) * c.WM + j];
+      rv = (1.0 - NIS_BN_MOM) * rv + NIS_BN_MOM * c.gstat[(((size_t)l * job.G + g) * 2 + 1) * c.WM + j];
+    }
+    run[j] = rm;
+    run[F + j] = rv;
+  }
+  if (j == 0 && c.tracked) c.tracked[l] += job.G;
 }
 
 static int stream_grid(int64_t N) { return (int)std::max<int64_t>(1, std::min<int64_t>(NIS_MAXB, (N + NIS_TPB - 1) / NIS_TPB)); }
@@ -832,8 +882,7 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
     else
       HIP_OK(launch_apply<WM>(c, planes, ld, N, bn_mode == NIS_BN_TRAIN ? 1 : 0, km, bins, fz, grid_apply, s));
   }
-  if (bn_mode == NIS_BN_TRAIN && c.G > 1) HIP_OK(launch_running_update<WM>(c, s));
-  return NIS_OK;
+  return NIS_OK;                      // G > 1: the running-statistics updates are applied by the launch set's k_group_epilogue
 }
 
 template <int WM>
@@ -904,6 +953,21 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       if (int rc = sync_records(o, ist.partials, tgrid, lay[0].WM, s)) return rc;
   }
 
+  EpiJob epi;                          // G > 1, train mode: running-statistics updates (+ moment merge) in one launch at the end
+  memset(&epi, 0, sizeof(epi));
+  epi.G = G;
+  auto epi_flush = [&](const double* fpart, int fparts) -> int {
+    if (epi.ncell == 0 && !fpart) return NIS_OK;
+    epi.fpart = fpart;
+    epi.fparts = fparts;
+    epi.out4 = o.out4;
+    epi.maxb = NIS_MAXB;
+    NisProfScope ps(NIS_K_MOMENTS, s);
+    hipLaunchKernelGGL(k_group_epilogue, dim3(epi.blk_off[epi.ncell] + (fpart ? G : 0)), dim3(NIS_TPB), 0, s, epi);
+    HIP_OK(hipGetLastError());
+    epi.ncell = 0;
+    return NIS_OK;
+  };
   int prev_records = tgrid;           // records of BN_0 of the current cell written by the previous launch
   bool have_stats0 = ingest_stats;
   double* const planes0 = planes;
@@ -1052,12 +1116,23 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     prev_records = grid_apply;
     if (next_rider)
       if (int rc2 = sync_records(o, c.next_partials, grid_apply, c.next_wm, s)) return rc2;
+    if (train && G > 1) {
+      EpiCell& e = epi.cell[epi.ncell];
+      e.running = c.running;
+      e.gstat = c.gstat;
+      e.tracked = c.tracked;
+      e.L = c.L;
+      e.WM = L.WM;
+      e.P = c.P;
+      for (int l = 0; l < NIS_MAX_HIDDEN; ++l) e.width[l] = c.width[l];
+      epi.blk_off[epi.ncell + 1] = epi.blk_off[epi.ncell] + c.L + 1;
+      ++epi.ncell;
+      if (epi.ncell == NIS_EPI_CELLS && !(last && fused_f))
+        if (int rc2 = epi_flush(nullptr, 0)) return rc2;
+    }
     if (last && o.f_kind >= 0) {
       if (fused_f) {
-        NisProfScope ps(NIS_K_MOMENTS, s);
-        hipLaunchKernelGGL(k_moments_final, dim3(G), dim3(NIS_TPB), 0, s, (const double*)(body + off_fpart), grid_apply, o.out4,
-                           NIS_MAXB);
-        HIP_OK(hipGetLastError());
+        if (int rc2 = epi_flush(body + off_fpart, grid_apply)) return rc2;
       } else {
         int rc2 = nis_integrand_moments(planes, ld, N, d, f->out_col, o.f_kind, o.f_params, o.fres_out, o.out4, body + off_fpart,
                                         (size_t)NIS_MAXB * 4 * sizeof(double), (void*)s);
@@ -1065,6 +1140,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       }
     }
   }
+  if (int rc2 = epi_flush(nullptr, 0)) return rc2;
   f->packed_token = o.pack_token;
   f->packed_mode = o.bn_mode;
   f->packed_ws = workspace;

@@ -99,7 +99,7 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
             run[j] = (1.0 - NIS_BN_MOM) * run[j] + NIS_BN_MOM * mean_r;
             run[F + j] = (1.0 - NIS_BN_MOM) * run[F + j] + NIS_BN_MOM * unb;
             if (j == 0 && c.tracked) c.tracked[fresh] += 1;
-          } else {                                               // applied in batch order by k_running_update
+          } else {                                               // applied in batch order by k_group_epilogue
             c.gstat[(((size_t)fresh * c.G + g) * 2 + 0) * WM + j] = mean_r;
             c.gstat[(((size_t)fresh * c.G + g) * 2 + 1) * WM + j] = unb;
           }
@@ -506,24 +506,6 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(CellK c, int layer) {
   load_coefs<WM, 1024>(c, blockIdx.x, layer + 1, layer, true, lds_coef, red);
 }
 
-// G > 1: apply the G momentum updates of every BN layer in batch order (BatchNorm1d semantics, momentum 0.1).
-template <int WM>
-__global__ void k_running_update(CellK c) {
-  const int l = blockIdx.x, j = threadIdx.x;
-  const int F = cellk_feat(c, l);
-  if (j < F) {
-    double* run = c.running + cellk_running_off(c, l);
-    double rm = run[j], rv = run[F + j];
-    for (int g = 0; g < c.G; ++g) {
-      rm = (1.0 - NIS_BN_MOM) * rm + NIS_BN_MOM * c.gstat[(((size_t)l * c.G + g) * 2 + 0) * WM + j];
-      rv = (1.0 - NIS_BN_MOM) * rv + NIS_BN_MOM * c.gstat[(((size_t)l * c.G + g) * 2 + 1) * WM + j];
-    }
-    run[j] = rm;
-    run[F + j] = rv;
-  }
-  if (j == 0 && c.tracked) c.tracked[l] += c.G;
-}
-
 // ---------------------------------------------------------------------------------------------
 // z = bias[row] + <wlast[row,:], a>
 template <int WM, int WX = WM>
@@ -923,8 +905,6 @@ hipError_t launch_stats(const CellK& c, const double* planes, long ld, long N, i
 template <int WM>
 hipError_t launch_finalize(const CellK& c, int layer, hipStream_t s);
 template <int WM>
-hipError_t launch_running_update(const CellK& c, hipStream_t s);
-template <int WM>
 hipError_t launch_apply(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz, int grid,
                         hipStream_t s);
 // matrix-core path (WM >= 16): weight fragments pre-packed per (row tile, k-step) as 64 contiguous doubles
@@ -951,8 +931,6 @@ hipError_t launch_apply_mfma(const CellK& c, const MfmaW& w, double* planes, lon
   hipError_t launch_stats<W>(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s);    \
   template <>                                                                                                               \
   hipError_t launch_finalize<W>(const CellK& c, int layer, hipStream_t s);                                                  \
-  template <>                                                                                                               \
-  hipError_t launch_running_update<W>(const CellK& c, hipStream_t s);                                                       \
   template <>                                                                                                               \
   hipError_t launch_apply<W>(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz, \
                              int grid, hipStream_t s);                                                                      \

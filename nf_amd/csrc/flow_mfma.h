@@ -207,7 +207,6 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
   load_coefs<WM, NIS_MF_TPB>(c, g, c.L + 1, (bn_train && c.pmerge) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red);
   const int out = c.out;
   double* ring = mf_dyn + (size_t)wave * NCB * out * 16;
-  const int Kq = KEXACT ? KM : c.K;
   const long wstride = (long)gridDim.x * NW * 16 * ST;
   for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
     double H[KQ][ST];

@@ -40,12 +40,6 @@ hipError_t launch_finalize<NIS_WM>(const CellK& c, int layer, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <>
-hipError_t launch_running_update<NIS_WM>(const CellK& c, hipStream_t s) {
-  hipLaunchKernelGGL((k_running_update<NIS_WM>), dim3(c.L + 1), dim3(NIS_WM), 0, s, c);
-  return hipGetLastError();
-}
-
 template <typename K>
 static int stats_occ_of(K kern) {
   constexpr int TPB = nis_stats_tpb(NIS_WM);

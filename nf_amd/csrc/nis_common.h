@@ -135,7 +135,7 @@ struct CellK {
   int sync_world;                        //   records gathered here (one record per rank) instead of this launch set's workgroup records
   int pmerge;                            // 1: consumers merge the records of the freshest BN layer in their prologue (every workgroup of
                                          //    batch g redoes the small tree merge); 0: k_bn_finalize launches publish the coefficients
-  double* gstat;                         // G > 1: (L+1) x G x 2 x WM  batch mean | unbiased var for k_running_update
+  double* gstat;                         // G > 1: (L+1) x G x 2 x WM  batch mean | unbiased var for k_group_epilogue
   // ---- training history (for the adjoint kernels): outputs go to the NEXT plane set, BN statistics are kept
   int derive1;                           // 1 (P == 1): BN_1's batch statistics follow analytically from BN_0's
                                          //   (h1_j = W0_j0 * BN_0(x) is affine in the single pass-through column),
