@@ -524,6 +524,41 @@ def test_ragged_batch_sizes_vs_oracle(N):
             params = {k: t2n(v) for k, v in NF._model.state_dict().items()}
 
 
+@pytest.mark.parametrize("N", [2, 65, 513, 131_073, 524_357, 700_001])
+def test_folded_chain_batch_sizes_vs_oracle(N):
+    """The d = 2 chain (single pass-through column: derived BN_1, folded input layer, k_bn_stats_fold with whole-tile and
+    ragged-tail loops, prefetching SPEC apply kernels) at batch sizes around its tile boundaries: 256 workgroups x 512
+    threads (131 072), 4 whole tiles per wave (524 288 + 64), and a ragged tail."""
+    torch.manual_seed(N % 1000)
+    NF = build_manager(dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3]))
+    params = {k: t2n(v) for k, v in NF._model.state_dict().items()}
+    w = torch.rand(N, 2, dtype=torch.double)
+    steps = oflow.plan_pwquad(2, 2, 4)
+    NF._model.train()
+    ref = oflow.model_forward(w.numpy(), params, steps, True)
+    got = NF._model.flow_forward(w.to(dev()), want_xj=True)["xj"]
+    np.testing.assert_allclose(t2n(got), ref, rtol=1e-8 if N < 4 else RTOL, atol=1e-11)
+    # the fused integrand path of the same batch (SPEC kernels, nothing stored): moments of f(X) J
+    from nf_amd import integrands
+    f = integrands.Camel()
+    NF2 = build_manager(dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3]))
+    NF2._model.load_state_dict({k: torch.as_tensor(v) for k, v in params.items()})
+    NF2._model.train()
+    out = torch.zeros((1, 4), dtype=torch.double, device=dev())
+    NF2._model.engine().integrate_steps(w.to(dev()).unsqueeze(0), True, f.nis_kind, f.nis_params, out)
+    fx = f(torch.as_tensor(ref[:, :2])).numpy() * ref[:, 2]
+    m = t2n(out)[0]
+    assert m[0] == N
+    np.testing.assert_allclose(m[1], fx.mean(), rtol=1e-9)
+    np.testing.assert_allclose(m[2], ((fx - fx.mean()) ** 2).sum(), rtol=1e-7)
+    np.testing.assert_allclose(m[3], fx.max(), rtol=1e-9)
+    # running statistics after one train-mode batch agree with the oracle's BatchNorm bookkeeping
+    sdA, sdB = NF._model.state_dict(), NF2._model.state_dict()
+    for k in sdA:
+        if "running" in k or "num_batches" in k:
+            np.testing.assert_allclose(t2n(sdA[k]), t2n(sdB[k]), rtol=1e-10, atol=1e-14, err_msg=k)
+
+
 def test_single_sample_train_mode_raises_like_torch():
     NF = build_manager(dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3]))
     NF._model.train()
