@@ -92,8 +92,9 @@ def bench_flow(args, rank, ws, dev):
     token = eng.pack_token()            # parameters do not change inside integrate(): pack the image once
 
     def run_group(wblock, dst):
-        # ONE library call = len(wblock) steps: ingest(+BN_0 stats) -> [BN stats x3 -> cell apply] x2 with
-        # camel*J + moments fused into the last apply; the steps are the y dimension of every launch.
+        # ONE library call = len(wblock) steps: BN_0 records of w -> [BN stats x2 -> cell apply] x2 (cells read w's rows /
+        # the planes the previous cell wrote) with camel*J + moments fused into the last apply -> one epilogue launch;
+        # the steps are the y dimension of every launch.
         eng.integrate_steps(wblock, True, f.nis_kind, f.nis_params, dst, token=token)
 
     for _ in range(max(1, (args.warmup + G - 1) // G)):
@@ -117,17 +118,16 @@ def bench_flow(args, rank, ws, dev):
     sig = float(np.sum(mom[:, 1] / var) / np.sum(1 / var))
     sig_err = float(np.sqrt(1 / np.sum(1 / var)) / np.sqrt(mom[0, 0] * args.steps))
     sig_mc = float(1 / np.sqrt(np.sum(mom[:, 0] / var)))
-    # algorithmic bytes of the dominant kernel (DESIGN.md "Kernels"): the cell-apply kernel reads the
-    # pass-through, transformed and Jacobian columns and writes the transformed + Jacobian columns:
-    # 8*((d+1) + (T+1)) B/sample; the first cell does not read J (it is 1): 8*(d + T+1).
-    d, T = 2, 1
-    # One launch covers G steps.  Cell 0 reads xA, xB (J_in = 1) and writes yB, J: 32 B/sample; the last cell
-    # reads xA, xB, J and (integrand fused, X/J not stored) writes nothing: 24 B/sample -> mean 28 B.
+    # algorithmic bytes of the dominant kernel (DESIGN.md "Kernels").  One launch covers G steps.  With float32 draws the
+    # cells of the d = 2 chain read w's (N, 2) rows themselves (direct row input): cell 0 reads one 8-byte row (J_in = 1) and
+    # writes y, J: 24 B/sample; the last cell reads x (plane), one row, J and -- integrand fused, X / J not stored -- writes
+    # nothing: 24 B/sample.  (Plane ingest, NIS_NO_DIRECT_ROWS=1: 32 B and 24 B, mean 28 B.)
     gmean = args.steps / len(draws)
-    per_launch = {"apply": gmean * BATCH * 28.0,
-                  "stats": gmean * BATCH * 8 * 1,                       # reads the P = 1 pass-through column
-                  "ingest": gmean * BATCH * (4 * d + 8 * d),
-                  "integrand": gmean * BATCH * 8 * (d + 1)}[args.roofline_kernel]
+    direct = os.environ.get("NIS_NO_DIRECT_ROWS", "0") in ("", "0")
+    per_launch = {"apply": gmean * BATCH * (24.0 if direct else 28.0),
+                  "stats": gmean * BATCH * 8 * 1,                       # reads the P = 1 pass-through column (or its 8-byte row)
+                  "ingest": gmean * BATCH * (4 * 2 if direct else 4 * 2 + 8 * 2),
+                  "integrand": gmean * BATCH * 8 * (2 + 1)}[args.roofline_kernel]
     roof = None
     if kern_n > 0:
         avg_s = kern_ms / kern_n / 1e3

@@ -377,7 +377,8 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest(const TIN* __restrict__ w, l
 
 // d == 2 (README / C1 / C2): a row is one 8- or 16-byte vector, so every lane loads its own rows directly (coalesced),
 // four in flight; no LDS transpose, no barriers.
-template <typename TIN>
+// WRITE = false (direct row input: the cells read w themselves): only the BN_0 records are gathered.
+template <typename TIN, bool WRITE = true>
 __global__ __launch_bounds__(NIS_TPB) void k_ingest2(const TIN* __restrict__ w, long N, double* __restrict__ planes, long ld,
                                                      IngestStats st) {
   typedef TIN vec2 __attribute__((ext_vector_type(2)));
@@ -406,8 +407,10 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest2(const TIN* __restrict__ w, 
       const long i = i0 + u * stride;
       if (i < N) {
         const double x0 = (double)r[u].x, x1 = (double)r[u].y;
-        planes[i] = x0;
-        planes[(size_t)ld + i] = x1;
+        if (WRITE) {
+          planes[i] = x0;
+          planes[(size_t)ld + i] = x1;
+        }
         if (st.P > 0) {
           const double v0 = s0 == 0 ? x0 : x1, v1 = s1 == 0 ? x0 : x1;
           if (firstit) {
@@ -894,6 +897,28 @@ static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid) {
   *grid = *ok ? grid_for(bpc > 0 ? bpc : mfma_blocks_per_cu<WM>(c), G, N, per_wg) : 1;
 }
 
+// Descriptor-level mirror of launch_apply's SPEC conditions (flow_wm.hip): every cell of a d = 2 PWQuad chain with 3-wide
+// conditioners and a compiled bin count, camel integrand fused into the last cell, nothing materialised.
+static bool direct_rows_ok(const nis_flow* f, const std::vector<CellLayout>& lay, const RunOpts& o, int w_dtype, int wcols, int ingest_P) {
+  if (f->d != 2 || wcols != 2 || w_dtype != NIS_F32 || o.w_has_jac || o.hist || o.keep_planes || o.xj_out || o.bins_out || o.fres_out ||
+      o.sync_fn || o.f_kind != NIS_F_CAMEL || !o.out4)
+    return false;
+  if (o.bn_mode != NIS_BN_TRAIN) return false;     // eval mode: inner cells carry no BN_0 rider and run the generic kernel
+  if (env_int("NIS_NO_FOLD", 0) || env_int("NIS_NO_WX", 0) || env_int("NIS_NO_DERIVE1", 0) || getenv("NIS_NO_STATS_FOLD")) return false;
+  if (ingest_P != 1) return false;
+  bool in_w[2] = {true, true};
+  for (int ci = 0; ci < f->n_cells; ++ci) {
+    const nis_cell_desc& cd = f->cells[ci];
+    if (cd.kind != NIS_PWQUAD || cd.P != 1 || lay[ci].WM != 4 || cell_wx(cd, 4) != 3) return false;
+    if (!(lay[ci].KM == -4 || lay[ci].KM == -8 || lay[ci].KM == -16)) return false;
+    if (cd.n_hidden < 1 || cd.n_hidden > 5) return false;               // k_bn_stats_fold instantiations: BN layers 2..5
+    if (cd.in_col[0] < 0 || cd.in_col[0] > 1 || cd.in_col[1] < 0 || cd.in_col[1] > 1) return false;
+    if (in_w[cd.in_col[0]] && !in_w[cd.in_col[1]]) return false;        // the row kernels take xb (and optionally x) from w
+    in_w[cd.in_col[1]] = false;
+  }
+  return true;
+}
+
 static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, const double* const* params, double* const* running,
                     double* planes, int64_t ld, void* workspace, size_t workspace_bytes, hipStream_t s, const RunOpts& o) {
   if (!f || !w || !params || !running || !planes || N < 1 || ld < N) return NIS_E_ARG;
@@ -934,8 +959,15 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     ist.wm = lay[0].WM;
     ist.partials = body + lay[0].off_part;
   }
+  // Direct row input: a d = 2 chain of SPEC kernels with the camel integrand fused never needs X as planes, so the
+  // (N, 2) float32 rows of w are read by the cells themselves (a column lives in w until a cell overwrites it) and the
+  // ingest launch only gathers BN_0's records: 80 MB read instead of 80 MB read + 160 MB written per 1e7 samples.
+  const bool direct = direct_rows_ok(f, lay, o, w_dtype, wcols, ist.P) && !env_int("NIS_NO_DIRECT_ROWS", 0);
+  bool col_in_w[2] = {direct, direct};
   nis_prof_mark(NIS_K_INGEST, 1, s);
-  if (wcols == 2 && ist.P <= 2 && w_dtype == NIS_F64)
+  if (direct)
+    hipLaunchKernelGGL((k_ingest2<float, false>), dim3(tgrid, G), dim3(NIS_TPB), 0, s, (const float*)w, (long)N, planes, (long)ld, ist);
+  else if (wcols == 2 && ist.P <= 2 && w_dtype == NIS_F64)
     hipLaunchKernelGGL(k_ingest2<double>, dim3(tgrid, G), dim3(NIS_TPB), 0, s, (const double*)w, (long)N, planes, (long)ld, ist);
   else if (wcols == 2 && ist.P <= 2)
     hipLaunchKernelGGL(k_ingest2<float>, dim3(tgrid, G), dim3(NIS_TPB), 0, s, (const float*)w, (long)N, planes, (long)ld, ist);
@@ -1040,6 +1072,15 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     c.sync_part = o.sync_fn ? o.sync_buf : nullptr;
     c.sync_world = o.sync_world;
     c.pmerge = (G == 1 || !env_int("NIS_FINALIZE_KERNEL", 0)) ? 1 : 0;   // a launch costs >= 4.3 us, the prologue merge ~1 us
+    if (direct) {
+      c.wrows = (const float*)w;
+      c.wrows_gs = 2 * (long)N;
+      c.x_wcol = col_in_w[cd.in_col[0]] ? cd.in_col[0] : -1;
+      c.xb_wcol = col_in_w[cd.in_col[1]] ? cd.in_col[1] : -1;
+      col_in_w[cd.in_col[1]] = false;            // an inner cell writes its transformed column to the plane; the last one stores nothing
+    } else {
+      c.x_wcol = c.xb_wcol = -1;
+    }
     c.out_off = o.hist ? plane_gs : 0;
     c.bnsave = (o.hist && o.bnsave && train) ? o.bnsave + bn_off : nullptr;
     bn_off += (size_t)(cd.n_hidden + 1) * 4 * L.WM;

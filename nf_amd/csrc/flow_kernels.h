@@ -376,7 +376,8 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
 #ifndef NIS_STATS_U
 #define NIS_STATS_U 4
 #endif
-template <int WM, int TPB, int WX, int LAYER>
+// ROWS: the pass-through column is column c.x_wcol of the float32 (N, 2) rows of w (CellK::wrows), not a plane.
+template <int WM, int TPB, int WX, int LAYER, bool ROWS = false>
 __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __restrict__ planes, long ld, long N) {
   static_assert(LAYER >= 2 && LAYER <= NIS_MAX_HIDDEN && WX <= WM, "folded statistics start at BN layer 2");
   constexpr int NW = TPB / NIS_WAVE;
@@ -403,14 +404,18 @@ __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __
   }
   constexpr int U = NIS_STATS_U;
   const double* px = planes + (size_t)c.in_plane[0] * ld;
+  const float* wr = ROWS ? c.wrows + (size_t)g * c.wrows_gs + c.x_wcol : nullptr;
+  auto sample = [&](long tile0, int l) -> double {                // tile0 wave-uniform, l = lane
+    return ROWS ? (double)(wr + 2 * tile0)[2 * l] : (px + tile0)[l];
+  };
   const long stride = (long)gridDim.x * TPB;
   long wbase = (long)blockIdx.x * TPB + wave * NIS_WAVE;          // wave-uniform: index of lane 0's next sample
   bool full = wbase + (U - 1) * stride + NIS_WAVE <= N;           // wave-uniform: U whole tiles ahead
   double x_first = 0.0, x[U];
   auto first_loads = [&]() {
-    x_first = wbase < N ? px[wbase] : 0.0;
+    x_first = wbase < N ? sample(wbase, 0) : 0.0;
 #pragma unroll
-    for (int u = 0; u < U; ++u) x[u] = full ? (px + wbase + u * stride)[lane] : 0.0;
+    for (int u = 0; u < U; ++u) x[u] = full ? sample(wbase + u * stride, lane) : 0.0;
   };
   load_coefs<WM, TPB>(c, g, LAYER, c.pmerge ? cellk_fresh(c, LAYER) : -1, blockIdx.x == 0, lds_coef, red, first_loads);
   fold_coefs<WM>(c, lds_coef, LAYER, w_fold);
@@ -479,13 +484,13 @@ __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __
     full = wbase + (U - 1) * stride + NIS_WAVE <= N;
     if (full) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) x[u] = (px + wbase + u * stride)[lane];
+      for (int u = 0; u < U; ++u) x[u] = sample(wbase + u * stride, lane);
     }
   }
   for (; wbase < N; wbase += stride) {                                         // the ragged rest, one tile at a time
     const bool valid = wbase + lane < N;
     double t[WX];
-    stack(valid ? px[wbase + lane] : 0.0, nshf, t);
+    stack(valid ? sample(wbase, lane) : 0.0, nshf, t);
 #pragma unroll
     for (int j = 0; j < WX; ++j) {
       const double tv = valid ? t[j] : 0.0;
@@ -686,9 +691,13 @@ __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const do
 // folded conditioner input, in place, no bin output): 1 = inner cell (BN_0 rider of the next cell, planes written),
 // 2 = last cell with the camel integrand fused and nothing stored.  The generic kernel (SPEC 0) carries every switch
 // as a scalar branch; resolving them removes ~60 branches, the SGPR spills and their v_readlane traffic from the loop.
-template <int KIND, int WM, int KM, bool KEXACT, int WX = WM, int SPEC = 0>
+// ROWS (SPEC kernels only): the transformed input -- and, for c.x_wcol >= 0, the pass-through input too -- is read from the
+// float32 (N, 2) rows of w (CellK::wrows) instead of its plane: one 8-byte row load per sample.
+template <int KIND, int WM, int KM, bool KEXACT, int WX = WM, int SPEC = 0, bool ROWS = false>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                         int* __restrict__ bins_out, FuseF fz) {
+  static_assert(!ROWS || SPEC != 0, "row input exists on the SPEC kernels only");
+  typedef float nis_f2 __attribute__((ext_vector_type(2)));
   constexpr int NW = NIS_TPB / NIS_WAVE;
   constexpr int NF = SPEC ? 1 : WM <= 4 ? 4 : NIS_PMAX_FUSED;      // next-cell pass-through features tracked here (<= its P)
   constexpr bool SP = SPEC != 0;
@@ -707,15 +716,20 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   // and iteration: ~0.7 us of arithmetic against ~2 us of HBM latency, 3-4 waves per SIMD); the first request goes out
   // inside the prologue.  jsrc: a first cell has no Jacobian plane to read -- it re-reads x (same line, L1 hit) so that
   // the loop's vector-memory sequence is fixed and the compiler's vmcnt bookkeeping stays exact.
-  const double* const P0 = planes + (size_t)c.in_plane[0] * ld;
+  const nis_f2* const rows = ROWS ? reinterpret_cast<const nis_f2*>(c.wrows + (size_t)g * c.wrows_gs) : nullptr;
+  const bool xrow = ROWS && c.x_wcol >= 0;                         // pass-through input from the row as well (first cell)
+  // xrow: P0 aliases the row (same 8 bytes, L1 hit, value unused) so that the loop's load sequence stays fixed
+  const double* const P0 = xrow ? reinterpret_cast<const double*>(rows) : planes + (size_t)c.in_plane[0] * ld;
   double* const P1 = planes + (size_t)c.in_plane[SP ? 1 : 0] * ld;
   const double* const jsrc = c.first ? P0 : planes + (size_t)c.jplane * ld;
   const long i_first = (long)blockIdx.x * NIS_TPB + tid;
   double xq = 0.0, xbq = 0.0, jq = 0.0;
+  nis_f2 rq = {0.f, 0.f};
   auto first_loads = [&]() {
     if (SP && i_first < N) {
       xq = P0[i_first];
-      xbq = P1[i_first];
+      if (ROWS) rq = rows[i_first];
+      else xbq = P1[i_first];
       jq = jsrc[i_first];
     }
   };
@@ -743,11 +757,15 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   const long stride = (long)gridDim.x * NIS_TPB;
   for (long i = i_first; i < N; i += stride) {
     double a[WM];
-    const double x0 = xq, xb0 = xbq, jin = c.first ? 1.0 : jq;      // SPEC: this sample's inputs, requested one iteration ago
+    // SPEC: this sample's inputs, requested one iteration ago
+    const double x0 = xrow ? (double)(c.x_wcol ? rq.y : rq.x) : xq;
+    const double xb0 = ROWS ? (double)(c.xb_wcol ? rq.y : rq.x) : xbq;
+    const double jin = c.first ? 1.0 : jq;
     if (SP) {
       const long ic = i + stride < N ? i + stride : i;              // last round: re-read the current sample (unused)
       xq = P0[ic];
-      xbq = P1[ic];
+      if (ROWS) rq = rows[ic];
+      else xbq = P1[ic];
       jq = jsrc[ic];
 #pragma unroll
       for (int p = 0; p < WM; ++p) a[p] = p == 0 ? x0 : 0.0;

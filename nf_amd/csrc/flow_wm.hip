@@ -16,7 +16,16 @@ hipError_t launch_stats<NIS_WM>(const CellK& c, const double* planes, long ld, l
 #if NIS_WM == 4
   if (c.wx == 3) {                       // every layer at most 3 wide (README / C1 / C2 nets): 3x3 blocks instead of 4x4
     static const bool hoisted = getenv("NIS_NO_STATS_FOLD") == nullptr;
-    if (c.P == 1 && c.fold && hoisted && layer >= 2 && layer <= 5) {     // folded chain, coefficients in registers
+    const bool rows = c.wrows && c.x_wcol >= 0;        // pass-through column still lives in the float32 rows of w
+    if (rows && !(c.P == 1 && c.fold && hoisted && layer >= 2 && layer <= 5)) return hipErrorInvalidValue;
+    if (rows) {
+      switch (layer) {
+        case 2: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 2, true>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
+        case 3: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 3, true>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
+        case 4: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 4, true>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
+        default: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 5, true>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
+      }
+    } else if (c.P == 1 && c.fold && hoisted && layer >= 2 && layer <= 5) {     // folded chain, coefficients in registers
       switch (layer) {
         case 2: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 2>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
         case 3: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 3>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
@@ -30,6 +39,7 @@ hipError_t launch_stats<NIS_WM>(const CellK& c, const double* planes, long ld, l
     return hipGetLastError();
   }
 #endif
+  if (c.wrows && c.x_wcol >= 0) return hipErrorInvalidValue;          // row input exists for the folded 3-wide chain only
   hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N, layer);
   return hipGetLastError();
 }
@@ -145,8 +155,17 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
 #if NIS_WM == 4
 #define NIS_APPLY3(KIND, KMV, EX) \
   hipLaunchKernelGGL((k_cell_apply<KIND, NIS_WM, KMV, EX, 3>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
-#define NIS_APPLY3S(KMV, SP) \
-  hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
+#define NIS_APPLY3S(KMV, SP)                                                                                                       \
+  do {                                                                                                                             \
+    if (rows)                                                                                                                      \
+      hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP, true>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c, planes, \
+                         ld, N, bn_train, bins, fz);                                                                               \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c, planes, ld, \
+                         N, bn_train, bins, fz);                                                                                   \
+  } while (0)
+  const bool rows = c.wrows && c.xb_wcol >= 0;           // transformed input (and maybe the pass-through one) from the rows of w
+  if (c.wrows && c.x_wcol >= 0 && !rows) return hipErrorInvalidValue;
   if (c.wx == 3 && c.kind == NIS_PWQUAD && km < 0 && c.P == 1 && c.T == 1 && c.fold && c.out_off == 0 && !bins && !fz.fres) {
     // the two cells of a d = 2 chain: every wave-uniform switch resolved at compile time (k_cell_apply, SPEC)
     const int spec = (c.next_P == 1 && fz.kind < 0 && fz.write_planes) ? 1
@@ -167,6 +186,7 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
       }
     }
   }
+  if (rows) return hipErrorInvalidValue;                 // row input exists on the SPEC kernels only (api.hip: direct_rows_ok)
   if (c.wx == 3) {
     if (c.kind == NIS_PWLIN) {
       NIS_APPLY3(NIS_PWLIN, 4, false);

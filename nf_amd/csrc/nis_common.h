@@ -136,6 +136,11 @@ struct CellK {
   int pmerge;                            // 1: consumers merge the records of the freshest BN layer in their prologue (every workgroup of
                                          //    batch g redoes the small tree merge); 0: k_bn_finalize launches publish the coefficients
   double* gstat;                         // G > 1: (L+1) x G x 2 x WM  batch mean | unbiased var for k_group_epilogue
+  // ---- direct row input (d = 2 chains on the SPEC kernels, float32 w): a column that no cell has written yet is read
+  //      straight from the (N, 2) float32 rows of w -- the ingest launch then only gathers BN_0's records
+  const float* wrows;                    // null: every column lives in its plane
+  long wrows_gs;                         // floats between the row blocks of consecutive g: 2 N
+  int x_wcol, xb_wcol;                   // column of w that holds the pass-through / the transformed input, -1: read the plane
   // ---- training history (for the adjoint kernels): outputs go to the NEXT plane set, BN statistics are kept
   int derive1;                           // 1 (P == 1): BN_1's batch statistics follow analytically from BN_0's
                                          //   (h1_j = W0_j0 * BN_0(x) is affine in the single pass-through column),

@@ -559,6 +559,42 @@ def test_folded_chain_batch_sizes_vs_oracle(N):
             np.testing.assert_allclose(t2n(sdA[k]), t2n(sdB[k]), rtol=1e-10, atol=1e-14, err_msg=k)
 
 
+@pytest.mark.parametrize("n_cells,G,N", [(2, 1, 70_001), (2, 3, 40_003), (3, 2, 20_001), (4, 1, 131_073), (4, 2, 5)])
+def test_direct_row_input_matches_planes_and_oracle(n_cells, G, N, monkeypatch):
+    """integrate_steps on float32 draws of a d = 2 chain reads the (N, 2) rows of w inside the statistics / apply kernels
+    (no plane ingest): same records and running statistics as the plane path, and the oracle's moments."""
+    from nf_amd import integrands
+    f = integrands.Camel()
+    torch.manual_seed(100 + n_cells)
+    cfg = dict(kind="pwquad", d=2, n_cells=n_cells, K=4, NN=[3, 3, 3])
+    A = build_manager(cfg)
+    sd = {k: v.clone() for k, v in A._model.state_dict().items()}
+    B = build_manager(cfg)
+    B._model.load_state_dict(sd)
+    params = {k: t2n(v) for k, v in sd.items()}
+    w = torch.rand(G, N, 2, dtype=torch.float32, device=dev())
+    A._model.train()
+    B._model.train()
+    outA = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    A._model.engine().integrate_steps(w, True, f.nis_kind, f.nis_params, outA)                 # direct rows
+    monkeypatch.setenv("NIS_NO_DIRECT_ROWS", "1")
+    outB = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    B._model.engine().integrate_steps(w, True, f.nis_kind, f.nis_params, outB)                 # plane ingest
+    monkeypatch.delenv("NIS_NO_DIRECT_ROWS")
+    np.testing.assert_allclose(t2n(outA), t2n(outB), rtol=1e-13)
+    for k in sd:
+        np.testing.assert_allclose(t2n(A._model.state_dict()[k]), t2n(B._model.state_dict()[k]), rtol=1e-13, atol=1e-16, err_msg=k)
+    steps = oflow.plan_pwquad(2, n_cells, 4)
+    for g in range(G):                                                                         # every batch starts from the same BN state
+        ref = oflow.model_forward(w[g].double().cpu().numpy(), params, steps, True)
+        fx = f(torch.as_tensor(ref[:, :2])).numpy() * ref[:, 2]
+        m = t2n(outA)[g]
+        assert m[0] == N
+        np.testing.assert_allclose(m[1], fx.mean(), rtol=1e-8)
+        np.testing.assert_allclose(m[2], ((fx - fx.mean()) ** 2).sum(), rtol=1e-6)
+        np.testing.assert_allclose(m[3], fx.max(), rtol=1e-8)
+
+
 def test_single_sample_train_mode_raises_like_torch():
     NF = build_manager(dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3]))
     NF._model.train()
