@@ -935,7 +935,6 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   double* body = (double*)((char*)workspace + WS_HEADER);
   const int d = f->d;
   const bool train = o.bn_mode == NIS_BN_TRAIN;
-  const int tgrid = grid_for(8, G, N, NIS_TPB);          // ingest / emit: 256-thread streaming workgroups
   const size_t tile_bytes = ((size_t)NIS_TPB * (d + 1) + 16) * sizeof(double);
   const int wcols = o.w_has_jac ? d + 1 : d;
   const long plane_gs = (long)(d + 1) * ld;
@@ -963,6 +962,9 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   // (N, 2) float32 rows of w are read by the cells themselves (a column lives in w until a cell overwrites it) and the
   // ingest launch only gathers BN_0's records: 80 MB read instead of 80 MB read + 160 MB written per 1e7 samples.
   const bool direct = direct_rows_ok(f, lay, o, w_dtype, wcols, ist.P) && !env_int("NIS_NO_DIRECT_ROWS", 0);
+  // ingest / emit: 256-thread streaming workgroups, 8 per CU; the read-only record pass of the direct mode runs best at 4
+  // (half the BN_0 records for the first statistics launch to merge: C2 bench 21.8e9 -> 22.2e9 samples/s)
+  const int tgrid = grid_for(env_int("NIS_INGEST_BPC", direct ? 4 : 8), G, N, NIS_TPB);
   bool col_in_w[2] = {direct, direct};
   nis_prof_mark(NIS_K_INGEST, 1, s);
   if (direct)

@@ -404,9 +404,13 @@ __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __
   }
   constexpr int U = NIS_STATS_U;
   const double* px = planes + (size_t)c.in_plane[0] * ld;
-  const float* wr = ROWS ? c.wrows + (size_t)g * c.wrows_gs + c.x_wcol : nullptr;
+  typedef float nis_f2 __attribute__((ext_vector_type(2)));
+  const nis_f2* wr = ROWS ? reinterpret_cast<const nis_f2*>(c.wrows + (size_t)g * c.wrows_gs) : nullptr;
+  const bool wcol1 = ROWS && c.x_wcol == 1;
   auto sample = [&](long tile0, int l) -> double {                // tile0 wave-uniform, l = lane
-    return ROWS ? (double)(wr + 2 * tile0)[2 * l] : (px + tile0)[l];
+    if (!ROWS) return (px + tile0)[l];
+    const nis_f2 r = (wr + tile0)[l];                             // the whole 8-byte row: same request shape as a plane load
+    return (double)(wcol1 ? r.y : r.x);
   };
   const long stride = (long)gridDim.x * TPB;
   long wbase = (long)blockIdx.x * TPB + wave * NIS_WAVE;          // wave-uniform: index of lane 0's next sample
