@@ -1082,3 +1082,32 @@ def test_integrate_steps_can_be_captured_in_a_hip_graph(G, N):
     assert torch.equal(out, ref)
     sd2 = NF.best_model.state_dict()
     assert all(torch.equal(sd1[k], sd2[k]) for k in sd1)
+
+
+# ------------------------------------------------------------------------------ driver contract
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """`python bench.py` (short run, child process): exactly one JSON line on stdout carrying the driver's fields, the live
+    roofline object of the dominant kernel and a result that agrees with the camel integral."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "10", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                   ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                   ("config", dict), ("roofline", dict)):
+        assert isinstance(d[k], typ), k
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 20 and d["scaling"] == "weak"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["launches"] == 4 and rf["avg_launch_us"] > 0                      # 2 launch sets x 2 cells
+    assert abs(d["value"] - 1e6 * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-9
+    assert abs(d["integral"]["value"] - 0.2323235706) < 6 * d["integral"]["sigma_mc"]
+    assert d["rambo"]["roofline"]["launches"] == 20
