@@ -615,15 +615,16 @@ def test_pwlin_input_one_raises_index_error():
         cell(x)
 
 
-@pytest.mark.parametrize("G", [1, 3, 7])
-def test_batched_iterations_equal_one_by_one(G):
-    """nis_integrate_steps with G batches == G separate calls (records and running statistics), train mode."""
+@pytest.mark.parametrize("G,n_cells", [(1, 2), (3, 2), (7, 2), (2, 18)])
+def test_batched_iterations_equal_one_by_one(G, n_cells):
+    """nis_integrate_steps with G batches == G separate calls (records and running statistics), train mode.
+    18 cells: the running-statistics epilogue (k_group_epilogue, 16 cells per launch) is split over two launches."""
     from nf_amd import integrands
     f = integrands.Camel()
     torch.manual_seed(4)
-    A = build_manager(dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3]))
+    A = build_manager(dict(kind="pwquad", d=2, n_cells=n_cells, K=4, NN=[3, 3, 3]))
     sd = {k: v.clone() for k, v in A._model.state_dict().items()}
-    B = build_manager(dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3]))
+    B = build_manager(dict(kind="pwquad", d=2, n_cells=n_cells, K=4, NN=[3, 3, 3]))
     B._model.load_state_dict(sd)
     w = torch.rand(G, 50_001, 2, dtype=torch.float32, device=dev())
     outA = torch.zeros((G, 4), dtype=torch.double, device=dev())
