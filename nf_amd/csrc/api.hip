@@ -914,6 +914,8 @@ static bool direct_rows_ok(const nis_flow* f, const std::vector<CellLayout>& lay
     if (cd.n_hidden < 1 || cd.n_hidden > 5) return false;               // k_bn_stats_fold instantiations: BN layers 2..5
     if (cd.in_col[0] < 0 || cd.in_col[0] > 1 || cd.in_col[1] < 0 || cd.in_col[1] > 1) return false;
     if (in_w[cd.in_col[0]] && !in_w[cd.in_col[1]]) return false;        // the row kernels take xb (and optionally x) from w
+    if (ci + 1 < f->n_cells && f->cells[ci + 1].in_col[0] != cd.in_col[1]) return false;   // SPEC 1: the next cell passes this output through
+    if (ci + 1 == f->n_cells && !((f->out_col[0] == 0 && f->out_col[1] == 1) || (f->out_col[0] == 1 && f->out_col[1] == 0))) return false;
     in_w[cd.in_col[1]] = false;
   }
   return true;

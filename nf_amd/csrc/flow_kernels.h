@@ -789,15 +789,14 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const int src = c.next_src[f];
-        if (SP) nv[f] = src == 0 ? x0 : 0.0;                        // the one pass-through column is already in a register
+        if (SP) nv[f] = 0.0;                                        // SPEC 1: the next cell passes this cell's OUTPUT through (set below)
         else nv[f] = (src >= 0 && src < cP) ? planes[(size_t)c.in_plane[src < 0 ? 0 : src] * ld + i] : 0.0;
       }
     }
     if (fuse) {
       if (SP) {
-        c0 = fz.loc0 == 0 ? x0 : 0.0;
-        c1 = fz.loc1 == 0 ? x0 : 0.0;
-      } else if (fkind == NIS_F_CAMEL) {
+        c0 = x0;                       // SPEC 2: the camel is symmetric in its two arguments (IEEE addition commutes), so the
+      } else if (fkind == NIS_F_CAMEL) {   // pass-through input and the output y are taken in this fixed order
         if (fz.loc0 >= 0 && fz.loc0 < cP) c0 = planes[(size_t)c.in_plane[fz.loc0] * ld + i];
         if (fz.loc1 >= 0 && fz.loc1 < cP) c1 = planes[(size_t)c.in_plane[fz.loc1] * ld + i];
       } else if (fkind == NIS_F_NORMAL) {
@@ -860,13 +859,15 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
       jprod *= jf;
       if (KIND != NIS_AFFINE && bins_o && g == 0) bins_o[(size_t)(c.bins_row + t) * ld + i] = bin;
       if (next) {
+        if (SP) nv[0] = y;             // launch_apply checked next_src[0] == 1
 #pragma unroll
         for (int f = 0; f < NF; ++f)
-          if (c.next_src[f] == cP + t) nv[f] = y;
+          if (!SP && c.next_src[f] == cP + t) nv[f] = y;
       }
       if (fuse) {
-        if (fz.loc0 == cP + t) c0 = y;
-        if (fz.loc1 == cP + t) c1 = y;
+        if (SP) c1 = y;                // launch_apply checked {loc0, loc1} == {0, 1}
+        if (!SP && fz.loc0 == cP + t) c0 = y;
+        if (!SP && fz.loc1 == cP + t) c1 = y;
         if (fkind == NIS_F_NORMAL) nsum += ((y - fz.p[0]) * (y - fz.p[0])) / (2 * fz.p[1] * fz.p[1]);
       }
     }

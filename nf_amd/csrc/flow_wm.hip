@@ -168,8 +168,11 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
   if (c.wrows && c.x_wcol >= 0 && !rows) return hipErrorInvalidValue;
   if (c.wx == 3 && c.kind == NIS_PWQUAD && km < 0 && c.P == 1 && c.T == 1 && c.fold && c.out_off == 0 && !bins && !fz.fres) {
     // the two cells of a d = 2 chain: every wave-uniform switch resolved at compile time (k_cell_apply, SPEC)
-    const int spec = (c.next_P == 1 && fz.kind < 0 && fz.write_planes) ? 1
-                     : (c.next_P == 0 && fz.kind == NIS_F_CAMEL && !fz.write_planes) ? 2 : 0;
+    // 1: the next cell passes THIS cell's output through (next_src[0] == 1: the alternating roll of a d = 2 chain);
+    // 2: the camel's two arguments are this cell's two columns, in either order (the integrand is symmetric)
+    const int spec = (c.next_P == 1 && c.next_src[0] == 1 && fz.kind < 0 && fz.write_planes) ? 1
+                     : (c.next_P == 0 && fz.kind == NIS_F_CAMEL && !fz.write_planes && (fz.loc0 == 0 || fz.loc0 == 1) &&
+                        fz.loc1 == 1 - fz.loc0) ? 2 : 0;
     if (spec == 1) {
       switch (km) {
         case -4: NIS_APPLY3S(4, 1); return hipGetLastError();
