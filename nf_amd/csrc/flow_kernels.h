@@ -697,7 +697,8 @@ __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const do
 // as a scalar branch; resolving them removes ~60 branches, the SGPR spills and their v_readlane traffic from the loop.
 // ROWS (SPEC kernels only): the transformed input -- and, for c.x_wcol >= 0, the pass-through input too -- is read from the
 // float32 (N, 2) rows of w (CellK::wrows) instead of its plane: one 8-byte row load per sample.
-template <int KIND, int WM, int KM, bool KEXACT, int WX = WM, int SPEC = 0, bool ROWS = false>
+// FIRST (ROWS kernels): the flow's first cell -- both inputs come from the row, the incoming Jacobian is 1: ONE load per sample.
+template <int KIND, int WM, int KM, bool KEXACT, int WX = WM, int SPEC = 0, bool ROWS = false, bool FIRST = false>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                         int* __restrict__ bins_out, FuseF fz) {
   static_assert(!ROWS || SPEC != 0, "row input exists on the SPEC kernels only");
@@ -720,21 +721,24 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   // and iteration: ~0.7 us of arithmetic against ~2 us of HBM latency, 3-4 waves per SIMD); the first request goes out
   // inside the prologue.  jsrc: a first cell has no Jacobian plane to read -- it re-reads x (same line, L1 hit) so that
   // the loop's vector-memory sequence is fixed and the compiler's vmcnt bookkeeping stays exact.
+  static_assert(!FIRST || ROWS, "FIRST is a property of the row-input kernels");
   const nis_f2* const rows = ROWS ? reinterpret_cast<const nis_f2*>(c.wrows + (size_t)g * c.wrows_gs) : nullptr;
-  const bool xrow = ROWS && c.x_wcol >= 0;                         // pass-through input from the row as well (first cell)
-  // xrow: P0 aliases the row (same 8 bytes, L1 hit, value unused) so that the loop's load sequence stays fixed
-  const double* const P0 = xrow ? reinterpret_cast<const double*>(rows) : planes + (size_t)c.in_plane[0] * ld;
+  constexpr bool xrow = ROWS && FIRST;                             // pass-through input from the row as well
+  const bool rswap = ROWS && (FIRST ? c.x_wcol == 1 : c.xb_wcol == 0);   // FIRST: (x, xb) = (r.y, r.x);  later cells: xb = r.x
+  const double* const P0 = planes + (size_t)c.in_plane[0] * ld;
   double* const P1 = planes + (size_t)c.in_plane[SP ? 1 : 0] * ld;
-  const double* const jsrc = c.first ? P0 : planes + (size_t)c.jplane * ld;
+  // plane kernels: a first cell has no Jacobian plane to read -- it re-reads x (same line, L1 hit) so that the loop's
+  // vector-memory sequence is fixed and the compiler's vmcnt bookkeeping stays exact
+  const double* const jsrc = (!ROWS && c.first) ? P0 : planes + (size_t)c.jplane * ld;
   const long i_first = (long)blockIdx.x * NIS_TPB + tid;
   double xq = 0.0, xbq = 0.0, jq = 0.0;
   nis_f2 rq = {0.f, 0.f};
   auto first_loads = [&]() {
     if (SP && i_first < N) {
-      xq = P0[i_first];
+      if (!xrow) xq = P0[i_first];
       if (ROWS) rq = rows[i_first];
       else xbq = P1[i_first];
-      jq = jsrc[i_first];
+      if (!FIRST) jq = jsrc[i_first];
     }
   };
   load_coefs<WM, NIS_TPB>(c, g, c.L + 1, (bn_train && c.pmerge) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red, first_loads);
@@ -762,15 +766,15 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   for (long i = i_first; i < N; i += stride) {
     double a[WM];
     // SPEC: this sample's inputs, requested one iteration ago
-    const double x0 = xrow ? (double)(c.x_wcol ? rq.y : rq.x) : xq;
-    const double xb0 = ROWS ? (double)(c.xb_wcol ? rq.y : rq.x) : xbq;
-    const double jin = c.first ? 1.0 : jq;
+    const double x0 = xrow ? (double)(rswap ? rq.y : rq.x) : xq;
+    const double xb0 = ROWS ? (double)(rswap ? rq.x : rq.y) : xbq;
+    const double jin = ROWS ? (FIRST ? 1.0 : jq) : (c.first ? 1.0 : jq);
     if (SP) {
       const long ic = i + stride < N ? i + stride : i;              // last round: re-read the current sample (unused)
-      xq = P0[ic];
+      if (!xrow) xq = P0[ic];
       if (ROWS) rq = rows[ic];
       else xbq = P1[ic];
-      jq = jsrc[ic];
+      if (!FIRST) jq = jsrc[ic];
 #pragma unroll
       for (int p = 0; p < WM; ++p) a[p] = p == 0 ? x0 : 0.0;
     } else {
