@@ -911,7 +911,7 @@ static bool direct_rows_ok(const nis_flow* f, const std::vector<CellLayout>& lay
     const nis_cell_desc& cd = f->cells[ci];
     if (cd.kind != NIS_PWQUAD || cd.P != 1 || lay[ci].WM != 4 || cell_wx(cd, 4) != 3) return false;
     if (!(lay[ci].KM == -4 || lay[ci].KM == -8 || lay[ci].KM == -16)) return false;
-    if (cd.n_hidden < 1 || cd.n_hidden > 5) return false;               // k_bn_stats_fold instantiations: BN layers 2..5
+    if (cd.n_hidden != 3) return false;                                 // SPEC apply kernels: three hidden layers, unrolled
     if (cd.in_col[0] < 0 || cd.in_col[0] > 1 || cd.in_col[1] < 0 || cd.in_col[1] > 1) return false;
     if (in_w[cd.in_col[0]] && !in_w[cd.in_col[1]]) return false;        // the row kernels take xb (and optionally x) from w
     if (ci + 1 < f->n_cells && f->cells[ci + 1].in_col[0] != cd.in_col[1]) return false;   // SPEC 1: the next cell passes this output through

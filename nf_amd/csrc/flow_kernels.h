@@ -809,7 +809,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
           if (p < cP) nsum += ((a[p] - fz.p[0]) * (a[p] - fz.p[0])) / (2 * fz.p[1] * fz.p[1]);
       }
     }
-    hidden_stack<WM, WX>(c, lds_coef, c.L, true, a, fold);
+    hidden_stack<WM, WX>(c, lds_coef, SP ? 3 : c.L, true, a, fold);      // SPEC: three hidden layers (launch_apply checks)
     double jprod = 1.0;
     for (int t = 0; t < cT; ++t) {
       double* col = SP ? P1 : planes + (size_t)c.in_plane[cP + t] * ld;
