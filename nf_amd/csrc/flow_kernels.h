@@ -372,7 +372,7 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
 // layer a compile-time constant: every coefficient and weight of the stack is hoisted into registers before the sample
 // loop (the generic kernel re-reads them per sample and layer behind s_waitcnt lgkmcnt(0)), whole wave tiles run
 // unguarded with U loads in flight off one scalar base, and the wave's shift enters the last layer's FMA chain as
-// its start value.  PMC on C2: 67 -> ~40 VALU instructions per sample, no scalar-memory or LDS traffic in the loop.
+// its start value.  PMC on C2: 67 -> 44 VALU instructions per sample, no scalar-memory or LDS traffic in the loop.
 #ifndef NIS_STATS_U
 #define NIS_STATS_U 4
 #endif
