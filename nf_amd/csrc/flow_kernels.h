@@ -526,6 +526,13 @@ __device__ __forceinline__ double last_dot(nis_cptr wl, nis_cptr bias, int row, 
   return acc;
 }
 
+// A wave-uniform double as a scalar value (two v_readfirstlane): lets uniform arithmetic done once on the vector pipe
+// feed v_fma_f64 as an SGPR operand afterwards.
+__device__ __forceinline__ double nis_uniform(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 // torch.lerp(start, end, weight) as the CPU kernel evaluates it (used at coupling_cells.py:224)
 __device__ __forceinline__ double lerp_torch(double a, double b, double w) {
   const double d = b - a;
@@ -757,6 +764,28 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   const int fkind = SPEC == 2 ? (int)NIS_F_CAMEL : fz.kind;
   const bool wplanes = SPEC == 1 ? true : SPEC == 2 ? false : fz.write_planes != 0;
   double* const fres = SP ? nullptr : fz.fres;
+  // SPEC, K = 4: the bijector only sees V up to a common factor and W up to a common factor (y and the Jacobian divide by
+  // the area sum (V_k + V_k+1) W_k and by sum W), so the last height and the last width are taken as exp(0) = 1 and every
+  // other logit is computed RELATIVE to them: rows k - K and K+1+k - 2K of the last layer, differenced once per workgroup
+  // into scalar registers.  7 instead of 9 exps and dot products per sample; values move by a few 1e-16 (rounding only).
+  constexpr bool SHIFT = SP && KIND == NIS_PWQUAD && KM == 4;
+  constexpr int RS = SHIFT ? 2 * KM + 1 : 1;
+  double wd[RS][WX], bd[RS];
+  if (SHIFT) {
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+      const int ref = r <= KM ? KM : 2 * KM;
+      bd[r] = nis_uniform(bias[r] - bias[ref]);
+#pragma unroll
+      for (int i = 0; i < WX; ++i) wd[r][i] = nis_uniform(wl[r * WM + i] - wl[ref * WM + i]);
+    }
+  }
+  auto rel_exp = [&](int r, const double (&av)[WM]) -> double {
+    double acc = bd[SHIFT ? r : 0];
+#pragma unroll
+    for (int i = 0; i < WX; ++i) acc = fma(wd[SHIFT ? r : 0][i], av[i], acc);
+    return nis_exp(acc, etab);
+  };
   double nS1[NF], nS2[NF], nsh[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) nS1[f] = nS2[f] = nsh[f] = 0.0;
@@ -819,13 +848,20 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
       int bin;
       if (KIND == NIS_PWQUAD) {
         double V[KM + 1], W[KM];
-#pragma unroll
-        for (int k = 0; k < KM + 1; ++k)
-          V[k] = (KEXACT || k <= c.K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + k, a), etab) : 0.0;                   // :173,189
         const int Kq = KEXACT ? KM : c.K;
+        if (SHIFT) {
 #pragma unroll
-        for (int k = 0; k < KM; ++k)
-          W[k] = (KEXACT || k < c.K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + Kq + 1 + k, a), etab) : 0.0;             // :175,178
+          for (int k = 0; k < KM + 1; ++k) V[k] = k < KM ? rel_exp(k, a) : 1.0;
+#pragma unroll
+          for (int k = 0; k < KM; ++k) W[k] = k < KM - 1 ? rel_exp(KM + 1 + k, a) : 1.0;
+        } else {
+#pragma unroll
+          for (int k = 0; k < KM + 1; ++k)
+            V[k] = (KEXACT || k <= c.K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + k, a), etab) : 0.0;                 // :173,189
+#pragma unroll
+          for (int k = 0; k < KM; ++k)
+            W[k] = (KEXACT || k < c.K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + Kq + 1 + k, a), etab) : 0.0;           // :175,178
+        }
         y = pwquad_column<KM, KEXACT>(xb, c.K, V, W, &jf, &bin, GATHER ? lds_gather + tid : nullptr);
       } else if (KIND == NIS_AFFINE) {
         // AffineCoupling (coupling_cells.py:56-68): rows [scale | shift][T];  y = atan(20 e^z0 x + relu(z1)) / (pi/2)
