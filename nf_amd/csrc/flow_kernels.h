@@ -786,7 +786,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
       const int ref = r <= KM ? KM : 2 * KM;
-      bd[r] = nis_uniform(bias[r] - bias[ref]);
+      bd[r] = bias[r] - bias[ref];                       // stays in a VGPR: start value of the FMA chain (an SGPR addend would need a v_mov)
 #pragma unroll
       for (int i = 0; i < WX; ++i) wd[r][i] = nis_uniform(wl[r * WM + i] - wl[ref * WM + i]);
     }
