@@ -698,8 +698,9 @@ __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const do
       vk = vn;
     }
   const double Vb = zr[idx * ZS], Vb1 = zr[(idx + 1) * ZS], Wb = zr[(K + 1 + idx) * ZS];
-  const double iA = 1.0 / A;
-  const double alpha = (xb * wn - run) / Wb;                      // :206-207
+  const double r = nis_rcp(Wb * A);                               // one reciprocal for both divisions (see pwquad_column)
+  const double iA = r * Wb;
+  const double alpha = (xb * wn - run) * (r * A);                 // :206-207
   const double num = ((alpha * alpha) / 2 * (Vb1 - Vb) + alpha * Vb) * (2 * Wb) + pre;   // :213-220
   *jf = lerp_torch(Vb, Vb1, alpha) * ((2 * wn) * iA);             // :224-225
   *bin = idx;
