@@ -71,11 +71,14 @@ __device__ __forceinline__ void nis_exp_init(double* lds_tab) {
   if (threadIdx.x < 64) lds_tab[threadIdx.x] = NIS_EXP_TAB[threadIdx.x];
 }
 __device__ __forceinline__ double nis_exp(double x, const double* lds_tab) {
-  // no clamp: for |x| > 709 v_cvt_i32_f64 saturates and v_ldexp_f64 returns 0 / inf like exp() would
-  const double k = rint(x * 0x1.71547652b82fep+6);
+  // k = rint(64 x / ln 2) by the 1.5 * 2^52 trick: the add rounds to nearest-even and leaves k (two's complement) in the
+  // low word of the sum -- one FMA + one subtraction instead of multiply, v_rndne and v_cvt_i32.  Valid for |k| < 2^31
+  // (|x| < 2.3e7); no clamp: |x| > 709 gives |k >> 6| > 1023 and v_ldexp_f64 returns 0 / inf like exp() would.
+  const double kd = fma(x, 0x1.71547652b82fep+6, 0x1.8p+52);
+  const double k = kd - 0x1.8p+52;
   double r = fma(k, -0x1.62e42fef00000p-7, x);
   r = fma(k, -0x1.473de6af278edp-40, r);
-  const int ki = (int)k;
+  const int ki = __double2loint(kd);
   const double T = lds_tab[ki & 63];
   double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
   p = fma(r, p, 1.0 / 6.0);
