@@ -533,15 +533,6 @@ __device__ __forceinline__ double nis_uniform(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// 1 / x for x in the normal range: v_rcp_f64 (~26 bits) + two Newton steps, no scaling / fix-up sequence (5 instructions
-// instead of the ~14 of an IEEE division; result within 1 ulp).
-__device__ __forceinline__ double nis_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
-}
-
 // torch.lerp(start, end, weight) as the CPU kernel evaluates it (used at coupling_cells.py:224)
 __device__ __forceinline__ double lerp_torch(double a, double b, double w) {
   const double d = b - a;

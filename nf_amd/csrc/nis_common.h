@@ -88,6 +88,22 @@ __device__ __forceinline__ double nis_exp(double x, const double* lds_tab) {
   return ldexp(fma(T, p, T), ki >> 6);
 }
 
+// 1 / x and 1 / sqrt(x) for x in the normal range: v_rcp_f64 / v_rsq_f64 (~26 bits) + two Newton steps, no scaling / fix-up
+// sequence (5 / 8 instructions instead of the ~14 of an IEEE division, ~26 of sqrt + division; results within 1-2 ulp).
+__device__ __forceinline__ double nis_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double nis_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  r = fma(r, fma(-(h * r), r, 0.5), r);
+  r = fma(r, fma(-(h * r), r, 0.5), r);
+  return r;
+}
+
 static inline int nis_pick_wm(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 16 ? 16 : m <= 32 ? 32 : m <= 64 ? 64 : -1; }
 static inline int nis_pick_km(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : -1; }
 // workgroup size of the statistics kernel: as many waves as the register budget of width WM allows

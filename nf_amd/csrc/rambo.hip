@@ -29,10 +29,12 @@ struct RamboK {
 #define RB_EPS 1.4901161193847656e-08     /* np.finfo(float).eps ** 0.5   (utils.py:151) */
 #define RB_HUGE 1.7976931348623157e308    /* np.finfo(float).max */
 
-__device__ __forceinline__ double rb_rho(double M, double N, double m) {          // :107-113
+// rho(M, N, m) = rb_rho_num(M, N, m) / (8 M^2)                                   // :107-113
+__device__ __forceinline__ double rb_rho_num(double M, double N, double m) {
   const double Msqr = M * M;
-  return sqrt((Msqr - (N + m) * (N + m)) * (Msqr - (N - m) * (N - m))) / (8. * Msqr);
+  return sqrt((Msqr - (N + m) * (N + m)) * (Msqr - (N - m) * (N - m)));
 }
+__device__ __forceinline__ double rb_rho(double M, double N, double m) { return rb_rho_num(M, N, m) * nis_rcp(8. * (M * M)); }
 
 __device__ __forceinline__ double rb_ipow(double x, int e) {
   double p = 1.0;
@@ -85,9 +87,9 @@ __device__ __forceinline__ void rb_set_square(V4& p, double sq) { p.e = sqrt((p.
 
 __device__ __forceinline__ void rb_boost(V4& p, double bx, double by, double bz) {                                          // utils.py:58-81
   const double b2 = bx * bx + by * by + bz * bz;
-  const double gamma = 1.0 / sqrt(1.0 - b2);
+  const double gamma = nis_rsqrt(1.0 - b2);
   const double bp = p.x * bx + p.y * by + p.z * bz;
-  const double gamma2 = b2 > 0 ? (gamma - 1.0) / b2 : 0.0;
+  const double gamma2 = b2 > 1e-280 ? (gamma - 1.0) * nis_rcp(b2) : 0.0;      // (gamma - 1 is exactly 0 long before b2 gets that small)
   const double factor = gamma2 * bp + gamma * p.e;
   p.x += factor * bx;
   p.y += factor * by;
@@ -237,9 +239,11 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     double prod = 1.0;
 #pragma unroll
     for (int c = 0; c < NF - 2; ++c)
-      prod *= (rb_rho(M[c], M[c + 1], k.d.final_masses[c]) / rb_rho(Kk[c], Kk[c + 1], 0.)) * (M[c + 1] / Kk[c + 1]);   // :400-401
+      // rho(M_c, M_c+1, m_c) / rho(K_c, K_c+1, 0) * (M_c+1 / K_c+1) with ONE reciprocal (the 8 M^2 denominators cross over)   :400-401
+      prod *= (rb_rho_num(M[c], M[c + 1], k.d.final_masses[c]) * (Kk[c] * Kk[c]) * M[c + 1]) *
+              nis_rcp(rb_rho_num(Kk[c], Kk[c + 1], 0.) * (M[c] * M[c]) * Kk[c + 1]);
     w_ps *= prod;
-    w_ps *= rb_ipow(Kk[0] / M[0], 2 * NF - 4);                                      // :403
+    w_ps *= rb_ipow(Kk[0] * nis_rcp(M[0]), 2 * NF - 4);                                      // :403
     double wtot = wgt * w_ps;
 
     // ---- sequential two-body decays (:223-278)
@@ -270,7 +274,7 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
       const double m2 = k.d.final_masses[c] * k.d.final_masses[c];
       rb_set_square(p, m2);
       bad_boost |= (Q.e <= 0.) || ((Q.e * Q.e - Q.x * Q.x - Q.y * Q.y - Q.z * Q.z) < 0.);   // utils.py:33
-      const double iQe = 1.0 / Q.e;                                                 // boostVector_t: Q_space / Q_0 (utils.py:36)
+      const double iQe = nis_rcp(Q.e);                                                 // boostVector_t: Q_space / Q_0 (utils.py:36)
       rb_boost(p, Q.x * iQe, Q.y * iQe, Q.z * iQe);
       rb_set_square(p, m2);
       if (STREAM) {
@@ -369,7 +373,7 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     }
     wtot *= factor;
     const double shat = x1 * x2 * (k.d.E_cm * k.d.E_cm);
-    if (live) weight[i] = wtot / (2 * shat);
+    if (live) weight[i] = wtot * nis_rcp(2 * shat);
   }
 }
 
