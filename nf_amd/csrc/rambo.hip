@@ -54,14 +54,14 @@ __device__ __forceinline__ double rb_solve(double v, int e) {
   const bool convex = v < vi;
   double u;
   if (convex) {
-    const double vr = v / (double)(e + 1);
+    const double vr = v * (1.0 / (double)(e + 1));      // starting guesses: reciprocals instead of IEEE divisions (the fixed point does not move)
     const double us = e == 2 ? sqrt(vr) : e == 3 ? cbrt(vr) : e == 4 ? sqrt(sqrt(vr)) : pow(vr, 1.0 / (double)e);
-    double c0 = us / (1.0 - fmin(us, 0.9));
+    double c0 = us * nis_rcp(1.0 - fmin(us, 0.9));
     c0 = fmin(c0, ui);
     const double g0 = rb_ipow(c0, e) * ((double)(e + 1) - (double)e * c0);
     u = (g0 >= v) ? c0 : ui;
   } else {
-    const double ub = 1.0 - sqrt(2.0 * (1.0 - v) / (double)(e * (e + 1)));
+    const double ub = 1.0 - sqrt((1.0 - v) * (2.0 / (double)(e * (e + 1))));
     u = fmax(ui, ub);
   }
 #pragma unroll 1
@@ -69,7 +69,7 @@ __device__ __forceinline__ double rb_solve(double v, int e) {
     const double um1 = rb_ipow(u, e - 1);
     const double g = um1 * u * ((double)(e + 1) - (double)e * u) - v;
     const double gp = (double)(e * (e + 1)) * um1 * (1.0 - u);
-    double un = u - g / gp;
+    double un = u - g * nis_rcp(gp);                    // gp == 0 (NaN here) is discarded two lines below
     un = convex ? fmin(fmax(un, 0.0), ui) : fmin(fmax(un, ui), 1.0);
     un = (gp > 0.0) ? un : u;
     const bool moved = fabs(un - u) > 4e-16 * un;       // the iteration is monotone: no movement = fixed point
