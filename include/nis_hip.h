@@ -136,6 +136,28 @@ int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_b
                         double* planes, int64_t ld, int32_t keep_planes, double* fres_out, double* out4,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same loop body with the draw INSIDE the step (manager.py:395 `uniform_(w)` is part of integrate()'s loop): batch g
+ * is drawn on the device from the counter-based generator Philox4x32-10 (Salmon et al. 2011, Random123 constants),
+ *   w[g][n][c] = (philox(ctr = {n>>1 lo, n>>1 hi, s lo, s hi}, key = {seed lo, seed hi})[2 (n & 1) + c] >> 8) * 2^-24,
+ *   s = stream0 + g   (the float32 lattice torch's uniform_ produces, manager.py:390),
+ * by the launch that gathers BN_0's records (the rows are written once, 8 B/sample, into the state plane the d = 2
+ * direct-row chain leaves unused, and read from there by the cells) -- no input buffer, no separate generator pass.
+ * Defined for the d = 2 PWQuad chain with a fused camel (nis_integrate_steps' direct-row class); other models return
+ * NIS_E_UNSUPPORTED and the caller materialises the same draws with nis_philox_rows.  w_out (n_batches, N, 2) optional:
+ * the draws that were used (tests replay them through the oracle).  planes as for nis_integrate_steps.
+ * rng_state (optional, device): {seed, next stream} as two uint64 -- when given it overrides seed / stream0, is read by the
+ * drawing launch and advanced by n_batches in the set's last launch, so a launch set captured into a hipGraph draws fresh
+ * numbers on every replay.
+ * nis_integrate_resident: 1 when the calls run the opt-in persistent whole-step kernel (NIS_MEGA=1, flow_mega.hip: the
+ * batch lives in LDS from its draw to its moment record); `planes` may then be NULL. */
+int nis_integrate_steps_rng(nis_flow* f, int32_t n_batches, int64_t N,
+                            const double* const* params, double* const* running, long long* const* tracked,
+                            int32_t bn_mode, int64_t pack_token, int32_t f_kind, const double* f_params_host,
+                            uint64_t seed, uint64_t stream0, uint64_t* rng_state, float* w_out, double* planes, int64_t ld, double* out4,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int nis_integrate_resident(const nis_flow* f, int32_t n_batches, int64_t N, int32_t bn_mode, int32_t f_kind);
+int nis_philox_rows(uint64_t seed, uint64_t stream0, int32_t n_batches, int64_t N, float* out, void* stream);
+
 /* Train-mode forward whose BatchNorm statistics are those of the batch that is SHARDED over `world` ranks (SURVEY.md 8(e)
  * option 1, "SyncBN-exact": every rank passes its N rows; results equal the reference's single-batch forward of the
  * concatenated batch up to summation order).  After each launch that produces BatchNorm records the rank's records are

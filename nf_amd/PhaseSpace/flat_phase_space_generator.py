@@ -83,9 +83,10 @@ class FlatInvertiblePhasespace(VirtualPhaseSpaceGenerator):
         N = r.shape[0] if N is None else N
         ld = r.shape[1] if ld is None else ld
         cp = (C.c_int32 * len(cols))(*cols) if cols is not None else None
-        rc = L.nis_rambo_forward(C.byref(desc), r.data_ptr(), ld, 1 if col_major else 0, cp, N,
-                                 momenta.data_ptr() if momenta is not None else None, weight.data_ptr(),
-                                 status.data_ptr(), _lib.stream_ptr())
+        with _lib.on_device(r.device):
+            rc = L.nis_rambo_forward(C.byref(desc), r.data_ptr(), ld, 1 if col_major else 0, cp, N,
+                                     momenta.data_ptr() if momenta is not None else None, weight.data_ptr(),
+                                     status.data_ptr(), _lib.stream_ptr(r.device))
         _lib.check(rc, "nis_rambo_forward")
 
     def generateKinematics_batch(self, E_cm, random_variables_full, pT_mincut=-1, delR_mincut=-1, rap_maxcut=-1,
@@ -129,6 +130,19 @@ class FlatInvertiblePhasespace(VirtualPhaseSpaceGenerator):
         weight = torch.empty(N, dtype=torch.double, device=planes.device)
         status = torch.zeros(1, dtype=torch.int32, device=planes.device)
         self.collider_energy = E_cm
-        desc = self._desc(E_cm, pT_mincut, delR_mincut, rap_maxcut, bool(self.pdf_active))
+        lab = bool(self.pdf_active)
+        desc = self._desc(E_cm, pT_mincut, delR_mincut, rap_maxcut, lab)
         self._launch(desc, planes, None, weight, status, col_major=True, cols=list(cols), ld=planes.shape[1], N=N)
+        # the status word is honoured exactly as on the row path (generateKinematics_batch): NaN guard (reference :147-149),
+        # and the batch-global "skip the lab boost if any sample has x1 == x2" rule (utils.py:139-144)
+        st = int(status.item())
+        if st & 2:
+            raise PhaseSpaceGeneratorError("Some of the random variables passed to the phase-space generator are NaN")
+        if lab and (st & 4):
+            status.zero_()
+            self._launch(self._desc(E_cm, pT_mincut, delR_mincut, rap_maxcut, False), planes, None, weight, status, col_major=True,
+                         cols=list(cols), ld=planes.shape[1], N=N)
+            st = int(status.item())
+        if st & 8:
+            print("Invalid boost")    # utils.py:33-34
         return weight, status

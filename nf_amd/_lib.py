@@ -22,10 +22,11 @@ NIS_RAMBO_PDF_ACTIVE, NIS_RAMBO_TAU, NIS_RAMBO_LAB_BOOST = 1, 2, 4
 ERRORS = {-1: "invalid argument", -2: "configuration outside the compiled kernel set",
           -3: "workspace too small", -4: "HIP runtime error", -5: "no device"}
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnis_hip.so")
+LIB_PATH = os.environ.get("NIS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnis_hip.so")   # NIS_LIB: A/B builds (tools/)
 
 EXPORTS = ["nis_cell_param_count", "nis_cell_running_count", "nis_flow_create", "nis_flow_destroy",
-           "nis_flow_workspace_bytes", "nis_flow_forward", "nis_flow_forward_sync", "nis_integrate_steps", "nis_flow_backward_supported",
+           "nis_flow_workspace_bytes", "nis_flow_forward", "nis_flow_forward_sync", "nis_integrate_steps", "nis_integrate_steps_rng",
+           "nis_integrate_resident", "nis_philox_rows", "nis_flow_backward_supported",
            "nis_flow_bnsave_count", "nis_flow_forward_train", "nis_flow_backward_workspace_bytes", "nis_flow_backward", "nis_integrand_moments", "nis_integrand_eval",
            "nis_moments_workspace_bytes",
            "nis_moments", "nis_rambo_forward", "nis_prof_enable", "nis_prof_read", "nis_prof_disable", "nis_last_error", "nis_version", "nis_device_count"]
@@ -79,6 +80,14 @@ def lib():
     L.nis_integrate_steps.restype = i32
     L.nis_integrate_steps.argtypes = [vp, vp, i32, i32, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, i32,
                                       C.POINTER(C.c_double), vp, i64, i32, vp, vp, vp, sz, vp]
+    u64 = C.c_uint64
+    L.nis_integrate_steps_rng.restype = i32
+    L.nis_integrate_steps_rng.argtypes = [vp, i32, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, i32,
+                                          C.POINTER(C.c_double), u64, u64, vp, vp, vp, i64, vp, vp, sz, vp]
+    L.nis_integrate_resident.restype = i32
+    L.nis_integrate_resident.argtypes = [vp, i32, i64, i32, i32]
+    L.nis_philox_rows.restype = i32
+    L.nis_philox_rows.argtypes = [u64, u64, i32, i64, vp, vp]
     L.nis_flow_backward_supported.restype = i32
     L.nis_flow_backward_supported.argtypes = [vp]
     L.nis_flow_bnsave_count.restype = sz
@@ -134,6 +143,14 @@ def require_gpu():
     lib()
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """Current HIP stream of `device` (default: the current device) as the void* the C ABI takes."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_device(device):
+    """Context for every libnis_hip call: the kernels launch on the device that HOLDS the tensors (the reference selects
+    the GPU by argument: create_model(dev=), integrate(dev=)), not on whatever device happens to be current."""
+    import torch
+    return torch.cuda.device(device)

@@ -15,9 +15,10 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libnis_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"] + \
+        os.environ.get("NIS_EXTRA_FLAGS", "").split()          # diagnostics only (e.g. -DNIS_MEGA_STAMPS), never for the shipped library
 
-UNITS = [("api", "api.hip", []), ("rambo", "rambo.hip", []), ("flow_bwd", "flow_bwd.hip", [])] + \
+UNITS = [("api", "api.hip", []), ("rambo", "rambo.hip", []), ("flow_bwd", "flow_bwd.hip", []), ("flow_mega", "flow_mega.hip", [])] + \
         [(f"flow_wm{w}", "flow_wm.hip", [f"-DNIS_WM={w}"]) for w in (4, 8, 16, 32, 64)] + \
         [(f"flow_bwd_wm{w}", "flow_bwd_wm.hip", [f"-DNIS_WM={w}"]) for w in (16, 32, 64)]
 

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "flow_kernels.h"
+#include "flow_mega.h"
 
 static thread_local std::string g_err;
 static int fail_hip(hipError_t e, const char* what) {
@@ -125,13 +126,27 @@ struct nis_flow {
   int packed_G = 0;
   const void* packed_ws = nullptr;
   std::vector<const double*> packed_params;
+  const void* mega_ws = nullptr;     // workspace whose hand-off granules have been zeroed (flow_mega.hip)
 };
 
 static const size_t WS_HEADER = 256;   // bytes: status word + padding
 
 // Workspace body for G batched iterations: per cell the zero-padded parameter image (shared by all batches),
 // then per-batch BN coefficients, partial records and batch statistics; finally the integrand's moment records.
-static size_t flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay, size_t* off_fpart) {
+// The persistent whole-step kernel (flow_mega.hip) covers the README / C1 / C2 model: d = 2, two PWQuad cells with 4 bins,
+// one pass-through column, three hidden layers at most 3 wide.
+static bool mega_model(const nis_flow* f) {
+  if (f->d != 2 || f->n_cells != 2) return false;
+  for (int ci = 0; ci < 2; ++ci) {
+    const nis_cell_desc& c = f->cells[ci];
+    if (c.kind != NIS_PWQUAD || c.P != 1 || c.K != 4 || c.n_hidden != 3) return false;
+    for (int l = 0; l < 3; ++l)
+      if (c.width[l] > 3) return false;
+  }
+  return true;
+}
+
+static size_t flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay, size_t* off_fpart, size_t* off_mega = nullptr) {
   size_t off = 0;
   for (int i = 0; i < f->n_cells; ++i) {
     const nis_cell_desc& c = f->cells[i];
@@ -161,6 +176,9 @@ static size_t flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay
   }
   if (off_fpart) *off_fpart = off;
   off += (size_t)G * NIS_MAXB * 4;
+  off = (off + 31) / 32 * 32;                                   // 256-byte aligned: the scratch starts with its counter block
+  if (off_mega) *off_mega = off;
+  if (mega_model(f)) off += (nis_mega_scratch_bytes() + 7) / 8;
   return off;
 }
 
@@ -317,6 +335,7 @@ struct IngestStats {
   int* status;                     // zeroed here (first launch of a forward)
   int maxb;                        // record stride between batches
   long plane_gs;                   // doubles between the plane sets of consecutive batches
+  int g0;                          // first batch of this launch (blockIdx.y counts from it)
 };
 
 template <typename TIN>
@@ -327,7 +346,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest(const TIN* __restrict__ w, l
   __shared__ double wshift[NW][NF];
   __shared__ double wmom[NW][NF][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = blockIdx.y;
+  const int g = st.g0 + blockIdx.y;
   w += (size_t)g * N * d;
   planes += (size_t)g * st.plane_gs;
   if (blockIdx.x == 0 && g == 0 && threadIdx.x == 0 && st.status) *st.status = 0;
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest2(const TIN* __restrict__ w, 
   __shared__ double wshift[NW][NF];
   __shared__ double wmom[NW][NF][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = blockIdx.y;
+  const int g = st.g0 + blockIdx.y;
   const vec2* rows = reinterpret_cast<const vec2*>(w + (size_t)g * N * 2);
   planes += (size_t)g * st.plane_gs;
   if (blockIdx.x == 0 && g == 0 && threadIdx.x == 0 && st.status) *st.status = 0;
@@ -426,6 +445,74 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest2(const TIN* __restrict__ w, 
           cnt += 1.0;
         }
       }
+    }
+  }
+  if (st.P > 0) emit_records<NF, NW>(S1, S2, cnt, wshift, wmom, st.P, st.partials + ((size_t)g * st.maxb + blockIdx.x) * st.wm * 3);
+}
+
+// In-kernel draws for the direct-row chain: the record pass GENERATES batch g's float32 rows (Philox4x32-10, the mapping of
+// nis_philox_rows / flow_mega.hip: sample n takes words 2 (n & 1), 2 (n & 1) + 1 of the call with counter n >> 1 on stream
+// stream0 + g) instead of reading them, writes them where the cells will read them, and gathers BN_0's records as k_ingest2
+// does.  One thread = one Philox call = two consecutive samples = one 16-byte store.
+__device__ __forceinline__ void nis_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+__global__ __launch_bounds__(NIS_TPB) void k_ingest2_rng(unsigned long long seed, unsigned long long stream0,
+                                                         const unsigned long long* __restrict__ state, long N, float* __restrict__ rows,
+                                                         long rows_gs, float* __restrict__ w_out, IngestStats st) {
+  typedef float vec4 __attribute__((ext_vector_type(4)));
+  constexpr int NW = NIS_TPB / NIS_WAVE, NF = 2;
+  __shared__ double wshift[NW][NF];
+  __shared__ double wmom[NW][NF][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = st.g0 + blockIdx.y;
+  if (state) {                                     // device-resident generator state (graph replays): {seed, next stream}
+    seed = state[0];
+    stream0 = state[1];
+  }
+  const unsigned long long sid = stream0 + (unsigned long long)g;
+  float* dst = rows + (size_t)g * rows_gs;
+  if (blockIdx.x == 0 && g == 0 && threadIdx.x == 0 && st.status) *st.status = 0;
+  double S1[NF] = {0.0, 0.0}, S2[NF] = {0.0, 0.0};
+  double cnt = 0.0;
+  bool firstit = true;
+  const int s0 = st.P > 0 ? st.sel[0] : 0;
+  const long npair = (N + 1) / 2;
+  const long stride = (long)gridDim.x * NIS_TPB;
+  for (long c = (long)blockIdx.x * NIS_TPB + threadIdx.x; c < npair; c += stride) {
+    unsigned r[4];
+    nis_philox4x32_10((unsigned)c, (unsigned)((unsigned long long)c >> 32), (unsigned)sid, (unsigned)(sid >> 32), (unsigned)seed,
+                      (unsigned)(seed >> 32), r);
+    const vec4 v = {(float)(r[0] >> 8) * 0x1p-24f, (float)(r[1] >> 8) * 0x1p-24f, (float)(r[2] >> 8) * 0x1p-24f, (float)(r[3] >> 8) * 0x1p-24f};
+    const bool two = 2 * c + 1 < N;
+    if (two) {
+      *reinterpret_cast<vec4*>(dst + 4 * c) = v;
+      if (w_out) *reinterpret_cast<vec4*>(w_out + (size_t)g * N * 2 + 4 * c) = v;
+    } else {
+      dst[4 * c] = v.x;
+      dst[4 * c + 1] = v.y;
+      if (w_out) w_out[(size_t)g * N * 2 + 4 * c] = v.x, w_out[(size_t)g * N * 2 + 4 * c + 1] = v.y;
+    }
+    if (st.P > 0) {
+      const double a0 = (double)(s0 == 0 ? v.x : v.y), a1 = (double)(s0 == 0 ? v.z : v.w);   // feature 0 of the pair's two samples
+      if (firstit) {
+        const double f0 = wave_first(a0);
+        if (lane == 0) wshift[wave][0] = f0, wshift[wave][1] = 0.0;
+        firstit = false;
+      }
+      const double t0 = a0 - wshift[wave][0], t1 = two ? a1 - wshift[wave][0] : 0.0;
+      S1[0] += t0 + t1;
+      S2[0] = fma(t0, t0, S2[0]);
+      S2[0] = fma(t1, t1, S2[0]);
+      cnt += two ? 2.0 : 1.0;
     }
   }
   if (st.P > 0) emit_records<NF, NW>(S1, S2, cnt, wshift, wmom, st.P, st.partials + ((size_t)g * st.maxb + blockIdx.x) * st.wm * 3);
@@ -680,6 +767,7 @@ struct EpiJob {
   const double* fpart;
   double* out4;
   int fparts, maxb;
+  unsigned long long* rng_state;     // {seed, next stream}: next stream += G (last thing the launch set does)
 };
 __global__ __launch_bounds__(NIS_TPB) void k_group_epilogue(EpiJob job) {
   const int b = blockIdx.x;
@@ -687,6 +775,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_group_epilogue(EpiJob job) {
   if (b >= nupd) {
     const int g = b - nupd;
     moments_final_body(job.fpart + (size_t)g * job.maxb * 4, job.fparts, job.out4 + (size_t)g * 4);
+    if (g == 0 && threadIdx.x == 0 && job.rng_state) job.rng_state[1] += (unsigned long long)job.G;
     return;
   }
   int ci = 0;
@@ -832,6 +921,12 @@ struct RunOpts {
   void* sync_ctx = nullptr;
   double* sync_buf = nullptr;
   int sync_world = 1, sync_rank = 0;
+  // in-kernel draws (nis_integrate_steps_rng): w == nullptr, the persistent kernel generates batch g from Philox stream stream0 + g
+  int rng = 0;
+  unsigned long long seed = 0, stream0 = 0;
+  float* w_out = nullptr;
+  unsigned long long* rng_state = nullptr;   // device {seed, next stream}: read by the drawing launch, advanced by n_batches in the
+                                             //   set's epilogue launch -- a captured launch set draws new numbers on every replay
 };
 
 // declared in flow_bwd.hip
@@ -854,10 +949,35 @@ static int sync_records(const RunOpts& o, const double* records, int nparts, int
   return NIS_OK;
 }
 
+// Side streams of the multi-chain mode (flow_run): created once per device, non-blocking; fork / join events without timing.
+struct SidePool {
+  std::vector<hipStream_t> stream;
+  std::vector<hipEvent_t> join, stag;
+  hipEvent_t fork = nullptr;
+};
+static SidePool* side_pool(int n) {
+  static SidePool pools[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SidePool& p = pools[dev];
+  if (!p.fork && hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+  while ((int)p.stream.size() < n) {
+    hipStream_t st;
+    hipEvent_t ev, ev2;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&ev2, hipEventDisableTiming) != hipSuccess) return nullptr;
+    p.stream.push_back(st);
+    p.join.push_back(ev);
+    p.stag.push_back(ev2);
+  }
+  return &p;
+}
+
 template <int WM>
 static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, long ld, long N, int bn_mode, int km, int* bins,
                     const FuseF& fz, bool need_stats0, int grid_stats, int grid_apply, int grid_mf, hipStream_t s,
-                    const RunOpts& o) {
+                    const RunOpts& o, hipEvent_t pre_apply = nullptr) {
   if (bn_mode == NIS_BN_TRAIN) {
     if (need_stats0) {
       NisProfScope ps(NIS_K_STATS, s);
@@ -878,6 +998,7 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
       if (!c.pmerge) HIP_OK(launch_finalize<WM>(c, l, s));
     }
   }
+  if (pre_apply) HIP_OK(hipEventRecord(pre_apply, s));      // the next chain of the set starts here (flow_run: staggered chains)
   {
     NisProfScope ps(NIS_K_APPLY, s);
     if (mfma)
@@ -923,7 +1044,7 @@ static bool direct_rows_ok(const nis_flow* f, const std::vector<CellLayout>& lay
 
 static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, const double* const* params, double* const* running,
                     double* planes, int64_t ld, void* workspace, size_t workspace_bytes, hipStream_t s, const RunOpts& o) {
-  if (!f || !w || !params || !running || !planes || N < 1 || ld < N) return NIS_E_ARG;
+  if (!f || (!w && !o.rng) || !params || !running || N < 1 || (planes && ld < N)) return NIS_E_ARG;
   if (o.bn_mode != NIS_BN_EVAL && o.bn_mode != NIS_BN_TRAIN) return NIS_E_ARG;
   if (w_dtype != NIS_F64 && w_dtype != NIS_F32) return NIS_E_ARG;
   const int G = o.G;
@@ -931,8 +1052,8 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   if (G > 1 && (o.xj_out || o.bins_out || o.w_has_jac || o.hist)) return NIS_E_UNSUPPORTED;
   if (!workspace || workspace_bytes < nis_flow_workspace_bytes(f, G)) return NIS_E_WORKSPACE;
   std::vector<CellLayout> lay;
-  size_t off_fpart = 0;
-  flow_layout(f, G, &lay, &off_fpart);
+  size_t off_fpart = 0, off_mega = 0;
+  flow_layout(f, G, &lay, &off_fpart, &off_mega);
   int* status = (int*)workspace;
   double* body = (double*)((char*)workspace + WS_HEADER);
   const int d = f->d;
@@ -964,65 +1085,9 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   // (N, 2) float32 rows of w are read by the cells themselves (a column lives in w until a cell overwrites it) and the
   // ingest launch only gathers BN_0's records: 80 MB read instead of 80 MB read + 160 MB written per 1e7 samples.
   const bool direct = direct_rows_ok(f, lay, o, w_dtype, wcols, ist.P) && !env_int("NIS_NO_DIRECT_ROWS", 0);
-  // ingest / emit: 256-thread streaming workgroups, 8 per CU; the read-only record pass of the direct mode runs best at 4
-  // (half the BN_0 records for the first statistics launch to merge: C2 bench 21.8e9 -> 22.2e9 samples/s)
-  const int tgrid = grid_for(env_int("NIS_INGEST_BPC", direct ? 4 : 8), G, N, NIS_TPB);
-  bool col_in_w[2] = {direct, direct};
-  nis_prof_mark(NIS_K_INGEST, 1, s);
-  if (direct)
-    hipLaunchKernelGGL((k_ingest2<float, false>), dim3(tgrid, G), dim3(NIS_TPB), 0, s, (const float*)w, (long)N, planes, (long)ld, ist);
-  else if (wcols == 2 && ist.P <= 2 && w_dtype == NIS_F64)
-    hipLaunchKernelGGL(k_ingest2<double>, dim3(tgrid, G), dim3(NIS_TPB), 0, s, (const double*)w, (long)N, planes, (long)ld, ist);
-  else if (wcols == 2 && ist.P <= 2)
-    hipLaunchKernelGGL(k_ingest2<float>, dim3(tgrid, G), dim3(NIS_TPB), 0, s, (const float*)w, (long)N, planes, (long)ld, ist);
-  else if (w_dtype == NIS_F64)
-    hipLaunchKernelGGL(k_ingest<double>, dim3(tgrid, G), dim3(NIS_TPB), tile_bytes, s, (const double*)w, (long)N, wcols, planes, (long)ld,
-                       ist);
-  else
-    hipLaunchKernelGGL(k_ingest<float>, dim3(tgrid, G), dim3(NIS_TPB), tile_bytes, s, (const float*)w, (long)N, wcols, planes, (long)ld,
-                       ist);
-  nis_prof_mark(NIS_K_INGEST, 0, s);
-  HIP_OK(hipGetLastError());
-  if (o.sync_fn) {
-    if (G != 1 || !train || o.hist) return NIS_E_UNSUPPORTED;
-    if (ingest_stats)
-      if (int rc = sync_records(o, ist.partials, tgrid, lay[0].WM, s)) return rc;
-  }
-
-  EpiJob epi;                          // G > 1, train mode: running-statistics updates (+ moment merge) in one launch at the end
-  memset(&epi, 0, sizeof(epi));
-  epi.G = G;
-  auto epi_flush = [&](const double* fpart, int fparts) -> int {
-    if (epi.ncell == 0 && !fpart) return NIS_OK;
-    epi.fpart = fpart;
-    epi.fparts = fparts;
-    epi.out4 = o.out4;
-    epi.maxb = NIS_MAXB;
-    NisProfScope ps(NIS_K_MOMENTS, s);
-    hipLaunchKernelGGL(k_group_epilogue, dim3(epi.blk_off[epi.ncell] + (fpart ? G : 0)), dim3(NIS_TPB), 0, s, epi);
-    HIP_OK(hipGetLastError());
-    epi.ncell = 0;
-    return NIS_OK;
-  };
-  int prev_records = tgrid;           // records of BN_0 of the current cell written by the previous launch
-  bool have_stats0 = ingest_stats;
-  double* const planes0 = planes;
-  size_t bn_off = 0;
-  for (int ci = 0; ci < f->n_cells; ++ci) {
+  // ---- parameter image (before anything forks): zero-padded weights (+ MFMA fragments, + eval-mode BN affine)
+  auto cell_shape = [&](int ci) {
     const nis_cell_desc& cd = f->cells[ci];
-    const CellLayout& L = lay[ci];
-    if (o.hist) planes = planes0 + (size_t)ci * plane_gs;
-    if (!params[ci] || !running[ci]) return NIS_E_ARG;
-    int grid_stats = 1, grid_apply = 1;
-    switch (L.WM) {
-      // folded statistics launches (k_bn_stats_fold): train mode, one pass-through column, BN_1 derived
-      case 4: cell_grids<4>(cd.kind, L.KM, cell_wx(cd, L.WM), train && cd.P == 1 && !env_int("NIS_NO_DERIVE1", 0) && !env_int("NIS_NO_FOLD", 0),
-                            G, N, &grid_stats, &grid_apply); break;
-      case 8: cell_grids<8>(cd.kind, L.KM, 0, false, G, N, &grid_stats, &grid_apply); break;
-      case 16: cell_grids<16>(cd.kind, L.KM, 0, false, G, N, &grid_stats, &grid_apply); break;
-      case 32: cell_grids<32>(cd.kind, L.KM, 0, false, G, N, &grid_stats, &grid_apply); break;
-      default: cell_grids<64>(cd.kind, L.KM, 0, false, G, N, &grid_stats, &grid_apply); break;
-    }
     CellK c;
     memset(&c, 0, sizeof(c));
     c.kind = cd.kind;
@@ -1036,168 +1101,351 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     for (int l = 0; l < cd.n_hidden; ++l) c.width[l] = cd.width[l];
     for (int j = 0; j < d; ++j) c.in_plane[j] = cd.in_col[j];
     c.jplane = d;
-    c.first = (ci == 0 && !o.w_has_jac) ? 1 : 0;
-    c.R = cell_R(cd);
-    c.out = cell_out(cd);
-    c.kind = cd.kind;
-    c.K = cd.K;
-    c.G = G;
-    bool mfma = false;
-    int grid_mf = 1;
-    switch (L.WM) {
-      case 16: mfma_plan<16>(c, G, N, &mfma, &grid_mf); break;
-      case 32: mfma_plan<32>(c, G, N, &mfma, &grid_mf); break;
-      case 64: mfma_plan<64>(c, G, N, &mfma, &grid_mf); break;
-      default: break;
-    }
-    c.nparts[0] = have_stats0 ? prev_records : grid_stats;
-    for (int l = 1; l <= cd.n_hidden; ++l) c.nparts[l] = mfma ? grid_mf : grid_stats;
-    c.maxb = NIS_MAXB;
-    c.bins_row = f->bins_row[ci];
-    c.wp = body + L.off_wp;
-    c.wlast = body + L.off_wlast;
-    c.bias = body + L.off_bias;
-    c.gb = body + L.off_gb;
-    c.hb = body + L.off_hb;
-    c.coef = body + L.off_coef;
-    c.partials = body + L.off_part;
-    c.gstat = body + L.off_gstat;
-    c.running = running[ci];
-    c.tracked = (train && o.tracked) ? o.tracked[ci] : nullptr;
-    c.status = status;
-    c.G = G;
-    c.coef_gs = train ? (cd.n_hidden + 1) * 2 * L.WM : 0;     // eval: every batch shares the running-stat coefficients
-    c.plane_gs = plane_gs;
-    c.derive1 = (train && cd.P == 1 && !env_int("NIS_NO_DERIVE1", 0)) ? 1 : 0;
-    // single pass-through column on the fp64 VALU kernels: BN_0, Linear_0 and BN_1 collapse into one affine map of x
-    // (needs the layer-1 statistics launch to be gone: train mode with derive1, or eval mode)
-    c.fold = (cd.P == 1 && !mfma && (c.derive1 || !train) && !env_int("NIS_NO_FOLD", 0)) ? 1 : 0;
-    c.wx = cell_wx(cd, L.WM);
-    c.sync_part = o.sync_fn ? o.sync_buf : nullptr;
-    c.sync_world = o.sync_world;
-    c.pmerge = (G == 1 || !env_int("NIS_FINALIZE_KERNEL", 0)) ? 1 : 0;   // a launch costs >= 4.3 us, the prologue merge ~1 us
-    if (direct) {
-      c.wrows = (const float*)w;
-      c.wrows_gs = 2 * (long)N;
-      c.x_wcol = col_in_w[cd.in_col[0]] ? cd.in_col[0] : -1;
-      c.xb_wcol = col_in_w[cd.in_col[1]] ? cd.in_col[1] : -1;
-      col_in_w[cd.in_col[1]] = false;            // an inner cell writes its transformed column to the plane; the last one stores nothing
-    } else {
-      c.x_wcol = c.xb_wcol = -1;
-    }
-    c.out_off = o.hist ? plane_gs : 0;
-    c.bnsave = (o.hist && o.bnsave && train) ? o.bnsave + bn_off : nullptr;
-    bn_off += (size_t)(cd.n_hidden + 1) * 4 * L.WM;
-    // rider 1: BN_0 records of the next cell (every state column is in this thread's registers)
-    bool next_rider = false;
-    if (train && ci + 1 < f->n_cells && L.WM <= 8 && f->cells[ci + 1].P <= (L.WM <= 4 ? 4 : NIS_PMAX_FUSED)) {
-      const nis_cell_desc& nx = f->cells[ci + 1];
-      next_rider = true;
-      c.next_P = nx.P;
-      for (int p = 0; p < nx.P; ++p) {
-        int src = -1;
-        for (int j = 0; j < d; ++j)
-          if (cd.in_col[j] == nx.in_col[p]) src = j;
-        c.next_src[p] = src;
-      }
-      for (int p = nx.P; p < NIS_PMAX_FUSED; ++p) c.next_src[p] = -1;
-      c.next_partials = body + lay[ci + 1].off_part;
-      c.next_wm = lay[ci + 1].WM;
-    }
-    // rider 2: built-in integrand + moment records in the last cell
-    FuseF fz;
-    memset(&fz, 0, sizeof(fz));
-    fz.kind = -1;
-    fz.write_planes = 1;
-    fz.maxb = NIS_MAXB;
-    fz.fres_gs = N;
-    const bool last = ci + 1 == f->n_cells;
-    bool fused_f = false;
-    if (last && o.f_kind >= 0 && L.WM <= 8) {
-      fused_f = true;
-      fz.kind = o.f_kind;
-      fz.loc0 = fz.loc1 = -1;
-      for (int j = 0; j < d; ++j) {
-        if (cd.in_col[j] == f->out_col[0]) fz.loc0 = j;
-        if (d > 1 && cd.in_col[j] == f->out_col[1]) fz.loc1 = j;
-      }
-      for (int k = 0; k < 4; ++k) fz.p[k] = o.f_params ? o.f_params[k] : 0.0;
-      if (o.f_kind == NIS_F_CAMEL) fz.p[3] = 1.0 / (fz.p[2] * fz.p[2]);
-      fz.partials = body + off_fpart;
-      fz.fres = o.fres_out;
-      fz.write_planes = (o.keep_planes || o.xj_out) ? 1 : 0;
-    }
-    if (last && o.f_kind >= 0 && !fused_f && G > 1) return NIS_E_UNSUPPORTED;
-    if (repack) {
+    c.coef = body + lay[ci].off_coef;
+    return c;
+  };
+  for (int ci = 0; ci < f->n_cells; ++ci)
+    if (!params[ci] || !running[ci]) return NIS_E_ARG;
+  if (repack) {
+    for (int ci = 0; ci < f->n_cells; ++ci) {
+      const nis_cell_desc& cd = f->cells[ci];
+      const CellLayout& L = lay[ci];
+      const CellK c = cell_shape(ci);
       const int pgrid = (int)std::min<size_t>(64, ((size_t)c.R * L.WM + NIS_TPB - 1) / NIS_TPB);
       NisProfScope ps(NIS_K_PACK, s);
       hipLaunchKernelGGL(k_pack, dim3(std::max(1, pgrid)), dim3(NIS_TPB), 0, s, c, L.WM, params[ci], (const double*)running[ci],
                          train ? 0 : 1, body + L.off_wp, body + L.off_wlast, body + L.off_bias, body + L.off_gb, body + L.off_hb,
                          cell_hidden_bias(cd) ? 1 : 0);
       HIP_OK(hipGetLastError());
-      if (mfma) {
+      if (L.WM >= 16 && use_mfma()) {
         hipLaunchKernelGGL(k_pack_mfma, dim3(std::max(1, pgrid)), dim3(NIS_TPB), 0, s, L.WM, c.L, c.R, L.RT,
                            (const double*)(body + L.off_wp), (const double*)(body + L.off_wlast), (const double*)(body + L.off_bias),
                            body + L.off_wm, body + L.off_wmlast, body + L.off_biaspad, cd.kind == NIS_AFFINE ? d - cd.P : 0);
         HIP_OK(hipGetLastError());
       }
     }
-    MfmaW mw;
-    mw.wm_all = body + L.off_wm;
-    mw.wm_last = body + L.off_wmlast;
-    mw.bias_pad = body + L.off_biaspad;
-    int rc;
-    const bool need0 = !have_stats0;
-    switch (L.WM) {
-      case 4: rc = run_cell<4>(c, mw, false, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, s, o); break;
-      case 8: rc = run_cell<8>(c, mw, false, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, s, o); break;
-      case 16: rc = run_cell<16>(c, mw, mfma, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, s, o); break;
-      case 32: rc = run_cell<32>(c, mw, mfma, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, s, o); break;
-      case 64: rc = run_cell<64>(c, mw, mfma, planes, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, s, o); break;
-      default: rc = NIS_E_UNSUPPORTED;
-    }
-    if (rc != NIS_OK) return rc;
-    have_stats0 = next_rider;
-    prev_records = grid_apply;
-    if (next_rider)
-      if (int rc2 = sync_records(o, c.next_partials, grid_apply, c.next_wm, s)) return rc2;
-    if (train && G > 1) {
-      EpiCell& e = epi.cell[epi.ncell];
-      e.running = c.running;
-      e.gstat = c.gstat;
-      e.tracked = c.tracked;
-      e.L = c.L;
-      e.WM = L.WM;
-      e.P = c.P;
-      for (int l = 0; l < NIS_MAX_HIDDEN; ++l) e.width[l] = c.width[l];
-      epi.blk_off[epi.ncell + 1] = epi.blk_off[epi.ncell] + c.L + 1;
-      ++epi.ncell;
-      if (epi.ncell == NIS_EPI_CELLS && !(last && fused_f))
-        if (int rc2 = epi_flush(nullptr, 0)) return rc2;
-    }
-    if (last && o.f_kind >= 0) {
-      if (fused_f) {
-        if (int rc2 = epi_flush(body + off_fpart, grid_apply)) return rc2;
-      } else {
-        int rc2 = nis_integrand_moments(planes, ld, N, d, f->out_col, o.f_kind, o.f_params, o.fres_out, o.out4, body + off_fpart,
-                                        (size_t)NIS_MAXB * 4 * sizeof(double), (void*)s);
-        if (rc2 != NIS_OK) return rc2;
+  }
+  auto packed_done = [&]() {
+    f->packed_token = o.pack_token;
+    f->packed_mode = o.bn_mode;
+    f->packed_ws = workspace;
+    f->packed_G = G;
+    for (int ci = 0; ci < f->n_cells; ++ci) f->packed_params[ci] = params[ci];
+  };
+  // G > 1, train mode: ONE launch at the end applies the running-statistics updates of all batches in batch order and
+  // merges the fused integrand's moment records
+  EpiJob epi;
+  memset(&epi, 0, sizeof(epi));
+  epi.G = G;
+  auto epi_add = [&](int ci) {
+    const nis_cell_desc& cd = f->cells[ci];
+    EpiCell& e = epi.cell[epi.ncell];
+    e.running = running[ci];
+    e.gstat = body + lay[ci].off_gstat;
+    e.tracked = (train && o.tracked) ? o.tracked[ci] : nullptr;
+    e.L = cd.n_hidden;
+    e.WM = lay[ci].WM;
+    e.P = cd.P;
+    for (int l = 0; l < NIS_MAX_HIDDEN; ++l) e.width[l] = l < cd.n_hidden ? cd.width[l] : 0;
+    epi.blk_off[epi.ncell + 1] = epi.blk_off[epi.ncell] + cd.n_hidden + 1;
+    ++epi.ncell;
+  };
+  auto epi_flush = [&](const double* fpart, int fparts) -> int {
+    if (epi.ncell == 0 && !fpart) return NIS_OK;
+    epi.fpart = fpart;
+    epi.fparts = fparts;
+    epi.out4 = o.out4;
+    epi.maxb = NIS_MAXB;
+    epi.rng_state = (fpart && o.rng) ? o.rng_state : nullptr;
+    NisProfScope ps(NIS_K_MOMENTS, s);
+    hipLaunchKernelGGL(k_group_epilogue, dim3(epi.blk_off[epi.ncell] + (fpart ? G : 0)), dim3(NIS_TPB), 0, s, epi);
+    HIP_OK(hipGetLastError());
+    epi.ncell = 0;
+    return NIS_OK;
+  };
+
+  // ---- persistent whole-step kernel (flow_mega.hip, opt-in: NIS_MEGA=1): the README / C1 / C2 model with everything the
+  //      direct-row mode requires (float32 rows or in-kernel draws, train-mode BN, camel fused, nothing materialised),
+  //      batch resident in LDS.  24-32 B/sample of HBM traffic instead of 88, but slower than the launch-per-phase path
+  //      (one wave per SIMD and team issues fp64 at half rate; 6 hand-offs of ~9 us per batch).
+  {
+    int NT = 0, teams = 0;
+    const bool mega = direct && mega_model(f) && env_int("NIS_MEGA", 0) && G <= NIS_MEGA_MAX_G && nis_mega_geometry(&NT, &teams) &&
+                      ((N + NT - 1) / NT + 1) / 2 * 2 <= NIS_MEGA_CAP;
+    if (mega) {
+      MegaArgs a;
+      memset(&a, 0, sizeof(a));
+      for (int ci = 0; ci < 2; ++ci) {
+        const CellLayout& L = lay[ci];
+        a.cell[ci].wp = body + L.off_wp;
+        a.cell[ci].wlast = body + L.off_wlast;
+        a.cell[ci].bias = body + L.off_bias;
+        a.cell[ci].gb = body + L.off_gb;
+        a.cell[ci].gstat = body + L.off_gstat;
       }
+      a.w = o.rng ? nullptr : (const float*)w;
+      a.w_out = o.rng ? o.w_out : nullptr;
+      a.N = (long)N;
+      a.G = G;
+      a.NT = NT;
+      a.teams = std::min(teams, G);
+      a.n_loc = (int)(((N + NT - 1) / NT + 1) / 2 * 2);
+      a.col0 = f->cells[0].in_col[0];
+      a.seed = o.seed;
+      a.stream0 = o.stream0;
+      a.rng_state = o.rng ? o.rng_state : nullptr;
+      a.status = status;
+      for (int k = 0; k < 3; ++k) a.fp[k] = o.f_params ? o.f_params[k] : 0.0;
+      a.fp[3] = 1.0 / (a.fp[2] * a.fp[2]);
+      a.fpart = body + off_fpart;
+      a.maxb = NIS_MAXB;
+      {
+        NisProfScope ps(NIS_K_APPLY, s);
+        HIP_OK(nis_mega_launch(a, body + off_mega, f->mega_ws != workspace, s));
+      }
+      f->mega_ws = workspace;
+      epi_add(0);
+      epi_add(1);
+      if (int rc2 = epi_flush(body + off_fpart, NT)) return rc2;
+      packed_done();
+      return NIS_OK;
     }
   }
+  if (!planes) return NIS_E_ARG;
+  if (o.rng && !direct) return NIS_E_UNSUPPORTED;        // in-kernel draws exist for the direct-row chain (d = 2 SPEC kernels)
+  // In-kernel draws on the launch-per-phase path: the record pass GENERATES the float32 rows (same Philox mapping as
+  // nis_philox_rows) into the state plane the d = 2 direct-row chain never touches -- the plane of cell 0's pass-through
+  // column, N float64 = N float32 pairs -- and the cells read them from there.
+  const float* wrows = (const float*)w;
+  long wrows_gs = 2 * (long)N;
+  if (o.rng) {
+    wrows = (const float*)(planes + (size_t)f->cells[0].in_col[0] * ld);
+    wrows_gs = 2 * plane_gs;
+  }
+
+  // ---- one chain of launches for batches [g0, g0 + Gy) on stream cs: ingest -> per cell [statistics ..., apply].
+  //      Gg (>= Gy) sizes the grids: every chain of a call uses the same grids, so every batch has the same record counts.
+  int epi_fparts = 0;
+  bool epi_fused = false;
+  auto chain = [&](hipStream_t cs, int g0, int Gy, int Gg, bool collect_epi, hipEvent_t stagger) -> int {
+    IngestStats is2 = ist;
+    is2.g0 = g0;
+    // ingest / emit: 256-thread streaming workgroups, 8 per CU; the read-only record pass of the direct mode runs best at 4
+    // (half the BN_0 records for the first statistics launch to merge: C2 bench 21.8e9 -> 22.2e9 samples/s)
+    const int tgrid = grid_for(env_int("NIS_INGEST_BPC", direct ? 4 : 8), Gg, N, NIS_TPB);
+    bool col_in_w[2] = {direct, direct};
+    nis_prof_mark(NIS_K_INGEST, 1, cs);
+    if (direct && o.rng)
+      hipLaunchKernelGGL(k_ingest2_rng, dim3(tgrid, Gy), dim3(NIS_TPB), 0, cs, (unsigned long long)o.seed, (unsigned long long)o.stream0,
+                         (const unsigned long long*)o.rng_state, (long)N, const_cast<float*>(wrows), wrows_gs, o.w_out, is2);
+    else if (direct)
+      hipLaunchKernelGGL((k_ingest2<float, false>), dim3(tgrid, Gy), dim3(NIS_TPB), 0, cs, (const float*)w, (long)N, planes, (long)ld, is2);
+    else if (wcols == 2 && is2.P <= 2 && w_dtype == NIS_F64)
+      hipLaunchKernelGGL(k_ingest2<double>, dim3(tgrid, Gy), dim3(NIS_TPB), 0, cs, (const double*)w, (long)N, planes, (long)ld, is2);
+    else if (wcols == 2 && is2.P <= 2)
+      hipLaunchKernelGGL(k_ingest2<float>, dim3(tgrid, Gy), dim3(NIS_TPB), 0, cs, (const float*)w, (long)N, planes, (long)ld, is2);
+    else if (w_dtype == NIS_F64)
+      hipLaunchKernelGGL(k_ingest<double>, dim3(tgrid, Gy), dim3(NIS_TPB), tile_bytes, cs, (const double*)w, (long)N, wcols, planes,
+                         (long)ld, is2);
+    else
+      hipLaunchKernelGGL(k_ingest<float>, dim3(tgrid, Gy), dim3(NIS_TPB), tile_bytes, cs, (const float*)w, (long)N, wcols, planes,
+                         (long)ld, is2);
+    nis_prof_mark(NIS_K_INGEST, 0, cs);
+    HIP_OK(hipGetLastError());
+    if (o.sync_fn) {
+      if (G != 1 || !train || o.hist) return NIS_E_UNSUPPORTED;
+      if (ingest_stats)
+        if (int rc = sync_records(o, is2.partials, tgrid, lay[0].WM, cs)) return rc;
+    }
+    int prev_records = tgrid;           // records of BN_0 of the current cell written by the previous launch
+    bool have_stats0 = ingest_stats;
+    double* pl = planes;
+    size_t bn_off = 0;
+    for (int ci = 0; ci < f->n_cells; ++ci) {
+      const nis_cell_desc& cd = f->cells[ci];
+      const CellLayout& L = lay[ci];
+      if (o.hist) pl = planes + (size_t)ci * plane_gs;
+      int grid_stats = 1, grid_apply = 1;
+      switch (L.WM) {
+        // folded statistics launches (k_bn_stats_fold): train mode, one pass-through column, BN_1 derived
+        case 4: cell_grids<4>(cd.kind, L.KM, cell_wx(cd, L.WM), train && cd.P == 1 && !env_int("NIS_NO_DERIVE1", 0) && !env_int("NIS_NO_FOLD", 0),
+                              Gg, N, &grid_stats, &grid_apply); break;
+        case 8: cell_grids<8>(cd.kind, L.KM, 0, false, Gg, N, &grid_stats, &grid_apply); break;
+        case 16: cell_grids<16>(cd.kind, L.KM, 0, false, Gg, N, &grid_stats, &grid_apply); break;
+        case 32: cell_grids<32>(cd.kind, L.KM, 0, false, Gg, N, &grid_stats, &grid_apply); break;
+        default: cell_grids<64>(cd.kind, L.KM, 0, false, Gg, N, &grid_stats, &grid_apply); break;
+      }
+      CellK c = cell_shape(ci);
+      c.first = (ci == 0 && !o.w_has_jac) ? 1 : 0;
+      c.G = G;
+      c.Gy = Gy;
+      c.g0 = g0;
+      bool mfma = false;
+      int grid_mf = 1;
+      switch (L.WM) {
+        case 16: mfma_plan<16>(c, Gg, N, &mfma, &grid_mf); break;
+        case 32: mfma_plan<32>(c, Gg, N, &mfma, &grid_mf); break;
+        case 64: mfma_plan<64>(c, Gg, N, &mfma, &grid_mf); break;
+        default: break;
+      }
+      c.nparts[0] = have_stats0 ? prev_records : grid_stats;
+      for (int l = 1; l <= cd.n_hidden; ++l) c.nparts[l] = mfma ? grid_mf : grid_stats;
+      c.maxb = NIS_MAXB;
+      c.bins_row = f->bins_row[ci];
+      c.wp = body + L.off_wp;
+      c.wlast = body + L.off_wlast;
+      c.bias = body + L.off_bias;
+      c.gb = body + L.off_gb;
+      c.hb = body + L.off_hb;
+      c.partials = body + L.off_part;
+      c.gstat = body + L.off_gstat;
+      c.running = running[ci];
+      c.tracked = (train && o.tracked) ? o.tracked[ci] : nullptr;
+      c.status = status;
+      c.coef_gs = train ? (cd.n_hidden + 1) * 2 * L.WM : 0;     // eval: every batch shares the running-stat coefficients
+      c.plane_gs = plane_gs;
+      c.derive1 = (train && cd.P == 1 && !env_int("NIS_NO_DERIVE1", 0)) ? 1 : 0;
+      // single pass-through column on the fp64 VALU kernels: BN_0, Linear_0 and BN_1 collapse into one affine map of x
+      // (needs the layer-1 statistics launch to be gone: train mode with derive1, or eval mode)
+      c.fold = (cd.P == 1 && !mfma && (c.derive1 || !train) && !env_int("NIS_NO_FOLD", 0)) ? 1 : 0;
+      c.wx = cell_wx(cd, L.WM);
+      c.sync_part = o.sync_fn ? o.sync_buf : nullptr;
+      c.sync_world = o.sync_world;
+      c.pmerge = (G == 1 || !env_int("NIS_FINALIZE_KERNEL", 0)) ? 1 : 0;   // a launch costs >= 4.3 us, the prologue merge ~1 us
+      if (direct) {
+        c.wrows = wrows;
+        c.wrows_gs = wrows_gs;
+        c.x_wcol = col_in_w[cd.in_col[0]] ? cd.in_col[0] : -1;
+        c.xb_wcol = col_in_w[cd.in_col[1]] ? cd.in_col[1] : -1;
+        col_in_w[cd.in_col[1]] = false;            // an inner cell writes its transformed column to the plane; the last one stores nothing
+      } else {
+        c.x_wcol = c.xb_wcol = -1;
+      }
+      c.out_off = o.hist ? plane_gs : 0;
+      c.bnsave = (o.hist && o.bnsave && train) ? o.bnsave + bn_off : nullptr;
+      bn_off += (size_t)(cd.n_hidden + 1) * 4 * L.WM;
+      // rider 1: BN_0 records of the next cell (every state column is in this thread's registers)
+      bool next_rider = false;
+      if (train && ci + 1 < f->n_cells && L.WM <= 8 && f->cells[ci + 1].P <= (L.WM <= 4 ? 4 : NIS_PMAX_FUSED)) {
+        const nis_cell_desc& nx = f->cells[ci + 1];
+        next_rider = true;
+        c.next_P = nx.P;
+        for (int p = 0; p < nx.P; ++p) {
+          int src = -1;
+          for (int j = 0; j < d; ++j)
+            if (cd.in_col[j] == nx.in_col[p]) src = j;
+          c.next_src[p] = src;
+        }
+        for (int p = nx.P; p < NIS_PMAX_FUSED; ++p) c.next_src[p] = -1;
+        c.next_partials = body + lay[ci + 1].off_part;
+        c.next_wm = lay[ci + 1].WM;
+      }
+      // rider 2: built-in integrand + moment records in the last cell
+      FuseF fz;
+      memset(&fz, 0, sizeof(fz));
+      fz.kind = -1;
+      fz.write_planes = 1;
+      fz.maxb = NIS_MAXB;
+      fz.fres_gs = N;
+      const bool last = ci + 1 == f->n_cells;
+      bool fused_f = false;
+      if (last && o.f_kind >= 0 && L.WM <= 8) {
+        fused_f = true;
+        fz.kind = o.f_kind;
+        fz.loc0 = fz.loc1 = -1;
+        for (int j = 0; j < d; ++j) {
+          if (cd.in_col[j] == f->out_col[0]) fz.loc0 = j;
+          if (d > 1 && cd.in_col[j] == f->out_col[1]) fz.loc1 = j;
+        }
+        for (int k = 0; k < 4; ++k) fz.p[k] = o.f_params ? o.f_params[k] : 0.0;
+        if (o.f_kind == NIS_F_CAMEL) fz.p[3] = 1.0 / (fz.p[2] * fz.p[2]);
+        fz.partials = body + off_fpart;
+        fz.fres = o.fres_out;
+        fz.write_planes = (o.keep_planes || o.xj_out) ? 1 : 0;
+      }
+      if (last && o.f_kind >= 0 && !fused_f && G > 1) return NIS_E_UNSUPPORTED;
+      MfmaW mw;
+      mw.wm_all = body + L.off_wm;
+      mw.wm_last = body + L.off_wmlast;
+      mw.bias_pad = body + L.off_biaspad;
+      int rc;
+      const bool need0 = !have_stats0;
+      switch (L.WM) {
+        case 4: rc = run_cell<4>(c, mw, false, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, cs, o, ci == 0 ? stagger : nullptr); break;
+        case 8: rc = run_cell<8>(c, mw, false, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, cs, o, ci == 0 ? stagger : nullptr); break;
+        case 16: rc = run_cell<16>(c, mw, mfma, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, cs, o, ci == 0 ? stagger : nullptr); break;
+        case 32: rc = run_cell<32>(c, mw, mfma, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, cs, o, ci == 0 ? stagger : nullptr); break;
+        case 64: rc = run_cell<64>(c, mw, mfma, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, cs, o, ci == 0 ? stagger : nullptr); break;
+        default: rc = NIS_E_UNSUPPORTED;
+      }
+      if (rc != NIS_OK) return rc;
+      have_stats0 = next_rider;
+      prev_records = grid_apply;
+      if (next_rider)
+        if (int rc2 = sync_records(o, c.next_partials, grid_apply, c.next_wm, cs)) return rc2;
+      if (train && G > 1 && collect_epi) {
+        epi_add(ci);
+        if (epi.ncell == NIS_EPI_CELLS && !(last && fused_f))
+          if (int rc2 = epi_flush(nullptr, 0)) return rc2;
+      }
+      if (last && o.f_kind >= 0) {
+        if (fused_f) {
+          epi_fparts = grid_apply;
+          epi_fused = true;
+        } else {
+          int rc2 = nis_integrand_moments(pl, ld, N, d, f->out_col, o.f_kind, o.f_params, o.fres_out, o.out4, body + off_fpart,
+                                          (size_t)NIS_MAXB * 4 * sizeof(double), (void*)cs);
+          if (rc2 != NIS_OK) return rc2;
+        }
+      }
+    }
+    return NIS_OK;
+  };
+
+  // Independent batches on several streams: one chain's HBM-bound statistics passes run beside another's fp64-issue-bound
+  // apply kernels (C2 at G = 10: 33.3 -> 28.8 us per step).  The chains share nothing but read-only parameters (records,
+  // coefficients, planes and moment records are indexed by batch); they fork from and join the caller's stream through
+  // events, so the call stays capturable into a hipGraph, and the one epilogue launch behind the join applies the
+  // running-statistics updates of ALL batches in batch order.
+  int n_chains = 1;
+  if (G >= 2 && !o.sync_fn && !o.hist && train && f->n_cells <= NIS_EPI_CELLS) n_chains = std::min(G, std::max(1, env_int("NIS_STREAMS", 1)));   // default 1: started together or staggered, the chains of ONE call gained nothing; free-running sets on separate streams do
+  SidePool* pool = n_chains > 1 ? side_pool(n_chains - 1) : nullptr;
+  if (n_chains > 1 && !pool) n_chains = 1;
+  if (n_chains == 1) {
+    if (int rc = chain(s, 0, G, G, true, nullptr)) return rc;
+  } else {
+    // Chains start STAGGERED: chain k + 1 waits until chain k reaches its first apply launch, so that the memory-bound
+    // head of one chain (record pass, statistics) runs beside the fp64-bound apply kernel of its predecessor; started
+    // together the chains would run the same kernel class in lockstep and overlap nothing.
+    const int Gg = (G + n_chains - 1) / n_chains;
+    static const bool stagger_on = env_int("NIS_NO_STAGGER", 0) == 0;
+    HIP_OK(hipEventRecord(pool->fork, s));
+    int g0 = 0;
+    for (int k = 0; k < n_chains; ++k) {
+      const int Gy = G / n_chains + (k < G % n_chains ? 1 : 0);
+      hipStream_t cs = k == 0 ? s : pool->stream[k - 1];
+      if (k > 0) HIP_OK(hipStreamWaitEvent(cs, (stagger_on ? pool->stag[k - 1] : pool->fork), 0));
+      if (int rc = chain(cs, g0, Gy, Gg, k == 0, (stagger_on && k + 1 < n_chains) ? pool->stag[k] : nullptr)) return rc;
+      if (k > 0) {
+        HIP_OK(hipEventRecord(pool->join[k - 1], cs));
+        HIP_OK(hipStreamWaitEvent(s, pool->join[k - 1], 0));
+      }
+      g0 += Gy;
+    }
+  }
+  if (epi_fused) {
+    if (int rc2 = epi_flush(body + off_fpart, epi_fparts)) return rc2;
+  }
   if (int rc2 = epi_flush(nullptr, 0)) return rc2;
-  f->packed_token = o.pack_token;
-  f->packed_mode = o.bn_mode;
-  f->packed_ws = workspace;
-  f->packed_G = G;
-  for (int ci = 0; ci < f->n_cells; ++ci) f->packed_params[ci] = params[ci];
-  if (o.hist) planes = planes0 + (size_t)f->n_cells * plane_gs;      // the final state lives in the last plane set
+  packed_done();
   if (o.xj_out) {
     ColMap m;
     for (int j = 0; j < d; ++j) m.col[j] = f->out_col[j];
     m.col[d] = d;
+    const int tgrid = grid_for(8, 1, N, NIS_TPB);
+    double* pl = o.hist ? planes + (size_t)f->n_cells * plane_gs : planes;      // hist: the final state lives in the last plane set
     NisProfScope ps(NIS_K_EMIT, s);
-    hipLaunchKernelGGL(k_emit, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const double*)planes, (long)ld, (long)N, d, m, o.xj_out);
+    hipLaunchKernelGGL(k_emit, dim3(tgrid), dim3(NIS_TPB), tile_bytes, s, (const double*)pl, (long)ld, (long)N, d, m, o.xj_out);
     HIP_OK(hipGetLastError());
   }
   return NIS_OK;
@@ -1254,6 +1502,44 @@ extern "C" int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, 
   o.out4 = out4;
   o.keep_planes = keep_planes;
   return flow_run(f, w, w_dtype, N, params, running, planes, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
+}
+
+extern "C" int nis_integrate_steps_rng(nis_flow* f, int32_t n_batches, int64_t N, const double* const* params, double* const* running,
+                                       long long* const* tracked, int32_t bn_mode, int64_t pack_token, int32_t f_kind,
+                                       const double* f_params_host, uint64_t seed, uint64_t stream0, uint64_t* rng_state, float* w_out,
+                                       double* planes, int64_t ld, double* out4, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!out4 || f_kind < 0) return NIS_E_ARG;
+  RunOpts o;
+  o.G = n_batches;
+  o.bn_mode = bn_mode;
+  o.pack_token = pack_token;
+  o.tracked = tracked;
+  o.f_kind = f_kind;
+  o.f_params = f_params_host;
+  o.out4 = out4;
+  o.keep_planes = 0;
+  o.rng = 1;
+  o.seed = seed;
+  o.stream0 = stream0;
+  o.rng_state = (unsigned long long*)rng_state;
+  o.w_out = w_out;
+  return flow_run(f, nullptr, NIS_F32, N, params, running, planes, planes ? ld : N, workspace, workspace_bytes, (hipStream_t)stream, o);
+}
+
+extern "C" int nis_integrate_resident(const nis_flow* f, int32_t n_batches, int64_t N, int32_t bn_mode, int32_t f_kind) {
+  int NT = 0, teams = 0;
+  return f && mega_model(f) && bn_mode == NIS_BN_TRAIN && f_kind == NIS_F_CAMEL && n_batches >= 1 && n_batches <= NIS_MEGA_MAX_G &&
+                 env_int("NIS_MEGA", 0) && !env_int("NIS_NO_DIRECT_ROWS", 0) && !env_int("NIS_NO_FOLD", 0) && !env_int("NIS_NO_WX", 0) &&
+                 !env_int("NIS_NO_DERIVE1", 0) && !getenv("NIS_NO_STATS_FOLD") && nis_mega_geometry(&NT, &teams) &&
+                 ((N + NT - 1) / NT + 1) / 2 * 2 <= NIS_MEGA_CAP
+             ? 1
+             : 0;
+}
+
+extern "C" int nis_philox_rows(uint64_t seed, uint64_t stream0, int32_t n_batches, int64_t N, float* out, void* stream) {
+  if (!out || n_batches < 1 || n_batches > 65535 || N < 1) return NIS_E_ARG;
+  HIP_OK(nis_philox_rows_launch(seed, stream0, n_batches, (long)N, out, (hipStream_t)stream));
+  return NIS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1359,6 +1645,7 @@ extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t
     c.jplane = d;
     c.first = (ci == 0 && !w_has_jac) ? 1 : 0;
     c.G = 1;
+    c.Gy = 1;
     const size_t WM = L.WM, R = c.R, nl = c.L;
     double* wp = pk;
     double* wlast = wp + nl * WM * WM;

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
   __shared__ double wshift[NW][WM];
   __shared__ double wmom[NW][WM][3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = blockIdx.y;
+  const int g = c.g0 + blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   // G == 1: the previous layer's records are merged here; G > 1: k_bn_finalize already published the coefficients
   const double w_fold = fold_weight<WM>(c);
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __
   __shared__ double wmom[NW][WM][3];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = blockIdx.y;
+  const int g = c.g0 + blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   // Requests that do not depend on the prologue go out first: the weights (scalar loads), the sample that fixes the
   // wave's shift and the first U tiles -- their latency overlaps the record merge.
@@ -512,7 +512,7 @@ template <int WM>
 __global__ __launch_bounds__(1024) void k_bn_finalize(CellK c, int layer) {
   __shared__ double lds_coef[(NIS_MAX_HIDDEN + 1) * 2 * WM];
   __shared__ double red[3 * 1024];
-  load_coefs<WM, 1024>(c, blockIdx.x, layer + 1, layer, true, lds_coef, red);
+  load_coefs<WM, 1024>(c, c.g0 + blockIdx.x, layer + 1, layer, true, lds_coef, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   __shared__ double fmom[NW][4];
   __shared__ double etab[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = blockIdx.y;
+  const int g = c.g0 + blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   nis_exp_init(etab);
   const double w_fold = fold_weight<WM>(c);

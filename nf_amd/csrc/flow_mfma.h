@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NIS_MF_TPB) void k_bn_stats_mfma(CellK c, const dou
   __shared__ int lds_plane[NIS_MAX_DIM];
   __shared__ double wmom[NW][WM][3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
-  const int g = blockIdx.y;
+  const int g = c.g0 + blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   if (tid < NIS_MAX_DIM) lds_plane[tid] = c.in_plane[tid];
   load_coefs<WM, NIS_MF_TPB>(c, g, layer, c.pmerge ? cellk_fresh(c, layer) : -1, blockIdx.x == 0, lds_coef, red);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
   __shared__ int lds_plane[NIS_MAX_DIM];
   __shared__ double etab[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
-  const int g = blockIdx.y;
+  const int g = c.g0 + blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   if (tid < NIS_MAX_DIM) lds_plane[tid] = c.in_plane[tid];
   nis_exp_init(etab);

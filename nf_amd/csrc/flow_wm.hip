@@ -20,33 +20,33 @@ hipError_t launch_stats<NIS_WM>(const CellK& c, const double* planes, long ld, l
     if (rows && !(c.P == 1 && c.fold && hoisted && layer >= 2 && layer <= 5)) return hipErrorInvalidValue;
     if (rows) {
       switch (layer) {
-        case 2: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 2, true>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
-        case 3: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 3, true>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
-        case 4: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 4, true>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
-        default: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 5, true>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
+        case 2: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 2, true>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N); break;
+        case 3: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 3, true>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N); break;
+        case 4: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 4, true>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N); break;
+        default: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 5, true>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N); break;
       }
     } else if (c.P == 1 && c.fold && hoisted && layer >= 2 && layer <= 5) {     // folded chain, coefficients in registers
       switch (layer) {
-        case 2: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 2>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
-        case 3: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 3>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
-        case 4: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 4>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
-        default: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 5>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N); break;
+        case 2: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 2>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N); break;
+        case 3: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 3>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N); break;
+        case 4: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 4>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N); break;
+        default: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 5>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N); break;
       }
     } else if (c.P == 1)
-      hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB, 3, true>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N, layer);
+      hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB, 3, true>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N, layer);
     else
-      hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB, 3>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N, layer);
+      hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB, 3>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N, layer);
     return hipGetLastError();
   }
 #endif
   if (c.wrows && c.x_wcol >= 0) return hipErrorInvalidValue;          // row input exists for the folded 3-wide chain only
-  hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB>), dim3(grid, c.G), dim3(TPB), 0, s, c, planes, ld, N, layer);
+  hipLaunchKernelGGL((k_bn_stats<NIS_WM, TPB>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N, layer);
   return hipGetLastError();
 }
 
 template <>
 hipError_t launch_finalize<NIS_WM>(const CellK& c, int layer, hipStream_t s) {
-  hipLaunchKernelGGL((k_bn_finalize<NIS_WM>), dim3(c.G), dim3(1024), 0, s, c, layer);
+  hipLaunchKernelGGL((k_bn_finalize<NIS_WM>), dim3(c.Gy), dim3(1024), 0, s, c, layer);
   return hipGetLastError();
 }
 
@@ -146,7 +146,7 @@ int apply_blocks_per_cu<NIS_WM>(int kind, int km, int wx) {
 }
 
 #define NIS_APPLY(KIND, KMV, EX) \
-  hipLaunchKernelGGL((k_cell_apply<KIND, NIS_WM, KMV, EX>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
+  hipLaunchKernelGGL((k_cell_apply<KIND, NIS_WM, KMV, EX>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
 
 // km < 0 selects the K == KM specialisation (no per-bin guards)
 template <>
@@ -154,17 +154,17 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
                                 int grid, hipStream_t s) {
 #if NIS_WM == 4
 #define NIS_APPLY3(KIND, KMV, EX) \
-  hipLaunchKernelGGL((k_cell_apply<KIND, NIS_WM, KMV, EX, 3>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
+  hipLaunchKernelGGL((k_cell_apply<KIND, NIS_WM, KMV, EX, 3>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
 #define NIS_APPLY3S(KMV, SP)                                                                                                       \
   do {                                                                                                                             \
     if (rows && c.first)                                                                                                           \
-      hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP, true, true>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c,   \
+      hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP, true, true>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c,   \
                          planes, ld, N, bn_train, bins, fz);                                                                       \
     else if (rows)                                                                                                                 \
-      hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP, true, false>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c,  \
+      hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP, true, false>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c,  \
                          planes, ld, N, bn_train, bins, fz);                                                                       \
     else                                                                                                                           \
-      hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP>), dim3(grid, c.G), dim3(NIS_TPB), 0, s, c, planes, ld, \
+      hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c, planes, ld, \
                          N, bn_train, bins, fz);                                                                                   \
   } while (0)
   const bool rows = c.wrows && c.xb_wcol >= 0;           // transformed input (and maybe the pass-through one) from the rows of w
@@ -254,12 +254,12 @@ int mfma_blocks_per_cu<NIS_WM>(const CellK& c) {
 template <>
 hipError_t launch_stats_mfma<NIS_WM>(const CellK& c, const MfmaW& w, const double* planes, long ld, long N, int layer, int grid,
                                      hipStream_t s) {
-  hipLaunchKernelGGL((k_bn_stats_mfma<NIS_WM>), dim3(grid, c.G), dim3(NIS_MF_TPB), 0, s, c, planes, ld, N, layer, w.wm_all);
+  hipLaunchKernelGGL((k_bn_stats_mfma<NIS_WM>), dim3(grid, c.Gy), dim3(NIS_MF_TPB), 0, s, c, planes, ld, N, layer, w.wm_all);
   return hipGetLastError();
 }
 
 #define NIS_APPLY_MF(KIND, KMV, EX)                                                                                               \
-  hipLaunchKernelGGL((k_cell_apply_mfma<KIND, NIS_WM, KMV, EX>), dim3(grid, c.G), dim3(NIS_MF_TPB), mf_ring_bytes(c), s, c, planes, ld, \
+  hipLaunchKernelGGL((k_cell_apply_mfma<KIND, NIS_WM, KMV, EX>), dim3(grid, c.Gy), dim3(NIS_MF_TPB), mf_ring_bytes(c), s, c, planes, ld, \
                      N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad)
 
 template <>

@@ -147,7 +147,9 @@ struct CellK {
   long long* tracked;                    // num_batches_tracked of the L+1 BN layers (incremented in train mode)
   int* status;                           // device error word (bit0: PWLin bin index out of range)
   // ---- batched iterations: blockIdx.y = g selects one of G independent batches (own planes, own BN statistics)
-  int G;                                 // number of batches in this launch set
+  int G;                                 // number of batches in this launch set (stride of the per-batch arrays)
+  int Gy, g0;                            // this launch covers batches [g0, g0 + Gy): blockIdx.y counts from g0 (several chains of a
+                                         //   set run on their own streams, flow_run)
   int coef_gs;                           // doubles between the coefficient sets of consecutive g: (L+1)*2*WM
   long plane_gs;                         // doubles between the plane sets of consecutive g: (d+1)*ld
   const double* sync_part;               // non-null (multi-rank exact BatchNorm): the freshest layer's records are the `sync_world` per-rank

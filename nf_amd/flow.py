@@ -176,10 +176,11 @@ class FlowEngine:
         planes = torch.empty((self.d + 1, N), dtype=torch.double, device=dev)
         xj = torch.empty((N, self.d + 1), dtype=torch.double, device=dev) if want_xj else None
         bins = torch.empty((self.n_bins_rows, N), dtype=torch.int32, device=dev) if want_bins else None
-        rc = self.L.nis_flow_forward(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
-                                     1 if has_jac else 0, N, pp, rp, tp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL,
-                                     token, planes.data_ptr(), N, xj.data_ptr() if want_xj else None,
-                                     bins.data_ptr() if want_bins else None, ws.data_ptr(), wsb, _lib.stream_ptr())
+        with _lib.on_device(dev):
+            rc = self.L.nis_flow_forward(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
+                                         1 if has_jac else 0, N, pp, rp, tp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL,
+                                         token, planes.data_ptr(), N, xj.data_ptr() if want_xj else None,
+                                         bins.data_ptr() if want_bins else None, ws.data_ptr(), wsb, _lib.stream_ptr(dev))
         _lib.check(rc, "nis_flow_forward")
         if train:
             self._stats_epoch += 1
@@ -212,10 +213,11 @@ class FlowEngine:
                 failure.append(exc)
 
         hook = _lib.SYNC_FN(exchange)
-        rc = self.L.nis_flow_forward_sync(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
-                                          1 if has_jac else 0, N, pp, rp, tp, self.pack_token(), planes.data_ptr(), N,
-                                          xj.data_ptr() if want_xj else None, ws.data_ptr(), wsb, _lib.stream_ptr(), hook, None,
-                                          buf.data_ptr(), world, rank)
+        with _lib.on_device(dev):
+            rc = self.L.nis_flow_forward_sync(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
+                                              1 if has_jac else 0, N, pp, rp, tp, self.pack_token(), planes.data_ptr(), N,
+                                              xj.data_ptr() if want_xj else None, ws.data_ptr(), wsb, _lib.stream_ptr(dev), hook, None,
+                                              buf.data_ptr(), world, rank)
         if failure:
             raise failure[0]
         _lib.check(rc, "nis_flow_forward_sync")
@@ -244,9 +246,10 @@ class FlowEngine:
         hist = torch.empty((len(self.cells) + 1, self.d + 1, N), dtype=torch.double, device=dev)
         bnsave = torch.empty(self.L.nis_flow_bnsave_count(self.handle), dtype=torch.double, device=dev)
         xj = torch.empty((N, self.d + 1), dtype=torch.double, device=dev)
-        rc = self.L.nis_flow_forward_train(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
-                                           1 if has_jac else 0, N, pp, rp, tp, self.pack_token(), hist.data_ptr(), N,
-                                           bnsave.data_ptr(), xj.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr())
+        with _lib.on_device(dev):
+            rc = self.L.nis_flow_forward_train(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
+                                               1 if has_jac else 0, N, pp, rp, tp, self.pack_token(), hist.data_ptr(), N,
+                                               bnsave.data_ptr(), xj.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
         _lib.check(rc, "nis_flow_forward_train")
         self._stats_epoch += 1
         self._raise_on_status(ws[:4].view(torch.int32))
@@ -263,11 +266,17 @@ class FlowEngine:
         wsb = self.L.nis_flow_backward_workspace_bytes(self.handle, N)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         gx = torch.empty((N, self.d + 1), dtype=torch.double, device=dev) if want_gx else None
-        gxj = gxj.to(torch.double).contiguous()
-        rc = self.L.nis_flow_backward(self.handle, hist.data_ptr(), N, N, 1 if has_jac else 0, pp, bnsave.data_ptr(), gxj.data_ptr(),
-                                      gp, gx.data_ptr() if want_gx else None, ws.data_ptr(), wsb, _lib.stream_ptr())
+        gxj = gxj.to(device=dev, dtype=torch.double).contiguous()
+        with _lib.on_device(dev):
+            rc = self.L.nis_flow_backward(self.handle, hist.data_ptr(), N, N, 1 if has_jac else 0, pp, bnsave.data_ptr(), gxj.data_ptr(),
+                                          gp, gx.data_ptr() if want_gx else None, ws.data_ptr(), wsb, _lib.stream_ptr(dev))
         _lib.check(rc, "nis_flow_backward")
         return gflat, gx
+
+    def resident(self, G, N, train, f_kind):
+        """True when `integrate_steps` / `integrate_steps_rng` run the persistent whole-step kernel (flow_mega.hip) for G
+        batches of N float32 rows: the batch then lives in LDS and no plane buffer is needed."""
+        return bool(self.L.nis_integrate_resident(self.handle, G, N, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL, f_kind))
 
     def integrate_steps(self, w, train, f_kind, f_params, out4, planes=None, token=None, want_fres=False):
         """G iterations of integrate()'s loop body in ONE library call.  w: (G, N, d) (or (N, d) for G = 1),
@@ -286,21 +295,163 @@ class FlowEngine:
         if token is None:
             token = self.pack_token()
         keep = planes is not None
-        if planes is None:
-            planes = torch.empty((G, self.d + 1, N), dtype=torch.double, device=dev)
+        if planes is None and not (w2.dtype == torch.float32 and not want_fres and self.resident(G, N, train, f_kind)):
+            planes = self._planes_scratch(G, N, dev)
         fres = torch.empty((G, N), dtype=torch.double, device=dev) if want_fres else None
         fp = (C.c_double * 4)(*(list(f_params) + [0.0] * 4)[:4])
-        rc = self.L.nis_integrate_steps(self.handle, w2.data_ptr(), _lib.NIS_F32 if w2.dtype == torch.float32 else _lib.NIS_F64,
-                                        G, N, pp, rp, tp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL, token, f_kind, fp,
-                                        planes.data_ptr(), N, 1 if keep else 0, fres.data_ptr() if want_fres else None,
-                                        out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr())
+        with _lib.on_device(dev):
+            rc = self.L.nis_integrate_steps(self.handle, w2.data_ptr(), _lib.NIS_F32 if w2.dtype == torch.float32 else _lib.NIS_F64,
+                                            G, N, pp, rp, tp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL, token, f_kind, fp,
+                                            planes.data_ptr() if planes is not None else None, N, 1 if keep else 0,
+                                            fres.data_ptr() if want_fres else None, out4.data_ptr(), ws.data_ptr(), wsb,
+                                            _lib.stream_ptr(dev))
         _lib.check(rc, "nis_integrate_steps")
         if train:
             self._stats_epoch += 1
         self._raise_on_status(ws[:4].view(torch.int32))
         return fres
 
+    def rng_supported(self, train=True, f_kind=_lib.NIS_F_CAMEL):
+        """True for the model class whose first launch can draw the batch itself (d = 2 PWQuad chain of SPEC kernels, fused
+        camel, train-mode BN): include/nis_hip.h, nis_integrate_steps_rng."""
+        if self.d != 2 or not train or f_kind != _lib.NIS_F_CAMEL:
+            return False
+        for c in self.cells:
+            if c.KIND != _lib.NIS_PWQUAD or c.pass_through_size != 1 or int(c.n_bins) not in (4, 8, 16) or \
+                    len(c.hidden_widths) != 3 or max(c.hidden_widths) > 3:
+                return False
+        return True
+
+    def integrate_steps_rng(self, G, N, dev, f_kind, f_params, out4, seed, stream0, token=None, w_out=None, rng_state=None):
+        """The same G iterations with the draw inside the step (manager.py:395): batch g is drawn on the device from Philox
+        stream `stream0 + g` of key `seed` (mapping: include/nis_hip.h) by the launch that gathers BN_0's records; no input
+        buffer exists.  Models outside that kernel class get the same draws from `philox_rows` and run `integrate_steps`.
+        w_out: optional (G, N, 2) float32 receiving the draws.  rng_state: optional int64[2] device tensor {seed, next stream}
+        that overrides seed / stream0 and is advanced by G on the device (IntegratePlan: graph replays)."""
+        _lib.require_gpu()
+        dev = torch.device(dev)
+        if N < 2:
+            raise ValueError("Expected more than 1 value per channel when training")
+        if not self.rng_supported(True, f_kind):
+            if rng_state is not None:
+                raise _lib.NisError("device-resident generator state needs the in-kernel draw (rng_supported())")
+            w = philox_rows(seed, stream0, G, N, self.d, dev)
+            if w_out is not None:
+                w_out.copy_(w)
+            return self.integrate_steps(w, True, f_kind, f_params, out4, token=token)
+        pp, rp, tp = self._pointers(dev)
+        ws, wsb = self._workspace(dev, G)
+        if token is None:
+            token = self.pack_token()
+        planes = None
+        if not self.resident(G, N, True, f_kind):
+            planes = self._planes_scratch(G, N, dev)
+        fp = (C.c_double * 4)(*(list(f_params) + [0.0] * 4)[:4])
+        with _lib.on_device(dev):
+            rc = self.L.nis_integrate_steps_rng(self.handle, G, N, pp, rp, tp, _lib.NIS_BN_TRAIN, token, f_kind, fp, seed, stream0,
+                                                rng_state.data_ptr() if rng_state is not None else None,
+                                                w_out.data_ptr() if w_out is not None else None,
+                                                planes.data_ptr() if planes is not None else None, N, out4.data_ptr(),
+                                                ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+        _lib.check(rc, "nis_integrate_steps_rng")
+        self._stats_epoch += 1
+        return None
+
+    def _planes_scratch(self, G, N, dev):
+        """(G, d+1, N) float64 state planes kept between calls (nothing in them outlives a call when X / J are not kept)."""
+        p = getattr(self, "_planes", None)
+        if p is None or p.device != dev or p.shape[0] < G or p.shape[2] != N:
+            self._planes = p = torch.empty((G, self.d + 1, N), dtype=torch.double, device=dev)
+        return p[:G]
+
+    def plan(self, G, N, dev, f_kind, f_params):
+        """Cached IntegratePlan (one captured launch set) for this model state, set size and integrand."""
+        # parameters only: the BN running statistics change with every train-mode forward and do not enter a train-mode set
+        psig = tuple((p.data_ptr(), p._version) for c in self.cells for p in c.parameters())
+        key = (int(G), int(N), str(torch.device(dev)), int(f_kind), tuple(float(x) for x in f_params), psig)
+        cache = getattr(self, "_plans", None)
+        if cache is None or cache[0] != key:
+            self._plans = cache = (key, IntegratePlan(self, G, N, dev, f_kind, f_params))
+        return cache[1]
+
+    def resident_status(self, dev):
+        """Raise if a hand-off of the persistent kernel timed out (status bit 1; synchronises)."""
+        if self._ws is not None and int(self._ws[:4].view(torch.int32)[0].item()) & 2:
+            raise _lib.NisError("k_flow_mega: a team hand-off timed out (workgroups not co-resident?); results are invalid")
+
     integrate_step = integrate_steps
+
+
+class IntegratePlan:
+    """G iterations of integrate()'s loop body (draw -> flow -> camel * J -> moment records) as ONE hipGraph replay.
+
+    Eagerly the 8 launches of a set reach the GPU one API call at a time and the first, short kernels of a set finish
+    before the host has issued the next one: the first set after a synchronize costs ~90-330 us more than a later one
+    (tools/graph_probe.py).  A captured set is submitted whole.  The generator state {seed, next stream} lives on the
+    device and is advanced by the set's last launch, so every replay draws fresh numbers; records land in `self.out`.
+    Valid while the model's parameters are unchanged (integrate() never changes them)."""
+
+    def __init__(self, eng, G, N, dev, f_kind, f_params):
+        self.eng, self.G, self.N, self.dev = eng, int(G), int(N), torch.device(dev)
+        self.token = eng.pack_token()
+        self.state = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        self.out = torch.zeros((self.G, 4), dtype=torch.double, device=self.dev)
+        cells = eng.cells
+        for c in cells:
+            ensure_flat(c, self.dev)
+        keep = [(c._running.clone(), c._tracked.clone()) for c in cells]
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+
+        def call(n):
+            eng.integrate_steps_rng(self.G, n, self.dev, f_kind, f_params, self.out, 0, 0, token=self.token, rng_state=self.state)
+
+        self._call = call
+
+        with torch.cuda.stream(side):
+            call(min(self.N, 512))                   # a small batch: loads the code objects, packs the parameter image, sizes the workspace
+            side.synchronize()
+            for c, (r, t) in zip(cells, keep):       # ... and must leave no trace in the BN running statistics / counters
+                c._running.copy_(r)
+                c._tracked.copy_(t)
+            eng._stats_epoch -= 1
+            eng._planes_scratch(self.G, self.N, self.dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                call(self.N)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        eng._stats_epoch -= 1                        # capturing executed nothing
+
+    def reset(self, seed, stream0=0):
+        """Generator state for the next replay: batch g of it is Philox stream `stream0 + g` of key `seed`."""
+        self.state.copy_(torch.tensor([seed, stream0], dtype=torch.int64))
+
+    def run(self, dst, replay=None):
+        """One set on the current stream; the (G, 4) records are copied to `dst`.  replay=None: the captured graph when the
+        stream is idle (the set's first short kernels would otherwise wait for the host, ~90-330 us), eager launches when
+        work is already queued (the host is ahead then, and back-to-back graph replays measured 20 % slower than eager
+        launches: tools/plan_check.py).  Both forms run the same launches on the same device-resident generator state."""
+        if replay is None:
+            replay = torch.cuda.current_stream(self.dev).query()
+        if replay:
+            self.graph.replay()
+            self.eng._stats_epoch += 1
+        else:
+            self._call(self.N)
+        dst.copy_(self.out)
+
+
+def philox_rows(seed, stream0, G, N, d, dev):
+    """(G, N, d) float32 uniform draws of the library's counter-based generator (d == 2: exactly the draws the persistent
+    kernel makes for the same seed / streams; include/nis_hip.h gives the mapping)."""
+    _lib.require_gpu()
+    if d != 2:
+        raise _lib.NisError("philox_rows: the in-kernel generator is defined for d = 2 rows")
+    dev = torch.device(dev)
+    out = torch.empty((G, N, 2), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        _lib.check(_lib.lib().nis_philox_rows(seed, stream0, G, N, out.data_ptr(), _lib.stream_ptr(dev)), "nis_philox_rows")
+    return out
 
 
 def moments_of(planes, d, out_col, f_kind, f_params, want_fres=False):
@@ -314,8 +465,9 @@ def moments_of(planes, d, out_col, f_kind, f_params, want_fres=False):
     fres = torch.empty(N, dtype=torch.double, device=dev) if want_fres else None
     oc = (C.c_int32 * d)(*out_col)
     fp = (C.c_double * 4)(*(list(f_params) + [0.0] * 4)[:4])
-    rc = L.nis_integrand_moments(planes.data_ptr(), N, N, d, oc, f_kind, fp, fres.data_ptr() if want_fres else None,
-                                 out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr())
+    with _lib.on_device(dev):
+        rc = L.nis_integrand_moments(planes.data_ptr(), N, N, d, oc, f_kind, fp, fres.data_ptr() if want_fres else None,
+                                     out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
     _lib.check(rc, "nis_integrand_moments")
     return out4, fres
 
@@ -331,7 +483,8 @@ def moments(a, b=None):
     out4 = torch.empty(4, dtype=torch.double, device=a.device)
     wsb = L.nis_moments_workspace_bytes()
     ws = torch.empty(wsb, dtype=torch.uint8, device=a.device)
-    rc = L.nis_moments(a.data_ptr(), b.data_ptr() if b is not None else None, a.numel(), out4.data_ptr(),
-                       ws.data_ptr(), wsb, _lib.stream_ptr())
+    with _lib.on_device(a.device):
+        rc = L.nis_moments(a.data_ptr(), b.data_ptr() if b is not None else None, a.numel(), out4.data_ptr(),
+                           ws.data_ptr(), wsb, _lib.stream_ptr(a.device))
     _lib.check(rc, "nis_moments")
     return out4

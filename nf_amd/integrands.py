@@ -20,9 +20,9 @@ def _hip_eval(f, x):
     L = _lib.lib()
     out = torch.empty(x.shape[0], dtype=torch.double, device=x.device)
     p = list(f.nis_params) + [0.0] * (4 - len(f.nis_params))
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = L.nis_integrand_eval(f.nis_kind, (C.c_double * 4)(*p), x.data_ptr(), x.stride(0), x.shape[0], x.shape[1],
-                                  out.data_ptr(), _lib.stream_ptr())
+                                  out.data_ptr(), _lib.stream_ptr(x.device))
     _lib.check(rc, "nis_integrand_eval")
     return out
 

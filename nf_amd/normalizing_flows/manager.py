@@ -374,7 +374,7 @@ class BasicManager(ModelAPI):
         p = next(self.best_model.parameters())
         return p.device if p.is_cuda else torch.device("cuda:0")
 
-    batch_iterations = 16      # integrate(): iterations fused into one launch set (independent BN batches)
+    batch_iterations = 20      # integrate(): iterations fused into one launch set (independent BN batches)
 
     def moments_batches(self, f, nitn, neval, dev):
         """(count, mean, M2, max) of f(X)*J for nitn fresh batches; stays on the device."""
@@ -385,11 +385,26 @@ class BasicManager(ModelAPI):
         if fused:                           # G iterations per library call, X / J never stored
             eng = model.engine()
             G = max(1, min(int(self.batch_iterations), nitn, max(1, (1 << 28) // max(1, neval * (self.n_flow + 1)))))
+            # the draw happens inside the step (manager.py:395) when nobody replays given draws: the first launch of a set
+            # generates the float32 batch itself (Philox, keyed from torch's generator so torch.manual_seed governs it),
+            # and whole sets are replayed from a hipGraph (flow.IntegratePlan)
+            in_kernel = self.sample_hook is None and model.training and eng.rng_supported(True, f.nis_kind) and neval >= 2
+            plan = None
+            if in_kernel:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                if nitn >= G and os.environ.get("NIS_NO_GRAPH", "0") in ("", "0"):
+                    plan = eng.plan(G, neval, dev, f.nis_kind, f.nis_params)
+                    plan.reset(seed, 0)
             i = 0
             while i < nitn:
                 g = min(G, nitn - i)
-                w = torch.stack([self._uniform(neval, dev, torch.float32, "integrate") for _ in range(g)])
-                eng.integrate_steps(w, model.training, f.nis_kind, f.nis_params, out[i:i + g])
+                if plan is not None and g == G:
+                    plan.run(out[i:i + g])
+                elif in_kernel:
+                    eng.integrate_steps_rng(g, neval, dev, f.nis_kind, f.nis_params, out[i:i + g], seed, i)
+                else:
+                    w = torch.stack([self._uniform(neval, dev, torch.float32, "integrate") for _ in range(g)])
+                    eng.integrate_steps(w, model.training, f.nis_kind, f.nis_params, out[i:i + g])
                 i += g
             return out
         planar = hasattr(f, "from_planes") and isinstance(model, FlowSequential)
