@@ -155,6 +155,14 @@ int nis_integrate_steps_rng(nis_flow* f, int32_t n_batches, int64_t N,
                             int32_t bn_mode, int64_t pack_token, int32_t f_kind, const double* f_params_host,
                             uint64_t seed, uint64_t stream0, uint64_t* rng_state, float* w_out, double* planes, int64_t ld, double* out4,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* Test entry: ONE iteration of the fused step on the production direct-row kernels that additionally writes the bin index
+ * selected for every cell's transformed column, bins_out int32 [n_cells][ld] (K = 4 PWQuad chains of that kernel class;
+ * others: NIS_E_UNSUPPORTED).  The parity tests assert the bins bit-exact against the oracle at the bench's batch size. */
+int nis_integrate_steps_bins(nis_flow* f, const void* w, int32_t w_dtype, int64_t N,
+                             const double* const* params, double* const* running, long long* const* tracked,
+                             int64_t pack_token, int32_t f_kind, const double* f_params_host,
+                             double* planes, int64_t ld, int32_t* bins_out, double* out4,
+                             void* workspace, size_t workspace_bytes, void* stream);
 int nis_integrate_resident(const nis_flow* f, int32_t n_batches, int64_t N, int32_t bn_mode, int32_t f_kind);
 int nis_philox_rows(uint64_t seed, uint64_t stream0, int32_t n_batches, int64_t N, float* out, void* stream);
 

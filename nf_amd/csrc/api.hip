@@ -925,6 +925,7 @@ struct RunOpts {
   int rng = 0;
   unsigned long long seed = 0, stream0 = 0;
   float* w_out = nullptr;
+  int spec_bins = 0;                         // test entry (nis_integrate_steps_bins): the SPEC kernels of the bench path write bins_out
   unsigned long long* rng_state = nullptr;   // device {seed, next stream}: read by the drawing launch, advanced by n_batches in the
                                              //   set's epilogue launch -- a captured launch set draws new numbers on every replay
 };
@@ -1021,8 +1022,8 @@ static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid) {
 // Descriptor-level mirror of launch_apply's SPEC conditions (flow_wm.hip): every cell of a d = 2 PWQuad chain with 3-wide
 // conditioners and a compiled bin count, camel integrand fused into the last cell, nothing materialised.
 static bool direct_rows_ok(const nis_flow* f, const std::vector<CellLayout>& lay, const RunOpts& o, int w_dtype, int wcols, int ingest_P) {
-  if (f->d != 2 || wcols != 2 || w_dtype != NIS_F32 || o.w_has_jac || o.hist || o.keep_planes || o.xj_out || o.bins_out || o.fres_out ||
-      o.sync_fn || o.f_kind != NIS_F_CAMEL || !o.out4)
+  if (f->d != 2 || wcols != 2 || w_dtype != NIS_F32 || o.w_has_jac || o.hist || o.keep_planes || o.xj_out || (o.bins_out && !o.spec_bins) ||
+      o.fres_out || o.sync_fn || o.f_kind != NIS_F_CAMEL || !o.out4)
     return false;
   if (o.bn_mode != NIS_BN_TRAIN) return false;     // eval mode: inner cells carry no BN_0 rider and run the generic kernel
   if (env_int("NIS_NO_FOLD", 0) || env_int("NIS_NO_WX", 0) || env_int("NIS_NO_DERIVE1", 0) || getenv("NIS_NO_STATS_FOLD")) return false;
@@ -1524,6 +1525,33 @@ extern "C" int nis_integrate_steps_rng(nis_flow* f, int32_t n_batches, int64_t N
   o.rng_state = (unsigned long long*)rng_state;
   o.w_out = w_out;
   return flow_run(f, nullptr, NIS_F32, N, params, running, planes, planes ? ld : N, workspace, workspace_bytes, (hipStream_t)stream, o);
+}
+
+// Test entry: ONE iteration of the fused integrate step on the production (direct-row SPEC) code path that additionally writes
+// the selected bin index of every cell's transformed column: bins_out int32 [n_cells][N] (tests/test_gpu_parity.py asserts them
+// bit-exact against the oracle at the bench's full batch size).  Models outside the SPEC class: NIS_E_UNSUPPORTED.
+extern "C" int nis_integrate_steps_bins(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, const double* const* params,
+                                        double* const* running, long long* const* tracked, int64_t pack_token, int32_t f_kind,
+                                        const double* f_params_host, double* planes, int64_t ld, int32_t* bins_out, double* out4,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (!out4 || !bins_out || f_kind < 0 || !f) return NIS_E_ARG;
+  for (int ci = 0; ci < f->n_cells; ++ci)
+    if (f->cells[ci].kind != NIS_PWQUAD || f->cells[ci].K != 4) return NIS_E_UNSUPPORTED;
+  RunOpts o;
+  o.G = 1;
+  o.bn_mode = NIS_BN_TRAIN;
+  o.pack_token = pack_token;
+  o.tracked = tracked;
+  o.f_kind = f_kind;
+  o.f_params = f_params_host;
+  o.out4 = out4;
+  o.keep_planes = 0;
+  o.bins_out = bins_out;
+  o.spec_bins = 1;
+  std::vector<CellLayout> lay;
+  flow_layout(f, 1, &lay, nullptr);
+  if (!direct_rows_ok(f, lay, o, w_dtype, f->d, f->cells[0].P) || env_int("NIS_NO_DIRECT_ROWS", 0) || env_int("NIS_MEGA", 0)) return NIS_E_UNSUPPORTED;
+  return flow_run(f, w, w_dtype, N, params, running, planes, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
 }
 
 extern "C" int nis_integrate_resident(const nis_flow* f, int32_t n_batches, int64_t N, int32_t bn_mode, int32_t f_kind) {

@@ -708,7 +708,9 @@ __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const do
 // ROWS (SPEC kernels only): the transformed input -- and, for c.x_wcol >= 0, the pass-through input too -- is read from the
 // float32 (N, 2) rows of w (CellK::wrows) instead of its plane: one 8-byte row load per sample.
 // FIRST (ROWS kernels): the flow's first cell -- both inputs come from the row, the incoming Jacobian is 1: ONE load per sample.
-template <int KIND, int WM, int KM, bool KEXACT, int WX = WM, int SPEC = 0, bool ROWS = false, bool FIRST = false>
+// BINS (SPEC kernels, test instantiation): the selected bin indices are written to bins_out although the production SPEC
+// kernels never output them -- tests assert them bit-exact against the oracle on the very code path the bench runs.
+template <int KIND, int WM, int KM, bool KEXACT, int WX = WM, int SPEC = 0, bool ROWS = false, bool FIRST = false, bool BINS = false>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                         int* __restrict__ bins_out, FuseF fz) {
   static_assert(!ROWS || SPEC != 0, "row input exists on the SPEC kernels only");
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   const bool fold = SP ? true : c.fold != 0;
   const int cP = SP ? 1 : c.P, cT = SP ? 1 : c.T;
   const long out_off = SP ? 0 : c.out_off;
-  int* const bins_o = SP ? nullptr : bins_out;
+  int* const bins_o = SP ? (BINS ? bins_out : nullptr) : bins_out;
   nis_cptr wl = as_const(c.wlast);
   nis_cptr bias = as_const(c.bias);
   constexpr bool GATHER = SP && KM <= 8;    // (2 KM + 1) x 2 KB of LDS per workgroup: 18 KB at KM = 4, 34 KB at KM = 8

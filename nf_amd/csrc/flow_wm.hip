@@ -157,7 +157,15 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
   hipLaunchKernelGGL((k_cell_apply<KIND, NIS_WM, KMV, EX, 3>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
 #define NIS_APPLY3S(KMV, SP)                                                                                                       \
   do {                                                                                                                             \
-    if (rows && c.first)                                                                                                           \
+    if (bins && rows && KMV == 4 && c.first)          /* test instantiation: SPEC kernels that also write the bin indices */        \
+      hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, 4, true, 3, SP, true, true, true>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c, \
+                         planes, ld, N, bn_train, bins, fz);                                                                       \
+    else if (bins && rows && KMV == 4)                                                                                             \
+      hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, 4, true, 3, SP, true, false, true>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c, \
+                         planes, ld, N, bn_train, bins, fz);                                                                       \
+    else if (bins)                                                                                                                 \
+      return hipErrorInvalidValue;                                                                                                 \
+    else if (rows && c.first)                                                                                                      \
       hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP, true, true>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c,   \
                          planes, ld, N, bn_train, bins, fz);                                                                       \
     else if (rows)                                                                                                                 \
@@ -170,7 +178,7 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
   const bool rows = c.wrows && c.xb_wcol >= 0;           // transformed input (and maybe the pass-through one) from the rows of w
   if (c.wrows && c.x_wcol >= 0 && !rows) return hipErrorInvalidValue;
   if (rows && (c.first != 0) != (c.x_wcol >= 0)) return hipErrorInvalidValue;   // row kernels: first cell <=> both inputs in w
-  if (c.wx == 3 && c.kind == NIS_PWQUAD && km < 0 && c.P == 1 && c.T == 1 && c.L == 3 && c.fold && c.out_off == 0 && !bins && !fz.fres) {
+  if (c.wx == 3 && c.kind == NIS_PWQUAD && km < 0 && c.P == 1 && c.T == 1 && c.L == 3 && c.fold && c.out_off == 0 && (!bins || (rows && km == -4)) && !fz.fres) {
     // the two cells of a d = 2 chain: every wave-uniform switch resolved at compile time (k_cell_apply, SPEC)
     // 1: the next cell passes THIS cell's output through (next_src[0] == 1: the alternating roll of a d = 2 chain);
     // 2: the camel's two arguments are this cell's two columns, in either order (the integrand is symmetric)

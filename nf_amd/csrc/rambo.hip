@@ -225,7 +225,9 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
           scale *= 0.5;
         }
       } else {
-        u = rb_solve(v, e);
+        // v == 0 exactly (a float32 draw is 0.0 once per 1.7e7 values): the reference's lattice bisection ends on its lowest
+        // lattice point 2^-levels > 0 (120-180 levels), never on 0, and its weight stays finite (every K ratio is 0/0 at u = 0)
+        u = fmax(rb_solve(v, e), 0x1p-180);
       }
       M[c + 1] = sqrt(u * (M[c] * M[c]));                                           // :370
     }

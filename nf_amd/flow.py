@@ -322,6 +322,25 @@ class FlowEngine:
                 return False
         return True
 
+    def integrate_step_bins(self, w, f_kind, f_params):
+        """Test hook: one fused train-mode iteration on the production direct-row kernels, returning ((4,) moment record,
+        (n_cells, N) int32 bin indices).  w: (N, 2) float32 CUDA tensor."""
+        w = self._check_input(w, self.d, True)
+        N, dev = w.shape[0], w.device
+        pp, rp, tp = self._pointers(dev)
+        ws, wsb = self._workspace(dev, 1)
+        planes = self._planes_scratch(1, N, dev)
+        bins = torch.full((len(self.cells), N), -1, dtype=torch.int32, device=dev)
+        out4 = torch.zeros((1, 4), dtype=torch.double, device=dev)
+        fp = (C.c_double * 4)(*(list(f_params) + [0.0] * 4)[:4])
+        with _lib.on_device(dev):
+            rc = self.L.nis_integrate_steps_bins(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64, N,
+                                                 pp, rp, tp, self.pack_token(), f_kind, fp, planes.data_ptr(), N, bins.data_ptr(),
+                                                 out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+        _lib.check(rc, "nis_integrate_steps_bins")
+        self._stats_epoch += 1
+        return out4[0], bins
+
     def integrate_steps_rng(self, G, N, dev, f_kind, f_params, out4, seed, stream0, token=None, w_out=None, rng_state=None):
         """The same G iterations with the draw inside the step (manager.py:395): batch g is drawn on the device from Philox
         stream `stream0 + g` of key `seed` (mapping: include/nis_hip.h) by the launch that gathers BN_0's records; no input

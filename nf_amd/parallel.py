@@ -44,9 +44,15 @@ def world():
     return 0, 1
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, timeout_s=300):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); backend "nccl" (= RCCL)
-    on GPUs, "gloo" on CPU.  Returns (rank, world_size, local_rank)."""
+    on GPUs, "gloo" on CPU.  Returns (rank, world_size, local_rank).
+
+    RCCL needs one GPU per rank: the call fails fast with a clear message when the node shows fewer devices than ranks
+    (two ranks on one device end in `ncclInvalidUsage: Duplicate GPU detected` deep inside the first collective otherwise),
+    binds the communicator to this rank's device (`device_id`: no "guessing device ID" warning, no lazy-init hang) and
+    sets an explicit timeout.  `NIS_DIST_BACKEND=gloo` rehearses several ranks on one GPU."""
+    import datetime
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -56,9 +62,17 @@ def init_from_env(backend=None):
         backend = os.environ.get("NIS_DIST_BACKEND") or backend        # e.g. gloo to rehearse N ranks on one GPU
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("NIS_DIST_TIMEOUT_S", timeout_s)))}
         if torch.cuda.is_available():
-            torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+            ndev = torch.cuda.device_count()
+            local_ws = int(os.environ.get("LOCAL_WORLD_SIZE", ws))
+            if backend == "nccl" and ndev < local_ws:
+                raise RuntimeError(f"RCCL needs one GPU per rank: {local_ws} local ranks but {ndev} visible device(s) "
+                                   "(set NIS_DIST_BACKEND=gloo to rehearse several ranks on one GPU)")
+            torch.cuda.set_device(local % ndev)
+            if backend == "nccl":
+                kw["device_id"] = torch.device("cuda", local % ndev)
+        dist.init_process_group(backend=backend, rank=rank, world_size=ws, **kw)
     return rank, ws, local
 
 

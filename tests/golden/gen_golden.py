@@ -18,6 +18,7 @@ Output files (np.savez_compressed, keys are "<case>/<name>"):
     training.npz   short _train_variance_forward_seq runs (history, grads, returns)
     rambo.npz      FlatInvertiblePhasespace.generateKinematics_batch cases
     affine.npz     AffineCoupling cells and AffineManager models
+    wide.npz       C3 / C4 / C5 topologies (width-32 conditioners): autograd gradients at N = 512, train-mode forward at N = 2e5
 """
 import os
 import sys
@@ -397,7 +398,90 @@ def gen_affine():
     print("affine.npz:", len(meta), "cases")
 
 
+# --------------------------------------------------------------------------- wide conditioners (BASELINE configs C3 / C4 / C5)
+def kronecker_w(N, d):
+    """Deterministic, exactly reproducible inputs in [0, 1): element k = i d + j of the golden-ratio Kronecker sequence,
+    ((k + 1) * 0x9E3779B97F4A7C15 mod 2^64) >> 11, times 2^-53 (the tests rebuild it with the same integer arithmetic)."""
+    k = np.arange(1, N * d + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        v = (k * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(11)
+    return (v.astype(np.float64) * 2.0 ** -53).reshape(N, d)
+
+
+def gen_wide():
+    """(a) reference autograd gradients of every parameter (and of the input) for a fixed random cotangent on XJ, C3 and C5
+    topologies at N = 512, train-mode BN;  (b) train-mode forward of the C3 / C4 / C5 topologies at N = 200 000: per-column
+    moments of XJ, 4 096 sampled rows and the updated running statistics (the input is kronecker_w, not stored)."""
+    out, meta = {}, {}
+    topo_cases = {"C3": ("pwlin", dict(d=8, P=4, n_cells=4, K=64, NN=[32] * 3, roll=4)),
+                  "C4": ("pwquad", dict(d=10, n_cells=5, K=16, NN=[32] * 3)),
+                  "C5": ("pwquad", dict(d=16, n_cells=8, K=16, NN=[32] * 3))}
+
+    def build(kind, c, seed):
+        if kind == "pwquad":
+            return build_pwquad(c["d"], c["n_cells"], c["K"], c["NN"], seed)
+        return build_pwlin(c["d"], c["P"], c["n_cells"], c["K"], c["NN"], c["roll"], seed)
+
+    for tag in ("C3", "C5"):
+        kind, c = topo_cases[tag]
+        name = f"grad_{tag}"
+        NF = build(kind, c, 70)
+        model = NF._model
+        for i, m in enumerate(model.children()):
+            if hasattr(m, "NN"):
+                randomize(m, 700 + i, last_scale=1.0)
+        put_state(out, name, model)
+        N = 512
+        g = torch.Generator().manual_seed(71)
+        w = torch.rand(N, c["d"], dtype=torch.double, generator=g).requires_grad_(True)
+        cot = torch.randn(N, c["d"] + 1, dtype=torch.double, generator=g)
+        model.train()
+        XJ = model(NF.format_input(w, torch.device("cpu")))
+        (XJ * cot).sum().backward()
+        out[f"{name}/w"] = npy(w)
+        out[f"{name}/cot"] = npy(cot)
+        out[f"{name}/XJ"] = npy(XJ)
+        out[f"{name}/gw"] = npy(w.grad)
+        for pn, p in model.named_parameters():
+            out[f"{name}/grad/{pn}"] = npy(p.grad)
+        names, passes = topo(model)
+        meta[name] = dict(kind=kind, what="grad", N=N, children=names, passes=passes, **c)
+
+    torch.set_num_threads(8)
+    for tag in ("C3", "C4", "C5"):
+        kind, c = topo_cases[tag]
+        name = f"fwd_{tag}"
+        NF = build(kind, c, 80)
+        model = NF._model
+        for i, m in enumerate(model.children()):
+            if hasattr(m, "NN"):
+                randomize(m, 800 + i, last_scale=1.0)
+        put_state(out, name, model)
+        N = 200_000
+        w = torch.as_tensor(kronecker_w(N, c["d"]))
+        model.train()
+        with torch.no_grad():
+            XJ = model(NF.format_input(w, torch.device("cpu")))
+        rows = np.arange(0, N, N // 4096)[:4096]
+        out[f"{name}/rows"] = rows
+        out[f"{name}/XJ_rows"] = npy(XJ[rows])
+        out[f"{name}/col_mean"] = npy(XJ.mean(0))
+        out[f"{name}/col_var"] = npy(XJ.var(0))
+        out[f"{name}/col_min"] = npy(XJ.min(0).values)
+        out[f"{name}/col_max"] = npy(XJ.max(0).values)
+        for k, v in model.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                out[f"{name}/sd_after/{k}"] = npy(v)
+        names, passes = topo(model)
+        meta[name] = dict(kind=kind, what="fwd", N=N, children=names, passes=passes, **c)
+        print(name, "done", flush=True)
+    torch.set_num_threads(1)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "wide.npz"), **out)
+    print("wide.npz:", len(meta), "cases")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cells", "models", "integrate", "training", "rambo", "affine"]
+    which = sys.argv[1:] or ["cells", "models", "integrate", "training", "rambo", "affine", "wide"]
     for w in which:
         globals()["gen_" + w]()

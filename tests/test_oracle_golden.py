@@ -87,6 +87,30 @@ def test_integrate_matches_reference(case, g_integrate):
         np.testing.assert_allclose(after[k], v, rtol=1e-10, atol=1e-14)
 
 
+def test_torch_restatement_matches_reference_and_numpy(g_integrate):
+    """oracle/flow_torch.py (bench.py's all-core CPU baseline) against the reference's own integrate() vectors and the NumPy oracle."""
+    import torch
+    from oracle import flow_torch as otorch
+    case = [c for c in _cases("integrate.npz") if c.startswith("camel")][0]
+    m = g_integrate.meta[case]
+    steps = plan_from_meta(m)
+    params = g_integrate.sub(case, "sd")
+    w = g_integrate.get(case, "w")
+    sig, sig_err, means, variances, after = otorch.integrate(otorch.camel, otorch.to_torch(params), steps,
+                                                             [torch.as_tensor(x) for x in w])
+    np.testing.assert_allclose(means.numpy(), g_integrate.get(case, "mean"), rtol=2e-6)        # float32 stores, as the reference
+    np.testing.assert_allclose(variances.numpy(), g_integrate.get(case, "var"), rtol=2e-6)
+    np.testing.assert_allclose(sig, g_integrate.get(case, "sig"), rtol=2e-6)
+    np.testing.assert_allclose(sig_err, g_integrate.get(case, "sig_err"), rtol=2e-6)
+    for k, v in g_integrate.sub(case, "sd_after").items():
+        np.testing.assert_allclose(after[k].numpy(), v, rtol=1e-10, atol=1e-14)
+    rng = np.random.default_rng(3)
+    x = rng.random((777, 2))
+    a = oflow.model_forward(x, params, steps, True)
+    b = otorch.model_forward(torch.as_tensor(x), otorch.to_torch(params), steps, True).numpy()
+    np.testing.assert_allclose(b, a, rtol=1e-12, atol=1e-15)
+
+
 @pytest.mark.parametrize("case", _cases("rambo.npz"))
 def test_rambo_matches_reference(case, g_rambo):
     m = g_rambo.meta[case]

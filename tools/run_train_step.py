@@ -1,6 +1,8 @@
 """Time one training minibatch (forward + backward of var(f*J/maxf)) of the C2 model at mbs = 1e6."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from torch_adjoint import model_torch          # test infrastructure: the stock-PyTorch adjoint the kernels are compared with
 import torch
 from nf_amd import integrands
 from nf_amd.normalizing_flows.manager import PWQuadManager, hip_var
@@ -12,14 +14,10 @@ f = integrands.Camel()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 w = torch.rand(N, 2, dtype=torch.double, device=dev)
 for mode in ("hip", "torch"):
-    if mode == "torch":
-        os.environ["NF_AMD_TORCH_ADJOINT"] = "1"
-    else:
-        os.environ.pop("NF_AMD_TORCH_ADJOINT", None)
     def step():
         for p in NF._model.parameters():
             p.grad = None
-        XJ = NF._forward(w, dev)                       # what _train_variance_forward_seq calls
+        XJ = model_torch(NF._model, w, has_jac=False) if mode == "torch" else NF._forward(w, dev)   # the latter: what _train_variance_forward_seq calls
         fres = f(XJ[:, :-1].detach()) * XJ[:, -1]
         loss = hip_var(fres)
         loss.backward()

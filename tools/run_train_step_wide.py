@@ -2,6 +2,8 @@
 hand-written matrix-core adjoint against the stock-PyTorch adjoint.  usage: run_train_step_wide.py [N] [configs]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from torch_adjoint import model_torch          # test infrastructure: the stock-PyTorch adjoint the kernels are compared with
 import torch
 from nf_amd import integrands
 from nf_amd.normalizing_flows.manager import PWLinManager, PWQuadManager, hip_var
@@ -31,15 +33,10 @@ for name in which:
     f = integrands.Normal(0.5, 0.1, d) if hasattr(integrands, "Normal") else None
     w = torch.rand(N, d, dtype=torch.double, device=dev) * (1 - 1e-9)
     for mode in modes:
-        if mode == "torch":
-            os.environ["NF_AMD_TORCH_ADJOINT"] = "1"
-        else:
-            os.environ.pop("NF_AMD_TORCH_ADJOINT", None)
-
         def step():
             for p in NF._model.parameters():
                 p.grad = None
-            XJ = NF._forward(w, dev)                       # what _train_variance_forward_seq calls
+            XJ = model_torch(NF._model, w, has_jac=False) if mode == "torch" else NF._forward(w, dev)   # the latter: what _train_variance_forward_seq calls
             fres = torch.exp(-((XJ[:, :-1].detach() - 0.5) ** 2).sum(-1) / 0.5) * XJ[:, -1]
             loss = hip_var(fres)
             loss.backward()
