@@ -104,6 +104,19 @@ __device__ __forceinline__ double nis_rsqrt(double x) {
   return r;
 }
 
+// sqrt(x) for x in the normal range or exactly 0 (negative -> NaN like sqrt): v_rsq_f64 + one Goldschmidt step + the residual
+// correction, <= 1 ulp.  11 instructions; the compiler's IEEE sqrt (input scaling by v_ldexp, v_cmp_class fix-ups) is ~20,
+// and the 2 -> 4 RAMBO map takes 29 square roots per sample.
+__device__ __forceinline__ double nis_sqrt(double x) {
+  const double r = __builtin_amdgcn_rsq(x);
+  double g = x * r, h = 0.5 * r;
+  const double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  g = fma(fma(-g, g, x), h, g);
+  return x == 0.0 ? 0.0 : g;
+}
+
 static inline int nis_pick_wm(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 16 ? 16 : m <= 32 ? 32 : m <= 64 ? 64 : -1; }
 static inline int nis_pick_km(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : -1; }
 // workgroup size of the statistics kernel: as many waves as the register budget of width WM allows

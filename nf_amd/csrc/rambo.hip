@@ -32,7 +32,7 @@ struct RamboK {
 // rho(M, N, m) = rb_rho_num(M, N, m) / (8 M^2)                                   // :107-113
 __device__ __forceinline__ double rb_rho_num(double M, double N, double m) {
   const double Msqr = M * M;
-  return sqrt((Msqr - (N + m) * (N + m)) * (Msqr - (N - m) * (N - m)));
+  return nis_sqrt((Msqr - (N + m) * (N + m)) * (Msqr - (N - m) * (N - m)));
 }
 __device__ __forceinline__ double rb_rho(double M, double N, double m) { return rb_rho_num(M, N, m) * nis_rcp(8. * (M * M)); }
 
@@ -48,20 +48,20 @@ __device__ __forceinline__ double rb_ipow(double x, int e) {
 // leading-order root) and left of it in the concave part.  8 steps reach the fixed point of the double evaluation
 // (<= few ulp from the lattice bisection's limit; identical conditioning: both stall where g' ~ 0 at v -> 1).
 __device__ __forceinline__ double rb_solve(double v, int e) {
-  if (e == 1) return v / (1.0 + sqrt(1.0 - v));                  // 2u - u^2 = v
+  if (e == 1) return v / (1.0 + nis_sqrt(1.0 - v));                  // 2u - u^2 = v
   const double ui = (double)(e - 1) / (double)e;
   const double vi = rb_ipow(ui, e) * ((double)(e + 1) - (double)e * ui);
   const bool convex = v < vi;
   double u;
   if (convex) {
     const double vr = v * (1.0 / (double)(e + 1));      // starting guesses: reciprocals instead of IEEE divisions (the fixed point does not move)
-    const double us = e == 2 ? sqrt(vr) : e == 3 ? cbrt(vr) : e == 4 ? sqrt(sqrt(vr)) : pow(vr, 1.0 / (double)e);
+    const double us = e == 2 ? nis_sqrt(vr) : e == 3 ? cbrt(vr) : e == 4 ? nis_sqrt(nis_sqrt(vr)) : pow(vr, 1.0 / (double)e);
     double c0 = us * nis_rcp(1.0 - fmin(us, 0.9));
     c0 = fmin(c0, ui);
     const double g0 = rb_ipow(c0, e) * ((double)(e + 1) - (double)e * c0);
     u = (g0 >= v) ? c0 : ui;
   } else {
-    const double ub = 1.0 - sqrt((1.0 - v) * (2.0 / (double)(e * (e + 1))));
+    const double ub = 1.0 - nis_sqrt((1.0 - v) * (2.0 / (double)(e * (e + 1))));
     u = fmax(ui, ub);
   }
 #pragma unroll 1
@@ -83,7 +83,7 @@ struct V4 {
   double e, x, y, z;
 };
 
-__device__ __forceinline__ void rb_set_square(V4& p, double sq) { p.e = sqrt((p.x * p.x + p.y * p.y + p.z * p.z) + sq); }   // utils.py:5-19
+__device__ __forceinline__ void rb_set_square(V4& p, double sq) { p.e = nis_sqrt((p.x * p.x + p.y * p.y + p.z * p.z) + sq); }   // utils.py:5-19
 
 __device__ __forceinline__ void rb_boost(V4& p, double bx, double by, double bz) {                                          // utils.py:58-81
   const double b2 = bx * bx + by * by + bz * bz;
@@ -101,15 +101,15 @@ __device__ __forceinline__ void rb_boost(V4& p, double bx, double by, double bz)
 // form without cancellation is taken per sign of pz -- same value to ~1 ulp without atan2 and tan (~200 VALU instructions).
 __device__ __forceinline__ double rb_pseudorap(const V4& p) {
   const double pt2 = p.x * p.x + p.y * p.y;
-  const double pt = sqrt(pt2);
-  const double pa = sqrt(pt2 + p.z * p.z);
+  const double pt = nis_sqrt(pt2);
+  const double pa = nis_sqrt(pt2 + p.z * p.z);
   double th2 = p.z >= 0.0 ? pt / (pa + p.z) : (pa - p.z) / pt;
   th2 = fmin(fmax(th2, 6.123e-17), 1.633e16);               // pt == 0 exactly: the reference's tan(atan2(0, pz) / 2) stays finite too
   return (pt < RB_EPS && fabs(p.z) < RB_EPS) ? RB_HUGE : -log(th2);
 }
 
 __device__ __forceinline__ double rb_delphi(const V4& a, const V4& b) {                                                     // utils.py:170-180
-  const double pt1 = sqrt(a.x * a.x + a.y * a.y), pt2 = sqrt(b.x * b.x + b.y * b.y);
+  const double pt1 = nis_sqrt(a.x * a.x + a.y * a.y), pt2 = nis_sqrt(b.x * b.x + b.y * b.y);
   double tmp = a.x * b.x + a.y * b.y;
   tmp /= (pt1 * pt2);
   double r = fabs(tmp) > 1.0 ? acos(tmp / fabs(tmp)) : acos(tmp);
@@ -153,9 +153,24 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
   // the cache lines are fully used) or its element of each column plane, one tile AHEAD: the loads of the next tile are
   // in flight while the current one is computed.  PDF columns only exist in the PDF modes.
   constexpr int NIN = HAS_PDF ? NPS + 2 : NPS;
+  // row-major rows of exactly NIN doubles (NIN even): 16-byte vector loads, NIN / 2 per sample instead of NIN 8-byte ones
+  typedef double nis_d2 __attribute__((ext_vector_type(2)));
+  const bool vec_rows = !col_major && (NIN % 2 == 0) && k.r_ld == NIN && k.ncol == NIN && ((unsigned long long)r & 15ull) == 0;
   auto fetch = [&](long t, double (&dst)[NPS + 2]) {
     const long ii = t * RB_TPB + tid;
     const bool ok = ii < N;
+    if (vec_rows) {
+      const nis_d2* p = reinterpret_cast<const nis_d2*>(r + (size_t)(ok ? ii : 0) * NIN);
+#pragma unroll
+      for (int c2 = 0; c2 < (NPS + 2) / 2; ++c2) {
+        nis_d2 v = {0.5, 0.5};
+        if (2 * c2 < NIN) v = p[c2];
+        dst[2 * c2] = ok ? v.x : 0.5;
+        dst[2 * c2 + 1] = ok ? v.y : 0.5;
+      }
+      if ((NPS + 2) % 2) dst[NPS + 1] = 0.5;
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < NPS + 2; ++c) {
       double v = 0.5;
@@ -188,14 +203,14 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
         const double ymin = 0.5 * log(tau);
         const double d_y = (-ymin) - ymin;
         const double ycm = ymin + d_y * rv[NPS + 1];
-        x1 = sqrt(tau) * exp(ycm);
-        x2 = sqrt(tau) * exp(-ycm);
-        E = sqrt(tau) * k.d.E_cm;
+        x1 = nis_sqrt(tau) * exp(ycm);
+        x2 = nis_sqrt(tau) * exp(-ycm);
+        E = nis_sqrt(tau) * k.d.E_cm;
         wgt *= d_tau * d_y;
       } else {
         x1 = rv[NPS + 1];
         x2 = rv[NPS];
-        E = sqrt(x1 * x2) * k.d.E_cm;
+        E = nis_sqrt(x1 * x2) * k.d.E_cm;
       }
       if (x1 < 1e-4 || x2 < 1e-4) wgt *= 0.0;         // x_cut (:185-186); pdf density == 1
     }
@@ -229,7 +244,7 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
         // lattice point 2^-levels > 0 (120-180 levels), never on 0, and its weight stays finite (every K ratio is 0/0 at u = 0)
         u = fmax(rb_solve(v, e), 0x1p-180);
       }
-      M[c + 1] = sqrt(u * (M[c] * M[c]));                                           // :370
+      M[c + 1] = nis_sqrt(u * (M[c] * M[c]));                                           // :370
     }
     double w_ps = pdf_active ? k.flat_ab * (rb_ipow(E * E, NF - 2) / k.flat_fact) : k.flat_const;   // :81-97
 #pragma unroll
@@ -267,10 +282,10 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     for (int c = 0; c < NF - 1; ++c) {
       const double q = 4. * M[c] * rb_rho(M[c], M[c + 1], k.d.final_masses[c]);     // :228
       const double cos_t = 2. * rv[NF - 2 + 2 * c] - 1.;
-      const double sin_t = sqrt(1. - cos_t * cos_t);
+      const double sin_t = nis_sqrt(1. - cos_t * cos_t);
       const double phi = 2 * M_PI * rv[NF - 2 + 2 * c + 1];
       const double cos_p = cospi(2.0 * rv[NF - 2 + 2 * c + 1]);   // = cos(2 pi r) without the large-argument reduction path
-      const double sq = sqrt(1. - cos_p * cos_p);
+      const double sq = nis_sqrt(1. - cos_p * cos_p);
       const double sin_p = phi > M_PI ? -sq : sq;                                   // :241-243
       V4 p = {0., q * sin_t * cos_p, q * sin_t * sin_p, q * cos_t};
       const double m2 = k.d.final_masses[c] * k.d.final_masses[c];
@@ -306,7 +321,7 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
       const double M1 = k.d.initial_masses[0] * k.d.initial_masses[0], M2 = k.d.initial_masses[1] * k.d.initial_masses[1];
       const double E2_ = E * E;
       const double E1 = (E2_ + M1 - M2) / E, E2 = (E2_ - M1 + M2) / E;
-      const double Z = sqrt(E2_ * E2_ - 2 * E2_ * M1 - 2 * E2_ * M2 + M1 * M1 - 2 * M1 * M2 + M2 * M2) / E;
+      const double Z = nis_sqrt(E2_ * E2_ - 2 * E2_ * M1 - 2 * E2_ * M2 + M1 * M1 - 2 * M1 * M2 + M2 * M2) / E;
       in0 = {E1 / 2.0, 0., 0., Z / 2.0};
       in1 = {E2 / 2.0, 0., 0., -(Z / 2.0)};
     }
@@ -322,14 +337,24 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
 #pragma unroll
         for (int l = 0; l < NF + 2; ++l) put_leg(l, mom[l]);
       }
-      __syncthreads();
-      double* dst = momenta + (size_t)i0 * LM;
-      const int tot = ns * LM;
-      for (int e = tid; e < tot; e += RB_TPB) {
-        const int s_ = e / LM, q = e - s_ * LM;      // LM is a compile-time constant
-        dst[e] = rb_lds[s_ * (LM + 1) + q];
+      // each wave stages and streams out ITS OWN 64 rows: the LDS unit serves one wave's accesses in order, so the wave's
+      // reads see its own writes without a workgroup barrier (two s_barrier per tile stalled every wave on the slowest one)
+      __builtin_amdgcn_wave_barrier();
+      const int wv = tid >> 6, ln = tid & 63;
+      const int nsw = min(64, ns - wv * 64);           // rows of this wave in the (possibly ragged) tile
+      double* dst = momenta + ((size_t)i0 + wv * 64) * LM;
+      const double* src = rb_lds + (size_t)wv * 64 * (LM + 1);
+      const int tot = nsw * LM;                        // LM is even: a 16-byte pair never straddles two rows
+      for (int e = 2 * ln; e < tot; e += 128) {        // 16 bytes per lane and store: 1 KiB contiguous per wave instruction
+        const int s_ = e / LM, q = e - s_ * LM;        // LM is a compile-time constant
+        const nis_d2 v = {src[s_ * (LM + 1) + q], src[s_ * (LM + 1) + q + 1]};
+#ifdef RB_ABLATE_STORE                                   // timing-only build: everything but the momenta stores (results wrong)
+        if (v.x == 1.2345e300) *reinterpret_cast<nis_d2*>(dst + e) = v;
+#else
+        *reinterpret_cast<nis_d2*>(dst + e) = v;
+#endif
       }
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();
     }
 
     // ---- lab frame (utils.py:134-146); the batch-global "any zero reference" test is the caller's
@@ -348,7 +373,7 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     if (pT_mincut > 0.) {                         // min pT >= 0 can never be below a cut <= 0 (:285-288)
       double ptmin = RB_HUGE;
 #pragma unroll
-      for (int l = 0; l < NF; ++l) ptmin = fmin(ptmin, fabs(sqrt(mom[2 + l].x * mom[2 + l].x + mom[2 + l].y * mom[2 + l].y)));
+      for (int l = 0; l < NF; ++l) ptmin = fmin(ptmin, fabs(nis_sqrt(mom[2 + l].x * mom[2 + l].x + mom[2 + l].y * mom[2 + l].y)));
       factor = (ptmin < pT_mincut) ? 0.0 : 1.0;
     }
     const bool need_eta = (delR_mincut > 0.) || (rap_maxcut > 0.);
@@ -362,7 +387,7 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
 #pragma unroll
           for (int b = 0; b < a; ++b) {
             const double de = eta[a] - eta[b], dp = rb_delphi(mom[2 + a], mom[2 + b]);
-            if (fabs(sqrt(de * de + dp * dp)) < delR_mincut) factor = 0.0;
+            if (fabs(nis_sqrt(de * de + dp * dp)) < delR_mincut) factor = 0.0;
           }
       }
       if (rap_maxcut > 0.) {

@@ -1,10 +1,12 @@
 #!/bin/bash
 # A/B builds of libnis_hip.so for on-box comparisons:  tools/build_variant.sh NAME "-DFLAG=.. -DFLAG2"  ->  nf_amd/lib/variants/NAME.so
-# (select with NIS_LIB=$PWD/nf_amd/lib/variants/NAME.so).  Only flow_mega.hip is rebuilt with the flags; the other objects are reused.
+# (select with NIS_LIB=$PWD/nf_amd/lib/variants/NAME.so).  Only UNIT (default flow_mega; e.g. rambo) is rebuilt with the flags; the other
+# objects are reused.   tools/build_variant.sh NAME "FLAGS" [UNIT]
 set -e
 cd "$(dirname "$0")/.."
+UNIT=${3:-flow_mega}
 mkdir -p nf_amd/lib/variants /tmp/nisvar
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function $2 -c nf_amd/csrc/flow_mega.hip -o /tmp/nisvar/$1.o
-OBJS=$(ls nf_amd/csrc/build/*.o | grep -v flow_mega.o)
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function $2 -c nf_amd/csrc/$UNIT.hip -o /tmp/nisvar/$1.o
+OBJS=$(ls nf_amd/csrc/build/*.o | grep -v /$UNIT.o)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o nf_amd/lib/variants/$1.so $OBJS /tmp/nisvar/$1.o
 echo nf_amd/lib/variants/$1.so
