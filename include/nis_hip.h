@@ -242,6 +242,24 @@ int nis_rambo_forward(const nis_rambo_desc* desc_host, const double* r, int64_t 
                       const int32_t* r_cols_host, int64_t N, double* momenta, double* weight,
                       int32_t* status, void* stream);
 
+/* Parton densities inside the map (flat_phase_space_generator.py:120-137, :183-187: `pdf.xfxQ2(pdg, x, 91.188^2) / x` per
+ * beam, an lhapdf.PDF call per sample in the reference).  One table per beam: x f(x, Q^2) of that beam's parton at the
+ * FIXED scale on the x knots of an lhagrid1 grid (device arrays: logx[nx] ascending, xf[nx]; nx == 0: density 1, which is
+ * also what the reference uses for particle ids other than the gluon and the quarks).  The kernel evaluates LHAPDF 6's
+ * log-cubic rule in x (cubic Hermite in log x, knot derivatives = mean of the adjacent differences, one-sided at the
+ * edges; the log Q^2 direction of the log-bicubic rule is folded into the table by the caller, nf_amd/PhaseSpace/
+ * pdf_grid.py), x frozen at the grid boundaries.  nis_pdf_xfx evaluates x f(x) alone (PdfGrid.xfxQ2). */
+typedef struct nis_pdf1d {
+  const double* logx;
+  const double* xf;
+  int32_t nx;
+  int32_t reserved;
+} nis_pdf1d;
+int nis_rambo_forward_pdf(const nis_rambo_desc* desc_host, const nis_pdf1d* pdf_beams_host /* [2] */,
+                          const double* r, int64_t r_ld, int32_t r_col_major, const int32_t* r_cols_host, int64_t N,
+                          double* momenta, double* weight, int32_t* status, void* stream);
+int nis_pdf_xfx(const nis_pdf1d* table_host, const double* x, int64_t N, double* out, void* stream);
+
 /* Live timing of ONE kernel class with HIP events recorded on the launch stream around every launch of
  * that class (bench.py's roofline leg).  kernel_class: 0 cell-apply, 1 BN statistics, 2 ingest,
  * 3 integrand+moments, 4 rambo, 5 emit, 6 pack, 7 moments.  nis_prof_read synchronises the recorded

@@ -1,7 +1,8 @@
 """`FlatInvertiblePhasespace` with the reference's constructor and `generateKinematics_batch` signature
 (/root/reference/nisrep/PhaseSpace/flat_phase_space_generator.py:25-54, :57-79, :139-308); the map itself
-runs in the `k_rambo` HIP kernel (nis_rambo_forward).  Only pdf=None is supported (density 1,
-reference :124-125); a real LHAPDF set is out of scope.
+runs in the `k_rambo` HIP kernel (nis_rambo_forward).  pdf=None gives unit parton densities (reference :124-125);
+`pdf=nf_amd.PhaseSpace.pdf_grid.PdfGrid` (an lhagrid1 grid, what LHAPDF reads) evaluates x f(x, 91.188^2) / x per beam
+inside the kernel (reference :120-137, :183-187; LHAPDF itself stays out of scope).
 """
 import ctypes as C
 import math
@@ -24,8 +25,9 @@ class VirtualPhaseSpaceGenerator(object):
         self.pdf = pdf
         self.pdf_active = pdf_active
         self.tau = tau
-        if pdf is not None:
-            raise NotImplementedError("nf_amd evaluates pdf=None only (unit parton densities); LHAPDF sets are out of scope")
+        if pdf is not None and not (hasattr(pdf, "table") and hasattr(pdf, "has")):
+            raise NotImplementedError("pdf must be None or an nf_amd.PhaseSpace.pdf_grid.PdfGrid (an lhagrid1 grid evaluated on "
+                                      "the device); lhapdf.PDF objects are host-only and out of scope")
 
     def generateKinematics(self, E_cm, random_variables):
         raise NotImplementedError
@@ -78,16 +80,33 @@ class FlatInvertiblePhasespace(VirtualPhaseSpaceGenerator):
         d.bisect_levels = int(self.bisect_levels)
         return d
 
-    def _launch(self, desc, r, momenta, weight, status, col_major=False, cols=None, ld=None, N=None):
+    PDF_SCALE2 = 91.188 ** 2   # the reference evaluates the densities at this fixed scale (:184)
+
+    def _pdf_tables(self, pdgs, dev):
+        """nis_pdf1d[2] for the two beams, or None: get_pdfQ2 (:120-137) uses the grid for the gluon and the quarks only."""
+        if self.pdf is None or not self.pdf_active:
+            return None
+        from .pdf_grid import Pdf1d
+        tabs = (Pdf1d * 2)()
+        for b in range(2):
+            pdg = int(pdgs[b])
+            if pdg == 21 or abs(pdg) in range(1, 7):
+                if not self.pdf.has(pdg):
+                    raise PhaseSpaceGeneratorError(f"the PDF grid holds no parton {pdg}")
+                tabs[b] = self.pdf.table(pdg, self.PDF_SCALE2, dev)
+        return tabs
+
+    def _launch(self, desc, r, momenta, weight, status, col_major=False, cols=None, ld=None, N=None, pdgs=(0, 0)):
         L = _lib.lib()
         N = r.shape[0] if N is None else N
         ld = r.shape[1] if ld is None else ld
         cp = (C.c_int32 * len(cols))(*cols) if cols is not None else None
+        tabs = self._pdf_tables(pdgs, r.device)
         with _lib.on_device(r.device):
-            rc = L.nis_rambo_forward(C.byref(desc), r.data_ptr(), ld, 1 if col_major else 0, cp, N,
-                                     momenta.data_ptr() if momenta is not None else None, weight.data_ptr(),
-                                     status.data_ptr(), _lib.stream_ptr(r.device))
-        _lib.check(rc, "nis_rambo_forward")
+            rc = L.nis_rambo_forward_pdf(C.byref(desc), tabs, r.data_ptr(), ld, 1 if col_major else 0, cp, N,
+                                         momenta.data_ptr() if momenta is not None else None, weight.data_ptr(),
+                                         status.data_ptr(), _lib.stream_ptr(r.device))
+        _lib.check(rc, "nis_rambo_forward_pdf")
 
     def generateKinematics_batch(self, E_cm, random_variables_full, pT_mincut=-1, delR_mincut=-1, rap_maxcut=-1,
                                  pdgs=[0, 0]):
@@ -109,19 +128,19 @@ class FlatInvertiblePhasespace(VirtualPhaseSpaceGenerator):
         # Lab boost: the reference boosts the WHOLE batch unless some sample has a zero spatial reference
         # vector (utils.py:139-144) -- always the case without PDFs (x1 = x2 = 1).
         lab = bool(self.pdf_active)
-        self._launch(self._desc(E_cm, pT_mincut, delR_mincut, rap_maxcut, lab), r, momenta, weight, status)
+        self._launch(self._desc(E_cm, pT_mincut, delR_mincut, rap_maxcut, lab), r, momenta, weight, status, pdgs=pdgs)
         st = int(status.item())
         if st & 2:
             raise PhaseSpaceGeneratorError("Some of the random variables passed to the phase-space generator are NaN")
         if lab and (st & 4):          # a sample with x1 == x2: the reference then skips the boost for everyone
             status.zero_()
-            self._launch(self._desc(E_cm, pT_mincut, delR_mincut, rap_maxcut, False), r, momenta, weight, status)
+            self._launch(self._desc(E_cm, pT_mincut, delR_mincut, rap_maxcut, False), r, momenta, weight, status, pdgs=pdgs)
             st = int(status.item())
         if st & 8:
             print("Invalid boost")    # utils.py:33-34
         return momenta, weight
 
-    def weights_from_planes(self, E_cm, planes, cols, N, pT_mincut=-1, delR_mincut=-1, rap_maxcut=-1):
+    def weights_from_planes(self, E_cm, planes, cols, N, pT_mincut=-1, delR_mincut=-1, rap_maxcut=-1, pdgs=(0, 0)):
         """Weight only, reading the random numbers from column planes (the flow's internal layout):
         the integrand side of a fused flow -> RAMBO evaluation.  No momenta are written."""
         _lib.require_gpu()
@@ -132,7 +151,7 @@ class FlatInvertiblePhasespace(VirtualPhaseSpaceGenerator):
         self.collider_energy = E_cm
         lab = bool(self.pdf_active)
         desc = self._desc(E_cm, pT_mincut, delR_mincut, rap_maxcut, lab)
-        self._launch(desc, planes, None, weight, status, col_major=True, cols=list(cols), ld=planes.shape[1], N=N)
+        self._launch(desc, planes, None, weight, status, col_major=True, cols=list(cols), ld=planes.shape[1], N=N, pdgs=pdgs)
         # the status word is honoured exactly as on the row path (generateKinematics_batch): NaN guard (reference :147-149),
         # and the batch-global "skip the lab boost if any sample has x1 == x2" rule (utils.py:139-144)
         st = int(status.item())
@@ -141,7 +160,7 @@ class FlatInvertiblePhasespace(VirtualPhaseSpaceGenerator):
         if lab and (st & 4):
             status.zero_()
             self._launch(self._desc(E_cm, pT_mincut, delR_mincut, rap_maxcut, False), planes, None, weight, status, col_major=True,
-                         cols=list(cols), ld=planes.shape[1], N=N)
+                         cols=list(cols), ld=planes.shape[1], N=N, pdgs=pdgs)
             st = int(status.item())
         if st & 8:
             print("Invalid boost")    # utils.py:33-34

@@ -20,6 +20,7 @@ struct RamboK {
   double msum[NIS_MAX_LEGS];   // msum[i] = sum_{j>=i} m_j
   double mtot;
   double tau_min;
+  nis_pdf1d pdf[2];            // per beam: x f(x) at the fixed scale on the grid's x knots (nx == 0: density 1)
   int cols[3 * NIS_MAX_LEGS];  // column -> plane (column-major input) or identity
   long r_ld;
   int col_major;
@@ -117,6 +118,33 @@ __device__ __forceinline__ double rb_delphi(const V4& a, const V4& b) {         
   return r;
 }
 
+// x f(x) by LHAPDF 6's log-cubic rule on one table (include/nis_hip.h, nis_pdf1d): binary search for the knot interval
+// (uniform trip count: ceil(log2 nx)), cubic Hermite in log x with mean-of-adjacent-differences knot derivatives.
+__device__ __forceinline__ double rb_pdf_xf(const nis_pdf1d& t, double x) {
+  const int n = t.nx;
+  double lx = log(x);
+  lx = fmin(fmax(lx, t.logx[0]), t.logx[n - 1]);
+  int lo = 0, hi = n - 1;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    const bool le = t.logx[mid] <= lx;
+    lo = le ? mid : lo;
+    hi = le ? hi : mid;
+  }
+  const int i = lo;
+  const double l0 = t.logx[i], l1 = t.logx[i + 1], f0 = t.xf[i], f1 = t.xf[i + 1];
+  const double dl = l1 - l0, s = (f1 - f0) / dl;
+  double d0 = s, d1 = s;
+  if (i > 0) d0 = 0.5 * (s + (f0 - t.xf[i - 1]) / (l0 - t.logx[i - 1]));
+  if (i + 2 < n) d1 = 0.5 * (s + (t.xf[i + 2] - f1) / (t.logx[i + 2] - l1));
+  const double u = (lx - l0) / dl, u2 = u * u, u3 = u2 * u;
+  return (2 * u3 - 3 * u2 + 1) * f0 + (u3 - 2 * u2 + u) * (d0 * dl) + (-2 * u3 + 3 * u2) * f1 + (u3 - u2) * (d1 * dl);
+}
+
+__global__ __launch_bounds__(256) void k_pdf_xfx(nis_pdf1d t, const double* __restrict__ x, long N, double* __restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) out[i] = rb_pdf_xf(t, x[i]);
+}
+
 #ifndef RB_TPB
 #define RB_TPB 128      // threads (= samples) per tile: bounds the LDS staging area to 128*(4(n+2)+1)*8 B
 #endif
@@ -212,7 +240,9 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
         x2 = rv[NPS];
         E = nis_sqrt(x1 * x2) * k.d.E_cm;
       }
-      if (x1 < 1e-4 || x2 < 1e-4) wgt *= 0.0;         // x_cut (:185-186); pdf density == 1
+      if (k.pdf[0].nx > 0) wgt *= rb_pdf_xf(k.pdf[0], x1) / x1;      // get_pdfQ2 (:120-137): x f(x, 91.188^2) / x per beam
+      if (k.pdf[1].nx > 0) wgt *= rb_pdf_xf(k.pdf[1], x2) / x2;
+      if (x1 < 1e-4 || x2 < 1e-4) wgt *= 0.0;         // x_cut (:185-186)
     }
 
     // ---- intermediate masses: lattice bisection per column (:313-359), then :363-406
@@ -410,15 +440,36 @@ static double host_fact(int n) {
   return f;
 }
 
+extern "C" int nis_pdf_xfx(const nis_pdf1d* th, const double* x, int64_t N, double* out, void* stream) {
+  if (!th || !x || !out || N < 1 || th->nx < 2 || !th->logx || !th->xf) return NIS_E_ARG;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (N + 255) / 256));
+  hipLaunchKernelGGL(k_pdf_xfx, dim3(grid), dim3(256), 0, (hipStream_t)stream, *th, x, (long)N, out);
+  return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
+}
+
 extern "C" int nis_rambo_forward(const nis_rambo_desc* dh, const double* r, int64_t r_ld, int32_t r_col_major,
                                  const int32_t* r_cols_host, int64_t N, double* momenta, double* weight, int32_t* status,
                                  void* stream) {
+  return nis_rambo_forward_pdf(dh, nullptr, r, r_ld, r_col_major, r_cols_host, N, momenta, weight, status, stream);
+}
+
+extern "C" int nis_rambo_forward_pdf(const nis_rambo_desc* dh, const nis_pdf1d* pdfh, const double* r, int64_t r_ld, int32_t r_col_major,
+                                     const int32_t* r_cols_host, int64_t N, double* momenta, double* weight, int32_t* status,
+                                     void* stream) {
   if (!dh || !r || !weight || !status || N < 1) return NIS_E_ARG;
+  if (pdfh)
+    for (int b = 0; b < 2; ++b)
+      if (pdfh[b].nx != 0 && (pdfh[b].nx < 2 || !pdfh[b].logx || !pdfh[b].xf)) return NIS_E_ARG;
+  if (pdfh && (pdfh[0].nx || pdfh[1].nx) && !(dh->flags & NIS_RAMBO_PDF_ACTIVE)) return NIS_E_ARG;
   const int n = dh->n_final;
   if (n < 2 || n > NIS_MAX_LEGS) return NIS_E_UNSUPPORTED;
   RamboK k;
   memset(&k, 0, sizeof(k));
   k.d = *dh;
+  if (pdfh) {
+    k.pdf[0] = pdfh[0];
+    k.pdf[1] = pdfh[1];
+  }
   const bool pdf_active = dh->flags & NIS_RAMBO_PDF_ACTIVE;
   k.ncol = 3 * n - 4 + (pdf_active ? 2 : 0);
   k.r_ld = r_ld;

@@ -84,5 +84,5 @@ class RamboWeight:
         return wgt
 
     def from_planes(self, planes, out_col, N):
-        wgt, status = self.gen.weights_from_planes(self.E_cm, planes, out_col, N, *self.cuts)
+        wgt, status = self.gen.weights_from_planes(self.E_cm, planes, out_col, N, *self.cuts, pdgs=self.pdgs)
         return wgt

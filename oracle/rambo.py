@@ -117,7 +117,7 @@ def _delta_R(p1, p2):
 
 
 def generate_kinematics(initial_masses, final_masses, E_cm, r_full, pT_mincut=-1, delR_mincut=-1, rap_maxcut=-1,
-                        pdf_active=False, tau=True, want=None):
+                        pdf_active=False, tau=True, want=None, pdf=None, pdgs=(0, 0)):
     """generateKinematics_batch with pdf=None (:139-308).  Returns (momenta (N,2+n,4) in the COM frame,
     weight (N,)).  `want` (dict) receives intermediates: u, M (with masses), x1, x2, cut factor, lab momenta."""
     r_full = np.asarray(r_full, dtype=np.float64)
@@ -152,7 +152,10 @@ def generate_kinematics(initial_masses, final_masses, E_cm, r_full, pT_mincut=-1
             E = np.sqrt(x1 * x2) * E_cm
         x_cut = np.where(x1 < 1e-4, 0.0, 1.0)
         x_cut = np.where(x2 < 1e-4, 0.0, x_cut)
-        wgt = wgt * x_cut                                                   # pdf == 1  (:187)
+        wgt = wgt * x_cut                                                   # pdf == None -> densities 1  (:187)
+        if pdf is not None:                                                 # get_pdfQ2 (:120-137) at the fixed scale 91.188^2 (:184);
+            from . import pdf as _pdf                                       # `pdf`: list of oracle.pdf.Subgrid (parity unpinned, see there)
+            wgt = wgt * _pdf.density(pdf, pdgs[0], x1, 91.188 ** 2) * _pdf.density(pdf, pdgs[1], x2, 91.188 ** 2)
     assert r.shape[1] == (0 if n == 1 else 3 * n - 4)                       # :191
     per_sample_E = isinstance(E, np.ndarray)
 

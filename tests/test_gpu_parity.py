@@ -1346,3 +1346,58 @@ def test_launch_set_variants_agree_with_the_plain_path(variant, monkeypatch):
         np.testing.assert_allclose(sd[k], sd_ref[k], rtol=1e-9, atol=1e-15, err_msg=k)
     fed, _ = run({}, "fed")
     np.testing.assert_allclose(fed, ref, rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------ device-side PDF interpolation (parity unpinned)
+def _synthetic_grid(two=False):
+    from test_oracle_golden import synthetic_pdf_grid
+    from oracle import pdf as opdf
+    from nf_amd.PhaseSpace.pdf_grid import PdfGrid
+    subs, f = synthetic_pdf_grid(two)
+    return subs, PdfGrid.from_lhagrid1(opdf.write_lhagrid1(subs))
+
+
+@pytest.mark.parametrize("two", [False, True])
+def test_pdf_grid_xfx_vs_oracle(two):
+    """PdfGrid.xfxQ2 (k_pdf_xfx: 1-D log-cubic on the host-folded table) against the NumPy restatement of LHAPDF's
+    log-bicubic rule: interior, knots, both grid edges, arguments outside the grid (frozen at the boundary)."""
+    from oracle import pdf as opdf
+    subs, grid = _synthetic_grid(two)
+    rng = np.random.default_rng(5)
+    x = np.concatenate([10 ** rng.uniform(-6, 0, 20000), subs[0].xs, [1e-7, 1e-9, 1.0, 1.5, subs[0].xs[0], subs[0].xs[-1]]])
+    for q2 in (91.188 ** 2, 20.0, 99.9, 100.0, 5e7, 1.0, 1e9):
+        for pid in (21, -2, 1):
+            got = t2n(grid.xfxQ2(pid, torch.as_tensor(x).to(dev()), q2))
+            want = opdf.xfx_q2(subs, pid, x, q2)
+            np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-14, err_msg=f"{pid} {q2}")
+
+
+@pytest.mark.parametrize("n,cuts,pdgs", [(4, (-1, -1, -1), [21, 21]), (6, (20., 0.4, 2.5), [2, -1]), (3, (5., 0.3, -1), [22, 21])])
+def test_rambo_with_pdf_grid_vs_oracle(n, cuts, pdgs):
+    """generateKinematics_batch with a PDF grid: x f(x, 91.188^2) / x per beam evaluated inside k_rambo (reference :120-137,
+    :183-187) -- weights against the oracle (pdf=None weight x the NumPy LHAPDF-rule densities), row and plane input."""
+    from nf_amd import integrands
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    subs, grid = _synthetic_grid(True)
+    rng = np.random.default_rng(n)
+    final = [0.0] * n if n != 4 else [float(v) for v in rng.uniform(5, 80, n)]
+    E, N = 13000., 20011
+    r = rng.random((N, 3 * n - 2))
+    ref_m, ref_w = orambo.generate_kinematics([0., 0.], final, E, r, *cuts, pdf_active=True, tau=True, pdf=subs, pdgs=pdgs)
+    gen = FlatInvertiblePhasespace([0., 0.], final, pdf=grid, pdf_active=True, tau=True)
+    mom, wgt = gen.generateKinematics_batch(E, torch.as_tensor(r).to(dev()), *cuts, pdgs=pdgs)
+    w = t2n(wgt)
+    differ = (w == 0) != (ref_w == 0)
+    assert differ.sum() <= 2
+    np.testing.assert_allclose(w[~differ], ref_w[~differ], rtol=1e-8)
+    np.testing.assert_allclose(t2n(mom), ref_m, rtol=1e-8, atol=1e-9 * E)
+    # the densities really entered: the same points without the grid differ by exactly that factor
+    gen0 = FlatInvertiblePhasespace([0., 0.], final, pdf=None, pdf_active=True, tau=True)
+    _, w0 = gen0.generateKinematics_batch(E, torch.as_tensor(r).to(dev()), *cuts, pdgs=pdgs)
+    ratio = w[(w != 0)] / t2n(w0)[(w != 0)]
+    assert ratio.std() > 0.1 * abs(ratio.mean()) and np.isfinite(ratio).all()
+    # plane input (the flow's layout): RamboWeight.from_planes
+    planes = torch.as_tensor(r.T.copy()).to(dev())
+    f = integrands.RamboWeight(gen, E, *cuts, pdgs=pdgs)
+    wp = t2n(f.from_planes(planes, list(range(3 * n - 2)), N))
+    np.testing.assert_array_equal(wp, w)

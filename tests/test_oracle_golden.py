@@ -192,3 +192,48 @@ def test_affine_model_topology_and_forward(case, g_affine):
     params2.update(upd)
     XJe = oflow.model_forward(w, params2, steps, False)
     np.testing.assert_allclose(XJe, g_affine.get(case, "XJ_eval"), rtol=1e-10, atol=1e-13)
+
+
+# ------------------------------------------------------------------------------ PDF grids (parity unpinned: no LHAPDF fixture exists)
+def synthetic_pdf_grid(two_subgrids=False):
+    """A smooth toy parton set on lhagrid1-like knots: x f = x^(-0.2 + 0.01 p) (1 - x)^(3 + 0.1 |p|) (1 + 0.05 ln Q^2)."""
+    from oracle import pdf as opdf
+    xs = np.concatenate([np.logspace(-6, -1, 40, endpoint=False), np.linspace(0.1, 1.0, 30)])
+    pids = [-2, -1, 1, 2, 21]
+
+    def f(x, q2, p):
+        return (x ** (-0.2 + 0.01 * p)) * ((1 - x) ** (3 + 0.1 * abs(p))) * (1 + 0.05 * np.log(q2))
+
+    def sub(q2s):
+        return opdf.Subgrid(xs, q2s, pids, np.array([[[f(x, q, p) for p in pids] for q in q2s] for x in xs]))
+
+    if two_subgrids:
+        return [sub(np.logspace(0.5, 2.0, 6)), sub(np.logspace(2.0, 8.0, 20))], f
+    return [sub(np.logspace(0.5, 8.0, 25))], f
+
+
+def test_pdf_oracle_and_host_collapse():
+    """oracle/pdf.py (the published LHAPDF 6 log-bicubic rule): lhagrid1 round trip, exact at the knots, close to the smooth
+    function between them; the product's host-side fold of the log Q^2 direction (PdfGrid.collapse) gives the oracle's
+    values on the x knots."""
+    from oracle import pdf as opdf
+    from nf_amd.PhaseSpace.pdf_grid import PdfGrid
+    for two in (False, True):
+        subs, f = synthetic_pdf_grid(two)
+        back = opdf.parse_lhagrid1(opdf.write_lhagrid1(subs))
+        assert len(back) == len(subs)
+        for a, b in zip(subs, back):
+            np.testing.assert_array_equal(a.xf, b.xf)
+            np.testing.assert_allclose(a.q2s, b.q2s, rtol=1e-15)
+        g = subs[-1]
+        np.testing.assert_allclose(opdf.xfx_q2(subs, 21, g.xs[3:-3], g.q2s[4]), g.xf[3:-3, 4, 4], rtol=1e-13)
+        rng = np.random.default_rng(1)
+        x, q2 = 10 ** rng.uniform(-4, np.log10(0.8), 3000), 10 ** rng.uniform(1, 7, 3000)
+        v = opdf.xfx_q2(subs, 2, x, q2)
+        assert np.max(np.abs(v - f(x, q2, 2)) / f(x, q2, 2)) < 2e-3
+        grid = PdfGrid.from_lhagrid1(opdf.write_lhagrid1(subs))
+        for q in (91.188 ** 2, 10.0, 3.5e7, g.q2s[5]):
+            lx, val = grid.collapse(-1, q)
+            want = opdf.xfx_q2(subs, -1, np.exp(lx), q)
+            np.testing.assert_allclose(val, want, rtol=1e-12)
+    assert float(opdf.density(subs, 22, np.array([0.3]), 8000.)[0]) == 1.0          # not a parton: density 1 (reference :128-129)
