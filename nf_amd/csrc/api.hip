@@ -125,7 +125,7 @@ struct nis_flow {
   int packed_mode = -1;
   int packed_G = 0;
   const void* packed_ws = nullptr;
-  std::vector<const double*> packed_params;
+  std::vector<const double*> packed_params, packed_running;
   const void* mega_ws = nullptr;     // workspace whose hand-off granules have been zeroed (flow_mega.hip)
 };
 
@@ -223,6 +223,7 @@ extern "C" int nis_flow_create(const nis_cell_desc* cells, int32_t n_cells, int3
     f->out_col[j] = out_col[j];
   }
   f->packed_params.assign(n_cells, nullptr);
+  f->packed_running.assign(n_cells, nullptr);
   *out = f;
   return NIS_OK;
 }
@@ -1066,7 +1067,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   // is the padded parameter image in this workspace still valid?
   bool repack = o.pack_token == 0 || o.pack_token != f->packed_token || o.bn_mode != f->packed_mode || workspace != f->packed_ws ||
                 G != f->packed_G;
-  for (int ci = 0; ci < f->n_cells && !repack; ++ci) repack = params[ci] != f->packed_params[ci];
+  for (int ci = 0; ci < f->n_cells && !repack; ++ci) repack = params[ci] != f->packed_params[ci] || running[ci] != f->packed_running[ci];
 
   // ---- ingest (+ BN_0 records of the first cell)
   const nis_cell_desc& c0 = f->cells[0];
@@ -1131,7 +1132,10 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     f->packed_mode = o.bn_mode;
     f->packed_ws = workspace;
     f->packed_G = G;
-    for (int ci = 0; ci < f->n_cells; ++ci) f->packed_params[ci] = params[ci];
+    for (int ci = 0; ci < f->n_cells; ++ci) {
+      f->packed_params[ci] = params[ci];
+      f->packed_running[ci] = running[ci];
+    }
   };
   // G > 1, train mode: ONE launch at the end applies the running-statistics updates of all batches in batch order and
   // merges the fused integrand's moment records

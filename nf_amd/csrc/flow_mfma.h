@@ -19,6 +19,9 @@ typedef double nis_d4 __attribute__((ext_vector_type(4)));
 
 #define NIS_MF_TPB 256                 // 4 waves, one per SIMD
 #define NIS_MF_NCB 4                   // transformed columns per bijector batch (4 x 16 samples = 64 lanes)
+#ifndef NIS_MF_CHAINS
+#define NIS_MF_CHAINS 1                // row tiles of the last layer in flight per wave; 2 independent chains measured SLOWER (C5 forward 10.3 vs 9.1 ms, C3 26.3 vs 22.2)
+#endif
 
 template <int WM>
 struct MfCfg {
@@ -239,20 +242,37 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
       for (int cb = 0; cb * NCB < c.T; ++cb) {
         const int r0 = cb * NCB * out;
         const int r1 = min(c.R, r0 + NCB * out);
-        for (int jt = r0 / 16; jt * 16 < r1; ++jt) {
-          nis_d4 z;
+        // two row tiles at a time: two independent accumulation chains per wave (a chain of dependent f64 MFMAs leaves the
+        // pipe idle between issues; with the other wave's chain that made two per SIMD, now four) sharing the B operands
+        for (int jt = r0 / 16; jt * 16 < r1; jt += NIS_MF_CHAINS) {
+          const bool two = NIS_MF_CHAINS > 1 && (jt + 1) * 16 < r1;
+          const int jb = two ? jt + 1 : jt;              // single tail tile: the second chain repeats it (results discarded)
+          nis_d4 z, zb;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) z[r] = bias_pad[16 * jt + gq + 4 * r];
+          for (int r = 0; r < 4; ++r) {
+            z[r] = bias_pad[16 * jt + gq + 4 * r];
+            zb[r] = bias_pad[16 * jb + gq + 4 * r];
+          }
 #pragma unroll
           for (int q = 0; q < KQ; ++q) {
             const double a = wm_last[((size_t)jt * KQ + q) * 64 + lane];
+            const double ab = wm_last[((size_t)jb * KQ + q) * 64 + lane];
             z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Hs[q], z, 0, 0, 0);
+            zb = __builtin_amdgcn_mfma_f64_16x16x4f64(ab, Hs[q], zb, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int j = 16 * jt + gq + 4 * r - r0;
             if (j >= 0 && j < NCB * out && 16 * jt + gq + 4 * r < c.R)
               ring[j * 16 + s] = (KIND == NIS_AFFINE && (j & 1)) ? z[r] : nis_exp(z[r], etab);   // affine: odd rows = raw shift
+          }
+          if (two) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = 16 * jb + gq + 4 * r - r0;
+              if (j >= 0 && j < NCB * out && 16 * jb + gq + 4 * r < c.R)
+                ring[j * 16 + s] = (KIND == NIS_AFFINE && (j & 1)) ? zb[r] : nis_exp(zb[r], etab);
+            }
           }
         }
         // (sample s, column t) per lane.  A wave executes in lock step and its LDS operations complete in order:

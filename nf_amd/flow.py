@@ -120,7 +120,6 @@ class FlowEngine:
         self._ws = None
         self._sig = None
         self._token = 0
-        self._stats_epoch = 0
 
     def fusable(self):
         """The built-in-integrand rider lives in the narrow (register width <= 8) apply kernels."""
@@ -143,10 +142,22 @@ class FlowEngine:
             self._sig = None
         return self._ws, wsb
 
+    # The running statistics live in blobs the kernels update behind torch's back; the count of such updates is kept ON THE
+    # CELL (several engines can share a cell: `model[0](x)` through the cell's own engine and `model(x)` through the
+    # Sequential's), so an engine sees the updates another engine made and re-packs its eval-mode BatchNorm image.
+    @property
+    def _stats_epoch(self):
+        return sum(getattr(c, "_stats_epoch", 0) for c in self.cells)
+
+    def _stats_bump(self, d):
+        for c in self.cells:
+            c._stats_epoch = getattr(c, "_stats_epoch", 0) + d
+
     def pack_token(self):
         """Changes whenever a parameter / BN buffer was modified (torch version counters) or a train-mode
-        forward of ours advanced the running statistics: libnis_hip then re-packs its parameter image."""
-        sig = (self._stats_epoch,) + tuple(t._version for c in self.cells for t in c.state_dict(keep_vars=True).values())
+        forward (of ANY engine over these cells) advanced the running statistics: libnis_hip then re-packs its parameter image."""
+        sig = tuple(getattr(c, "_stats_epoch", 0) for c in self.cells) + \
+            tuple(t._version for c in self.cells for t in c.state_dict(keep_vars=True).values())
         if sig != self._sig:
             self._sig = sig
             self._token += 1
@@ -183,7 +194,7 @@ class FlowEngine:
                                          bins.data_ptr() if want_bins else None, ws.data_ptr(), wsb, _lib.stream_ptr(dev))
         _lib.check(rc, "nis_flow_forward")
         if train:
-            self._stats_epoch += 1
+            self._stats_bump(1)
         status = ws[:4].view(torch.int32)
         self._raise_on_status(status)
         return dict(planes=planes, xj=xj, bins=bins, status=status, ws=ws)
@@ -194,9 +205,25 @@ class FlowEngine:
         in-place all-gather (RCCL on GPUs) of `world` x (3 x width) doubles per BatchNorm layer.  Returns the same dict as
         `forward`; concatenating the ranks' results reproduces the single-process forward of the concatenated batch."""
         import torch.distributed as dist
-        w = self._check_input(w, self.d + (1 if has_jac else 0), False)      # a shard may hold a single row
-        N, dev = w.shape[0], w.device
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+        # every check that can fail happens BEFORE the first exchange, and the ranks agree on the outcome with one small
+        # all-reduce: a rank that raised alone would leave its peers blocked in the first all-gather
+        err = None
+        try:
+            w = self._check_input(w, self.d + (1 if has_jac else 0), False)      # a shard may hold a single row
+            if max([c.pass_through_size for c in self.cells] + [max(c.hidden_widths) for c in self.cells]) > 64:
+                raise _lib.NisError("forward_sync exchanges at most 64 features per BatchNorm layer")
+        except Exception as exc:                          # noqa: BLE001 - re-raised below on every rank
+            err = exc
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=w.device if torch.is_tensor(w) and w.is_cuda else "cpu")
+        if dist.get_backend(group) == "nccl" and not ok.is_cuda:
+            ok = ok.cuda()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if err is not None:
+            raise err
+        if int(ok.item()) == 0:
+            raise _lib.NisError("forward_sync: another rank rejected its arguments; no exchange was started")
+        N, dev = w.shape[0], w.device
         pp, rp, tp = self._pointers(dev)
         ws, wsb = self._workspace(dev)
         planes = torch.empty((self.d + 1, N), dtype=torch.double, device=dev)
@@ -207,6 +234,7 @@ class FlowEngine:
 
         def exchange(ctx, records, count, stream):
             try:                                             # an exception must not vanish inside the ctypes callback
+                assert count <= 64 * 3, f"record of {count} doubles exceeds the exchange buffer"
                 flat = buf[:world * count]
                 dist.all_gather_into_tensor(flat, flat[rank * count:(rank + 1) * count].clone(), group=group)
             except BaseException as exc:                     # noqa: BLE001 - re-raised after the library call returns
@@ -221,7 +249,7 @@ class FlowEngine:
         if failure:
             raise failure[0]
         _lib.check(rc, "nis_flow_forward_sync")
-        self._stats_epoch += 1
+        self._stats_bump(1)
         status = ws[:4].view(torch.int32)
         self._raise_on_status(status)
         return dict(planes=planes, xj=xj, bins=None, status=status, ws=ws)
@@ -251,7 +279,7 @@ class FlowEngine:
                                                1 if has_jac else 0, N, pp, rp, tp, self.pack_token(), hist.data_ptr(), N,
                                                bnsave.data_ptr(), xj.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
         _lib.check(rc, "nis_flow_forward_train")
-        self._stats_epoch += 1
+        self._stats_bump(1)
         self._raise_on_status(ws[:4].view(torch.int32))
         return xj, (hist, bnsave, has_jac)
 
@@ -307,7 +335,7 @@ class FlowEngine:
                                             _lib.stream_ptr(dev))
         _lib.check(rc, "nis_integrate_steps")
         if train:
-            self._stats_epoch += 1
+            self._stats_bump(1)
         self._raise_on_status(ws[:4].view(torch.int32))
         return fres
 
@@ -338,7 +366,7 @@ class FlowEngine:
                                                  pp, rp, tp, self.pack_token(), f_kind, fp, planes.data_ptr(), N, bins.data_ptr(),
                                                  out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
         _lib.check(rc, "nis_integrate_steps_bins")
-        self._stats_epoch += 1
+        self._stats_bump(1)
         return out4[0], bins
 
     def integrate_steps_rng(self, G, N, dev, f_kind, f_params, out4, seed, stream0, token=None, w_out=None, rng_state=None):
@@ -373,7 +401,7 @@ class FlowEngine:
                                                 planes.data_ptr() if planes is not None else None, N, out4.data_ptr(),
                                                 ws.data_ptr(), wsb, _lib.stream_ptr(dev))
         _lib.check(rc, "nis_integrate_steps_rng")
-        self._stats_epoch += 1
+        self._stats_bump(1)
         return None
 
     def _planes_scratch(self, G, N, dev):
@@ -433,13 +461,13 @@ class IntegratePlan:
             for c, (r, t) in zip(cells, keep):       # ... and must leave no trace in the BN running statistics / counters
                 c._running.copy_(r)
                 c._tracked.copy_(t)
-            eng._stats_epoch -= 1
+            eng._stats_bump(-1)
             eng._planes_scratch(self.G, self.N, self.dev)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=side):
                 call(self.N)
         torch.cuda.current_stream(self.dev).wait_stream(side)
-        eng._stats_epoch -= 1                        # capturing executed nothing
+        eng._stats_bump(-1)                          # capturing executed nothing
 
     def reset(self, seed, stream0=0):
         """Generator state for the next replay: batch g of it is Philox stream `stream0 + g` of key `seed`."""
@@ -454,7 +482,7 @@ class IntegratePlan:
             replay = torch.cuda.current_stream(self.dev).query()
         if replay:
             self.graph.replay()
-            self.eng._stats_epoch += 1
+            self.eng._stats_bump(1)
         else:
             self._call(self.N)
         dst.copy_(self.out)

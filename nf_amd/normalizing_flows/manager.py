@@ -150,9 +150,12 @@ class BasicManager(ModelAPI):
         d = self.n_flow
 
         # ---- flat-sampling survey: d batches of 2*mbs points (:139-165)
+        survey = []
         for _ in range(d):
             w = self._uniform(2 * mini_batch_size, dev, torch.double, "survey")
             fres = f(w)
+            if self.data_parallel is not None:
+                survey.append(fres.detach())
             m = hip_moments(fres)
             integ[0] += m[1] * (2 * mini_batch_size) / (d * 2 * mini_batch_size)
             err[0] += (m[2] / (m[0] - 1.0)) / d
@@ -171,6 +174,16 @@ class BasicManager(ModelAPI):
         if self.data_parallel is not None:                  # same normalisation / starting point on every rank
             dp = self.data_parallel
             maxf = dp.sync_max(torch.as_tensor(maxf, device=dev))
+            # the survey's loss / variance are ratios to max f: with the rank-local running maximum the ranks would average
+            # differently normalised numbers -- redo them with the global one before averaging
+            self.best_loss, self.best_var = 0, 0
+            for fres in survey:
+                if loss_mode == "var":
+                    self.best_loss = self.best_loss + hip_var(fres / maxf) / d
+                else:
+                    self.best_loss = self.best_loss + _HipMeanSq.apply(fres) / d
+                m2 = hip_moments((fres / maxf) ** 2)
+                self.best_var += float((m2[2] / (m2[0] - 1.0)) / 2 * mini_batch_size)
             self.best_loss = dp.mean(self.best_loss)
             self.best_var = float(dp.mean(torch.as_tensor(self.best_var, device=dev, dtype=torch.double)))
             integ[0], err[0] = dp.mean(integ[0]), dp.mean(err[0])

@@ -145,9 +145,12 @@ class DataParallel:
 
     Every rank runs `_train_variance_forward_seq` on its OWN minibatches (`batch_size` / `mini_batch_size` are per
     rank; seed the ranks differently), as independent train-mode BatchNorm batches.  Per optimizer step ONE all-reduce
-    carries the flattened parameter gradients (<= 448 KB at C5) together with the bookkeeping scalars (loss, variance,
-    estimator terms); all of them are averaged over the ranks, so the optimizer states, the early-stopping decisions and
-    the saved best model stay identical everywhere.  `max f` of the survey is combined with one all-reduce(MAX).
+    carries the flattened parameter gradients (<= 448 KB at C5), the BatchNorm running statistics (every rank's train-mode
+    forwards advance them from its OWN minibatches; averaging them each step keeps the buffers -- hence `best_model`'s
+    state_dict, checkpoints and the eval-mode `integrate=True` tail -- identical on every rank) and the bookkeeping scalars
+    (loss, variance, estimator terms); all of them are averaged over the ranks, so the optimizer states, the early-stopping
+    decisions and the saved best model stay identical everywhere.  `max f` of the survey is combined with one
+    all-reduce(MAX), and the survey's loss / variance are normalised with that GLOBAL maximum.
 
         rank, ws, _ = parallel.init_from_env()
         NF = PWQuadManager(n_flow=2); NF.create_model(2, 4, [3] * 3)
@@ -186,12 +189,19 @@ class DataParallel:
         if self.world == 1:
             return scalars
         grads = [p.grad for p in model.parameters() if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads] + [scalars.detach().reshape(-1).to(grads[0].dtype)])
+        stats = [b for name, b in model.named_buffers() if b.is_floating_point()]      # running_mean / running_var
+        flat = torch.cat([g.reshape(-1) for g in grads] + [b.detach().reshape(-1).to(grads[0].dtype) for b in stats] +
+                         [scalars.detach().reshape(-1).to(grads[0].dtype)])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat /= self.world
         off = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
+        with torch.no_grad():
+            for g in grads:
+                n = g.numel()
+                g.copy_(flat[off:off + n].view_as(g))
+                off += n
+            for b in stats:
+                n = b.numel()
+                b.copy_(flat[off:off + n].view_as(b))
+                off += n
         return flat[off:].to(scalars.dtype)

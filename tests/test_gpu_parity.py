@@ -1401,3 +1401,50 @@ def test_rambo_with_pdf_grid_vs_oracle(n, cuts, pdgs):
     f = integrands.RamboWeight(gen, E, *cuts, pdgs=pdgs)
     wp = t2n(f.from_planes(planes, list(range(3 * n - 2)), N))
     np.testing.assert_array_equal(wp, w)
+
+
+def test_engines_sharing_cells_see_each_others_running_statistics():
+    """`model[0](x)` runs through the cell's own engine, `model(x)` through the Sequential's: a train-mode forward of one
+    advances the BatchNorm running statistics, and an eval-mode forward of the OTHER must then use them (the epoch that
+    invalidates a packed eval-mode image is kept on the cell, not on the engine)."""
+    from nf_amd.normalizing_flows.manager import PWQuadManager
+    torch.manual_seed(5)
+    NF = PWQuadManager(n_flow=3)
+    NF.create_model(3, 5, [6, 6])
+    model = NF._model
+    x = torch.rand(4000, 4, dtype=torch.double, device=dev())
+    x[:, 3] = 1.0
+    with torch.no_grad():
+        model.eval()
+        y0 = model(x).clone()                                  # packs the Sequential engine's eval-mode image
+        model.train()
+        for _ in range(3):
+            model[0](torch.rand(3000, 4, dtype=torch.double, device=dev()))      # cell engine: running stats of cell 0 move
+        model.eval()
+        y1 = model(x)
+    params = {k: t2n(v) for k, v in model.state_dict().items()}
+    ref = oflow.model_forward(t2n(x[:, :3]), params, oflow.plan_pwquad(3, 3, 5), False)
+    np.testing.assert_allclose(t2n(y1), ref, rtol=RTOL, atol=ATOL)
+    assert float((y1 - y0).abs().max()) > 1e-6                # the statistics did change the eval-mode output
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_launches_follow_the_tensors_device():
+    """The reference selects the GPU by argument (`create_model(dev=)`, `integrate(dev=)`): kernels must run on the device
+    that holds the tensors, whatever the current device is."""
+    from nf_amd import integrands
+    from nf_amd.normalizing_flows.manager import PWQuadManager
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    torch.cuda.set_device(0)
+    torch.manual_seed(2)
+    NF = PWQuadManager(n_flow=2)
+    NF.create_model(2, 4, [3] * 3, dev=1)
+    assert next(NF._model.parameters()).device.index == 1
+    sig, err = NF.integrate(integrands.Camel(), 3, 20000, 1)
+    assert abs(float(sig) - 0.2323) < 0.05
+    gen = FlatInvertiblePhasespace([100.] * 2, [100.] * 4)
+    r = torch.rand(3000, 8, dtype=torch.double, device="cuda:1")
+    mom, wgt = gen.generateKinematics_batch(1000., r)
+    rm, rw = orambo.generate_kinematics([100.] * 2, [100.] * 4, 1000., t2n(r))
+    np.testing.assert_allclose(t2n(wgt), rw, rtol=1e-9)
+    assert torch.cuda.current_device() == 0

@@ -28,9 +28,15 @@ dist.all_gather(gathered, flat)
 params_equal = all(torch.equal(g[:sum(p.numel() for p in NF._model.parameters())],
                                gathered[0][:sum(p.numel() for p in NF._model.parameters())]) for g in gathered)
 hist_equal = all(torch.equal(g[-len(NF.history) - 2:], gathered[0][-len(NF.history) - 2:]) for g in gathered)
-ok = params_equal and hist_equal and bool(torch.isfinite(flat).all())
+# everything, BatchNorm buffers included (running statistics averaged in the per-step all-reduce): model AND best_model
+all_equal = all(torch.equal(g, gathered[0]) for g in gathered)
+best = torch.cat([t.detach().double().reshape(-1) for t in NF.best_model.state_dict().values()])
+gb = [torch.zeros_like(best) for _ in range(ws)]
+dist.all_gather(gb, best)
+best_equal = all(torch.equal(g, gb[0]) for g in gb)
+ok = params_equal and hist_equal and all_equal and best_equal and bool(torch.isfinite(flat).all())
 if rank == 0:
-    print(f"{'DP_OK' if ok else 'DP_FAIL'} world={ws} epochs_run={len(NF.history)} params_equal={params_equal} "
+    print(f"{'DP_OK' if ok else 'DP_FAIL'} world={ws} epochs_run={len(NF.history)} params_equal={params_equal} buffers_equal={all_equal} best_model_equal={best_equal} "
           f"history_equal={hist_equal} result={res} last_loss={float(NF.history[-1]):.6e}", flush=True)
 dist.barrier()
 dist.destroy_process_group()
