@@ -193,6 +193,8 @@ class BasicManager(ModelAPI):
             self.varJ = _HipMeanSq.apply(J.detach())
             dkl = torch.nn.KLDivLoss(reduction="batchmean")
             self.DKL = dkl(torch.log(X.detach() + 1e-45), w.to(dev)).detach()
+            if self.data_parallel is not None:              # the forward above advanced the running statistics rank-locally
+                self.data_parallel.sync_buffers(self.model)
             self.best_model = copy.deepcopy(self.model)
             self.best_epoch = 0
             self.best_time = 0

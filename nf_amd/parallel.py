@@ -184,6 +184,24 @@ class DataParallel:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t / self.world
 
+    def sync_buffers(self, model):
+        """Average the BatchNorm running statistics of `model` over the ranks (one all-reduce): called before a copy of the
+        model is kept (`best_model`), so that what is saved / evaluated later is the same on every rank."""
+        if self.world == 1:
+            return
+        stats = [b for _, b in model.named_buffers() if b.is_floating_point()]
+        if not stats:
+            return
+        flat = torch.cat([b.detach().reshape(-1).double() for b in stats])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat /= self.world
+        off = 0
+        with torch.no_grad():
+            for b in stats:
+                n = b.numel()
+                b.copy_(flat[off:off + n].view_as(b))
+                off += n
+
     def sync_step(self, model, scalars):
         """Average the gradients of `model` (in place) and the 1-d tensor `scalars` over the ranks: one all-reduce."""
         if self.world == 1:
