@@ -233,7 +233,7 @@ def bench_config(name, rank, ws, dev, steps=3):
     NF.create_model(**kw) if kind == "pwlin" else NF.create_model(dev=dev.index, **kw)
     NF.best_model.train()
     f, fdesc = config_integrand(name)
-    NF.moments_batches(f, 1, N, dev)                    # warm-up iteration (code objects, workspaces)
+    NF.moments_batches(f, steps, N, dev)                # warm-up: the same call (code objects, workspaces and scratch planes sized for it)
     barrier_sync(ws)
     t0 = time.perf_counter()
     mom = NF.moments_batches(f, steps, N, dev)

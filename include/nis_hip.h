@@ -163,6 +163,8 @@ int nis_integrate_steps_bins(nis_flow* f, const void* w, int32_t w_dtype, int64_
                              int64_t pack_token, int32_t f_kind, const double* f_params_host,
                              double* planes, int64_t ld, int32_t* bins_out, double* out4,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* 1 when the built-in integrand of nis_integrate_steps is fused into the last cell's kernel for this model. */
+int nis_flow_fusable(const nis_flow* f);
 int nis_integrate_resident(const nis_flow* f, int32_t n_batches, int64_t N, int32_t bn_mode, int32_t f_kind);
 int nis_philox_rows(uint64_t seed, uint64_t stream0, int32_t n_batches, int64_t N, float* out, void* stream);
 

@@ -26,7 +26,7 @@ LIB_PATH = os.environ.get("NIS_LIB") or os.path.join(os.path.dirname(os.path.abs
 
 EXPORTS = ["nis_cell_param_count", "nis_cell_running_count", "nis_flow_create", "nis_flow_destroy",
            "nis_flow_workspace_bytes", "nis_flow_forward", "nis_flow_forward_sync", "nis_integrate_steps", "nis_integrate_steps_rng",
-           "nis_integrate_resident", "nis_philox_rows", "nis_integrate_steps_bins", "nis_flow_backward_supported",
+           "nis_integrate_resident", "nis_philox_rows", "nis_integrate_steps_bins", "nis_flow_fusable", "nis_flow_backward_supported",
            "nis_flow_bnsave_count", "nis_flow_forward_train", "nis_flow_backward_workspace_bytes", "nis_flow_backward", "nis_integrand_moments", "nis_integrand_eval",
            "nis_moments_workspace_bytes",
            "nis_moments", "nis_rambo_forward", "nis_rambo_forward_pdf", "nis_pdf_xfx", "nis_prof_enable", "nis_prof_read", "nis_prof_disable", "nis_last_error", "nis_version", "nis_device_count"]
@@ -87,6 +87,8 @@ def lib():
     L.nis_integrate_steps_bins.restype = i32
     L.nis_integrate_steps_bins.argtypes = [vp, vp, i32, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64, i32,
                                            C.POINTER(C.c_double), vp, i64, vp, vp, vp, sz, vp]
+    L.nis_flow_fusable.restype = i32
+    L.nis_flow_fusable.argtypes = [vp]
     L.nis_integrate_resident.restype = i32
     L.nis_integrate_resident.argtypes = [vp, i32, i64, i32, i32]
     L.nis_philox_rows.restype = i32

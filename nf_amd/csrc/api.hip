@@ -468,7 +468,7 @@ __device__ __forceinline__ void nis_philox4x32_10(unsigned c0, unsigned c1, unsi
 }
 __global__ __launch_bounds__(NIS_TPB) void k_ingest2_rng(unsigned long long seed, unsigned long long stream0,
                                                          const unsigned long long* __restrict__ state, long N, float* __restrict__ rows,
-                                                         long rows_gs, float* __restrict__ w_out, IngestStats st) {
+                                                         long rows_gs, long plane_ld, float* __restrict__ w_out, IngestStats st) {
   typedef float vec4 __attribute__((ext_vector_type(4)));
   constexpr int NW = NIS_TPB / NIS_WAVE, NF = 2;
   __shared__ double wshift[NW][NF];
@@ -494,13 +494,24 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest2_rng(unsigned long long seed
                       (unsigned)(seed >> 32), r);
     const vec4 v = {(float)(r[0] >> 8) * 0x1p-24f, (float)(r[1] >> 8) * 0x1p-24f, (float)(r[2] >> 8) * 0x1p-24f, (float)(r[3] >> 8) * 0x1p-24f};
     const bool two = 2 * c + 1 < N;
-    if (two) {
+    if (plane_ld > 0) {                       // two float32 column planes: samples 2c, 2c+1 of column 0 | of column 1
+      typedef float vec2 __attribute__((ext_vector_type(2)));
+      if (two) {
+        *reinterpret_cast<vec2*>(dst + 2 * c) = vec2{v.x, v.z};
+        *reinterpret_cast<vec2*>(dst + plane_ld + 2 * c) = vec2{v.y, v.w};
+      } else {
+        dst[2 * c] = v.x;
+        dst[plane_ld + 2 * c] = v.y;
+      }
+    } else if (two) {
       *reinterpret_cast<vec4*>(dst + 4 * c) = v;
-      if (w_out) *reinterpret_cast<vec4*>(w_out + (size_t)g * N * 2 + 4 * c) = v;
     } else {
       dst[4 * c] = v.x;
       dst[4 * c + 1] = v.y;
-      if (w_out) w_out[(size_t)g * N * 2 + 4 * c] = v.x, w_out[(size_t)g * N * 2 + 4 * c + 1] = v.y;
+    }
+    if (w_out) {
+      if (two) *reinterpret_cast<vec4*>(w_out + (size_t)g * N * 2 + 4 * c) = v;
+      else w_out[(size_t)g * N * 2 + 4 * c] = v.x, w_out[(size_t)g * N * 2 + 4 * c + 1] = v.y;
     }
     if (st.P > 0) {
       const double a0 = (double)(s0 == 0 ? v.x : v.y), a1 = (double)(s0 == 0 ? v.z : v.w);   // feature 0 of the pair's two samples
@@ -1004,7 +1015,7 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
   {
     NisProfScope ps(NIS_K_APPLY, s);
     if (mfma)
-      HIP_OK(launch_apply_mfma<WM>(c, mw, planes, ld, N, bn_mode == NIS_BN_TRAIN ? 1 : 0, km, bins, grid_mf, s));
+      HIP_OK(launch_apply_mfma<WM>(c, mw, planes, ld, N, bn_mode == NIS_BN_TRAIN ? 1 : 0, km, bins, fz, grid_mf, s));
     else
       HIP_OK(launch_apply<WM>(c, planes, ld, N, bn_mode == NIS_BN_TRAIN ? 1 : 0, km, bins, fz, grid_apply, s));
   }
@@ -1223,9 +1234,13 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   // column, N float64 = N float32 pairs -- and the cells read them from there.
   const float* wrows = (const float*)w;
   long wrows_gs = 2 * (long)N;
+  long wplane_ld = 0;                      // > 0: two float32 column planes instead of rows (K = 4 chains: PLN kernel instantiations)
   if (o.rng) {
     wrows = (const float*)(planes + (size_t)f->cells[0].in_col[0] * ld);
     wrows_gs = 2 * plane_gs;
+    bool k4 = N % 2 == 0 && !env_int("NIS_NO_PLANAR", 0);          // even N: the second plane starts 8-byte aligned
+    for (int ci = 0; ci < f->n_cells; ++ci) k4 = k4 && lay[ci].KM == -4;
+    if (k4) wplane_ld = (long)N;
   }
 
   // ---- one chain of launches for batches [g0, g0 + Gy) on stream cs: ingest -> per cell [statistics ..., apply].
@@ -1242,7 +1257,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     nis_prof_mark(NIS_K_INGEST, 1, cs);
     if (direct && o.rng)
       hipLaunchKernelGGL(k_ingest2_rng, dim3(tgrid, Gy), dim3(NIS_TPB), 0, cs, (unsigned long long)o.seed, (unsigned long long)o.stream0,
-                         (const unsigned long long*)o.rng_state, (long)N, const_cast<float*>(wrows), wrows_gs, o.w_out, is2);
+                         (const unsigned long long*)o.rng_state, (long)N, const_cast<float*>(wrows), wrows_gs, wplane_ld, o.w_out, is2);
     else if (direct)
       hipLaunchKernelGGL((k_ingest2<float, false>), dim3(tgrid, Gy), dim3(NIS_TPB), 0, cs, (const float*)w, (long)N, planes, (long)ld, is2);
     else if (wcols == 2 && is2.P <= 2 && w_dtype == NIS_F64)
@@ -1320,6 +1335,8 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       if (direct) {
         c.wrows = wrows;
         c.wrows_gs = wrows_gs;
+        c.wplanar = wplane_ld > 0 ? 1 : 0;
+        c.wplane_ld = wplane_ld;
         c.x_wcol = col_in_w[cd.in_col[0]] ? cd.in_col[0] : -1;
         c.xb_wcol = col_in_w[cd.in_col[1]] ? cd.in_col[1] : -1;
         col_in_w[cd.in_col[1]] = false;            // an inner cell writes its transformed column to the plane; the last one stores nothing
@@ -1354,7 +1371,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       fz.fres_gs = N;
       const bool last = ci + 1 == f->n_cells;
       bool fused_f = false;
-      if (last && o.f_kind >= 0 && L.WM <= 8) {
+      if (last && o.f_kind >= 0 && (L.WM <= 8 || (mfma && nis_mfma_fusable(cd.kind, L.KM) && !o.fres_out))) {
         fused_f = true;
         fz.kind = o.f_kind;
         fz.loc0 = fz.loc1 = -1;
@@ -1395,7 +1412,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       }
       if (last && o.f_kind >= 0) {
         if (fused_f) {
-          epi_fparts = grid_apply;
+          epi_fparts = mfma ? grid_mf : grid_apply;
           epi_fused = true;
         } else {
           int rc2 = nis_integrand_moments(pl, ld, N, d, f->out_col, o.f_kind, o.f_params, o.fres_out, o.out4, body + off_fpart,
@@ -1556,6 +1573,31 @@ extern "C" int nis_integrate_steps_bins(nis_flow* f, const void* w, int32_t w_dt
   flow_layout(f, 1, &lay, nullptr);
   if (!direct_rows_ok(f, lay, o, w_dtype, f->d, f->cells[0].P) || env_int("NIS_NO_DIRECT_ROWS", 0) || env_int("NIS_MEGA", 0)) return NIS_E_UNSUPPORTED;
   return flow_run(f, w, w_dtype, N, params, running, planes, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
+}
+
+// 1 when nis_integrate_steps can fuse a built-in integrand into the last cell's kernel (narrow conditioners: the fp64 VALU
+// apply kernel's rider; wide ones: the FUSE instantiations of the matrix-core apply kernel)
+extern "C" int nis_flow_fusable(const nis_flow* f) {
+  if (!f) return 0;
+  std::vector<CellLayout> lay;
+  flow_layout(f, 1, &lay, nullptr);
+  const nis_cell_desc& cd = f->cells[f->n_cells - 1];
+  const CellLayout& L = lay[f->n_cells - 1];
+  if (L.WM <= 8) return 1;
+  if (!use_mfma() || !nis_mfma_fusable(cd.kind, L.KM)) return 0;
+  CellK c;
+  memset(&c, 0, sizeof(c));
+  c.kind = cd.kind;
+  c.K = cd.K;
+  c.out = cell_out(cd);
+  bool ok = false;
+  switch (L.WM) {
+    case 16: ok = mfma_supported<16>(c); break;
+    case 32: ok = mfma_supported<32>(c); break;
+    case 64: ok = mfma_supported<64>(c); break;
+    default: break;
+  }
+  return ok ? 1 : 0;
 }
 
 extern "C" int nis_integrate_resident(const nis_flow* f, int32_t n_batches, int64_t N, int32_t bn_mode, int32_t f_kind) {

@@ -377,7 +377,8 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
 #define NIS_STATS_U 4
 #endif
 // ROWS: the pass-through column is column c.x_wcol of the float32 (N, 2) rows of w (CellK::wrows), not a plane.
-template <int WM, int TPB, int WX, int LAYER, bool ROWS = false>
+// PLN (ROWS kernels): w is two float32 column planes (CellK::wplanar) -- one 4-byte load per sample.
+template <int WM, int TPB, int WX, int LAYER, bool ROWS = false, bool PLN = false>
 __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __restrict__ planes, long ld, long N) {
   static_assert(LAYER >= 2 && LAYER <= NIS_MAX_HIDDEN && WX <= WM, "folded statistics start at BN layer 2");
   constexpr int NW = TPB / NIS_WAVE;
@@ -407,8 +408,10 @@ __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __
   typedef float nis_f2 __attribute__((ext_vector_type(2)));
   const nis_f2* wr = ROWS ? reinterpret_cast<const nis_f2*>(c.wrows + (size_t)g * c.wrows_gs) : nullptr;
   const bool wcol1 = ROWS && c.x_wcol == 1;
+  const float* const wpl = (ROWS && PLN) ? c.wrows + (size_t)g * c.wrows_gs + (size_t)c.x_wcol * c.wplane_ld : nullptr;
   auto sample = [&](long tile0, int l) -> double {                // tile0 wave-uniform, l = lane
     if (!ROWS) return (px + tile0)[l];
+    if (PLN) return (double)(wpl + tile0)[l];
     const nis_f2 r = (wr + tile0)[l];                             // the whole 8-byte row: same request shape as a plane load
     return (double)(wcol1 ? r.y : r.x);
   };
@@ -710,7 +713,9 @@ __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const do
 // FIRST (ROWS kernels): the flow's first cell -- both inputs come from the row, the incoming Jacobian is 1: ONE load per sample.
 // BINS (SPEC kernels, test instantiation): the selected bin indices are written to bins_out although the production SPEC
 // kernels never output them -- tests assert them bit-exact against the oracle on the very code path the bench runs.
-template <int KIND, int WM, int KM, bool KEXACT, int WX = WM, int SPEC = 0, bool ROWS = false, bool FIRST = false, bool BINS = false>
+// PLN (ROWS kernels): w is two float32 column planes (CellK::wplanar): the first cell takes one float from each, a later cell one
+// float of its transformed column.
+template <int KIND, int WM, int KM, bool KEXACT, int WX = WM, int SPEC = 0, bool ROWS = false, bool FIRST = false, bool BINS = false, bool PLN = false>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                         int* __restrict__ bins_out, FuseF fz) {
   static_assert(!ROWS || SPEC != 0, "row input exists on the SPEC kernels only");
@@ -736,7 +741,14 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   static_assert(!FIRST || ROWS, "FIRST is a property of the row-input kernels");
   const nis_f2* const rows = ROWS ? reinterpret_cast<const nis_f2*>(c.wrows + (size_t)g * c.wrows_gs) : nullptr;
   constexpr bool xrow = ROWS && FIRST;                             // pass-through input from the row as well
-  const bool rswap = ROWS && (FIRST ? c.x_wcol == 1 : c.xb_wcol == 0);   // FIRST: (x, xb) = (r.y, r.x);  later cells: xb = r.x
+  const bool rswap = ROWS && !PLN && (FIRST ? c.x_wcol == 1 : c.xb_wcol == 0);   // FIRST: (x, xb) = (r.y, r.x);  later cells: xb = r.x
+  // PLN: rq is assembled as (pass-through, transformed) from the two float planes, no swap
+  const float* const wpx = (ROWS && PLN && FIRST) ? c.wrows + (size_t)g * c.wrows_gs + (size_t)c.x_wcol * c.wplane_ld : nullptr;
+  const float* const wpb = (ROWS && PLN) ? c.wrows + (size_t)g * c.wrows_gs + (size_t)c.xb_wcol * c.wplane_ld : nullptr;
+  auto row_at = [&](long i) -> nis_f2 {
+    if (!PLN) return rows[i];
+    return nis_f2{FIRST ? wpx[i] : 0.f, wpb[i]};
+  };
   const double* const P0 = planes + (size_t)c.in_plane[0] * ld;
   double* const P1 = planes + (size_t)c.in_plane[SP ? 1 : 0] * ld;
   // plane kernels: a first cell has no Jacobian plane to read -- it re-reads x (same line, L1 hit) so that the loop's
@@ -748,7 +760,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   auto first_loads = [&]() {
     if (SP && i_first < N) {
       if (!xrow) xq = P0[i_first];
-      if (ROWS) rq = rows[i_first];
+      if (ROWS) rq = row_at(i_first);
       else xbq = P1[i_first];
       if (!FIRST) jq = jsrc[i_first];
     }
@@ -806,7 +818,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
     if (SP) {
       const long ic = i + stride < N ? i + stride : i;              // last round: re-read the current sample (unused)
       if (!xrow) xq = P0[ic];
-      if (ROWS) rq = rows[ic];
+      if (ROWS) rq = row_at(ic);
       else xbq = P1[ic];
       if (!FIRST) jq = jsrc[ic];
 #pragma unroll
@@ -988,8 +1000,10 @@ int mfma_blocks_per_cu(const CellK& c);
 template <int WM>
 hipError_t launch_stats_mfma(const CellK& c, const MfmaW& w, const double* planes, long ld, long N, int layer, int grid, hipStream_t s);
 template <int WM>
-hipError_t launch_apply_mfma(const CellK& c, const MfmaW& w, double* planes, long ld, long N, int bn_train, int km, int* bins, int grid,
-                             hipStream_t s);
+hipError_t launch_apply_mfma(const CellK& c, const MfmaW& w, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz,
+                             int grid, hipStream_t s);
+// true when launch_apply_mfma has a fused-integrand instantiation for this cell (PWLin, AffineCoupling, PWQuad with K == KM)
+static inline bool nis_mfma_fusable(int kind, int km) { return kind != NIS_PWQUAD || km < 0; }
 #define NIS_DECL_WM(W)                                                                                                      \
   template <>                                                                                                               \
   int stats_blocks_per_cu<W>(int wx, bool folded);                                                                                          \
@@ -1011,7 +1025,7 @@ hipError_t launch_apply_mfma(const CellK& c, const MfmaW& w, double* planes, lon
                                   hipStream_t s);                                                                           \
   template <>                                                                                                               \
   hipError_t launch_apply_mfma<W>(const CellK& c, const MfmaW& w, double* planes, long ld, long N, int bn_train, int km, int* bins, \
-                                  int grid, hipStream_t s);
+                                  const FuseF& fz, int grid, hipStream_t s);
 NIS_DECL_WM(4)
 NIS_DECL_WM(8)
 NIS_DECL_WM(16)

@@ -192,16 +192,22 @@ __global__ __launch_bounds__(NIS_MF_TPB) void k_bn_stats_mfma(CellK c, const dou
 
 // ---------------------------------------------------------------------------------------------
 // Full cell with the conditioner on the matrix cores.
-template <int KIND, int WM, int KM, bool KEXACT>
+// FUSE (last cell of an integrate step): a built-in integrand f(X) * J and its moment records are produced here -- the four
+// lanes that share a sample each hold the contributions of their columns (transformed: the y they just computed;
+// pass-through: column p of lane group p % 4) and combine them with two shuffles, like the Jacobian product -- and with
+// fz.write_planes == 0 neither the transformed columns nor the Jacobian are stored (nothing reads them).
+template <int KIND, int WM, int KM, bool KEXACT, bool FUSE = false>
 __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfma(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                                 int* __restrict__ bins_out, const double* __restrict__ wm_all,
-                                                                const double* __restrict__ wm_last, const double* __restrict__ bias_pad) {
+                                                                const double* __restrict__ wm_last, const double* __restrict__ bias_pad,
+                                                                FuseF fz) {
   constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ, NW = NIS_MF_TPB / 64, NCB = NIS_MF_NCB;
   extern __shared__ double mf_dyn[];                 // per wave: [NCB*out rows][16 samples]
   __shared__ double lds_coef[(NIS_MAX_HIDDEN + 1) * 2 * WM];
   __shared__ double red[3 * NIS_MF_TPB];
   __shared__ int lds_plane[NIS_MAX_DIM];
   __shared__ double etab[64];
+  __shared__ double fmom[NW][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
   const int g = c.g0 + blockIdx.y;
   planes += (size_t)g * c.plane_gs;
@@ -209,6 +215,12 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
   nis_exp_init(etab);
   load_coefs<WM, NIS_MF_TPB>(c, g, c.L + 1, (bn_train && c.pmerge) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red);
   const int out = c.out;
+  const bool wplanes = FUSE ? fz.write_planes != 0 : true;
+  double fS1 = 0.0, fS2 = 0.0, fcnt = 0.0, fmx = -__builtin_huge_val(), fshift = 0.0;
+  bool ffirst = true;
+  // normal(): exp(-sum (x - mu)^2 / (2 sigma^2)) / (sigma sqrt((2 pi)^d)); the constants once per launch, not per sample
+  const double f_i2s = FUSE ? 1.0 / (2 * fz.p[1] * fz.p[1]) : 0.0;
+  const double f_norm = (FUSE && fz.kind == NIS_F_NORMAL) ? 1.0 / (fz.p[1] * sqrt(pow(2 * M_PI, (double)c.d))) : 1.0;
   double* ring = mf_dyn + (size_t)wave * NCB * out * 16;
   const long wstride = (long)gridDim.x * NW * 16 * ST;
   for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
@@ -231,6 +243,18 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
 #pragma unroll 1
     for (int st = 0; st < ST; ++st) {
       double jprod = 1.0;                            // this lane's columns (t = NCB*cb + gq) of sample s
+      double facc = 0.0, fc0 = 0.0, fc1 = 0.0;       // FUSE: this lane's share of the integrand's argument
+      if (FUSE) {
+        const long ip = base + 16 * st + s;
+        for (int p = gq; p < c.P; p += 4) {          // pass-through columns, spread over the four lanes of the sample
+          const double xp = ip < N ? planes[(size_t)lds_plane[p] * ld + ip] : 0.0;
+          if (fz.kind == NIS_F_NORMAL) facc = fma((xp - fz.p[0]) * (xp - fz.p[0]), f_i2s, facc);
+          if (fz.kind == NIS_F_CAMEL) {
+            fc0 = (p == fz.loc0) ? xp : fc0;
+            fc1 = (p == fz.loc1) ? xp : fc1;
+          }
+        }
+      }
       double Hs[KQ];                                 // B operands of this sample tile (st is a runtime index: select once)
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
@@ -316,8 +340,15 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
             y = qn * alpha + below / tot;
             jf = qn;
           }
-          col[c.out_off + i] = y;
+          if (wplanes) col[c.out_off + i] = y;
           jprod *= jf;
+          if (FUSE) {
+            if (fz.kind == NIS_F_NORMAL) facc = fma((y - fz.p[0]) * (y - fz.p[0]), f_i2s, facc);
+            if (fz.kind == NIS_F_CAMEL) {
+              fc0 = (c.P + t == fz.loc0) ? y : fc0;
+              fc1 = (c.P + t == fz.loc1) ? y : fc1;
+            }
+          }
           if (KIND != NIS_AFFINE && bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
         }
         __builtin_amdgcn_wave_barrier();
@@ -327,10 +358,41 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
       jprod *= __shfl_xor(jprod, 32, 64);
       if (KIND == NIS_AFFINE) jprod *= 1.0 / (M_PI / 2);       // the reference applies 2/pi ONCE per cell (:68)
       const long i = base + 16 * st + s;
+      double jout = 1.0;
       if (gq == 0 && i < N) {
         double* jp = planes + (size_t)c.jplane * ld;
-        jp[c.out_off + i] = (c.first ? 1.0 : jp[i]) * jprod;
+        jout = (c.first ? 1.0 : jp[i]) * jprod;
+        if (wplanes) jp[c.out_off + i] = jout;
+      }
+      if (FUSE) {
+        facc += __shfl_xor(facc, 16, 64);            // every column belongs to exactly one of the four lanes: sums of
+        facc += __shfl_xor(facc, 32, 64);            // (value or 0) reassemble the sample's argument in all four
+        fc0 += __shfl_xor(fc0, 16, 64);
+        fc0 += __shfl_xor(fc0, 32, 64);
+        fc1 += __shfl_xor(fc1, 16, 64);
+        fc1 += __shfl_xor(fc1, 32, 64);
+        double fv = 1.0;
+        if (fz.kind == NIS_F_NORMAL) {                                                    // manager.py:39-40
+          fv = nis_exp(-facc, etab) * f_norm;
+        } else if (fz.kind == NIS_F_CAMEL) {                                              // README.md:35-36
+          const double is2 = fz.p[3];
+          const double e1 = -((fc0 - fz.p[0]) * (fc0 - fz.p[0]) + (fc1 - fz.p[0]) * (fc1 - fz.p[0])) * is2;
+          const double e2 = -((fc0 - fz.p[1]) * (fc0 - fz.p[1]) + (fc1 - fz.p[1]) * (fc1 - fz.p[1])) * is2;
+          fv = nis_exp(e1, etab) + nis_exp(e2, etab);
+        }
+        const double v = fv * jout;
+        const bool mine = gq == 0 && i < N;          // one lane per sample contributes
+        if (ffirst) {
+          fshift = __shfl(v, 0, 64);                 // lane 0 = (group 0, sample 0) of the wave's first tile: always a valid sample
+          ffirst = false;
+        }
+        const double tt = mine ? v - fshift : 0.0;
+        fS1 += tt;
+        fS2 = fma(tt, tt, fS2);
+        fmx = mine ? fmax(fmx, v) : fmx;
+        fcnt += mine ? 1.0 : 0.0;
       }
     }
   }
+  if (FUSE) block_record<NW>(fshift, fS1, fS2, fcnt, fmx, fmom, fz.partials + ((size_t)g * fz.maxb + blockIdx.x) * 4);
 }

@@ -18,7 +18,13 @@ hipError_t launch_stats<NIS_WM>(const CellK& c, const double* planes, long ld, l
     static const bool hoisted = getenv("NIS_NO_STATS_FOLD") == nullptr;
     const bool rows = c.wrows && c.x_wcol >= 0;        // pass-through column still lives in the float32 rows of w
     if (rows && !(c.P == 1 && c.fold && hoisted && layer >= 2 && layer <= 5)) return hipErrorInvalidValue;
-    if (rows) {
+    if (rows && c.wplanar) {
+      switch (layer) {
+        case 2: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 2, true, true>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N); break;
+        case 3: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 3, true, true>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N); break;
+        default: return hipErrorInvalidValue;       // planar draws exist for the three-hidden-layer SPEC chain
+      }
+    } else if (rows) {
       switch (layer) {
         case 2: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 2, true>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N); break;
         case 3: hipLaunchKernelGGL((k_bn_stats_fold<NIS_WM, TPB, 3, 3, true>), dim3(grid, c.Gy), dim3(TPB), 0, s, c, planes, ld, N); break;
@@ -157,7 +163,15 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
   hipLaunchKernelGGL((k_cell_apply<KIND, NIS_WM, KMV, EX, 3>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
 #define NIS_APPLY3S(KMV, SP)                                                                                                       \
   do {                                                                                                                             \
-    if (bins && rows && KMV == 4 && c.first)          /* test instantiation: SPEC kernels that also write the bin indices */        \
+    if (rows && c.wplanar && !bins && KMV == 4 && c.first)   /* in-kernel draws: float32 column planes */                           \
+      hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, 4, true, 3, SP, true, true, false, true>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, \
+                         c, planes, ld, N, bn_train, bins, fz);                                                                    \
+    else if (rows && c.wplanar && !bins && KMV == 4)                                                                               \
+      hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, 4, true, 3, SP, true, false, false, true>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, \
+                         c, planes, ld, N, bn_train, bins, fz);                                                                    \
+    else if (rows && c.wplanar)                                                                                                    \
+      return hipErrorInvalidValue;                                                                                                 \
+    else if (bins && rows && KMV == 4 && c.first)     /* test instantiation: SPEC kernels that also write the bin indices */        \
       hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, 4, true, 3, SP, true, true, true>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c, \
                          planes, ld, N, bn_train, bins, fz);                                                                       \
     else if (bins && rows && KMV == 4)                                                                                             \
@@ -268,11 +282,31 @@ hipError_t launch_stats_mfma<NIS_WM>(const CellK& c, const MfmaW& w, const doubl
 
 #define NIS_APPLY_MF(KIND, KMV, EX)                                                                                               \
   hipLaunchKernelGGL((k_cell_apply_mfma<KIND, NIS_WM, KMV, EX>), dim3(grid, c.Gy), dim3(NIS_MF_TPB), mf_ring_bytes(c), s, c, planes, ld, \
-                     N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad)
+                     N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad, fz)
+#define NIS_APPLY_MFF(KIND, KMV)                                                                                                  \
+  hipLaunchKernelGGL((k_cell_apply_mfma<KIND, NIS_WM, KMV, true, true>), dim3(grid, c.Gy), dim3(NIS_MF_TPB), mf_ring_bytes(c), s, c, planes, \
+                     ld, N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad, fz)
 
 template <>
 hipError_t launch_apply_mfma<NIS_WM>(const CellK& c, const MfmaW& w, double* planes, long ld, long N, int bn_train, int km, int* bins,
-                                     int grid, hipStream_t s) {
+                                     const FuseF& fz, int grid, hipStream_t s) {
+  if (fz.kind >= 0) {                      // last cell of an integrate step: integrand * J + moment records fused (FUSE instantiations)
+    if (!nis_mfma_fusable(c.kind, km) || bins || fz.fres) return hipErrorInvalidValue;
+    if (c.kind == NIS_PWLIN) {
+      NIS_APPLY_MFF(NIS_PWLIN, 4);
+    } else if (c.kind == NIS_AFFINE) {
+      NIS_APPLY_MFF(NIS_AFFINE, 4);
+    } else {
+      switch (km) {
+        case -4: NIS_APPLY_MFF(NIS_PWQUAD, 4); break;
+        case -8: NIS_APPLY_MFF(NIS_PWQUAD, 8); break;
+        case -16: NIS_APPLY_MFF(NIS_PWQUAD, 16); break;
+        case -32: NIS_APPLY_MFF(NIS_PWQUAD, 32); break;
+        default: return hipErrorInvalidValue;
+      }
+    }
+    return hipGetLastError();
+  }
   if (c.kind == NIS_PWLIN) {
     NIS_APPLY_MF(NIS_PWLIN, 4, false);
   } else if (c.kind == NIS_AFFINE) {
@@ -302,7 +336,7 @@ hipError_t launch_stats_mfma<NIS_WM>(const CellK&, const MfmaW&, const double*, 
   return hipErrorInvalidValue;
 }
 template <>
-hipError_t launch_apply_mfma<NIS_WM>(const CellK&, const MfmaW&, double*, long, long, int, int, int*, int, hipStream_t) {
+hipError_t launch_apply_mfma<NIS_WM>(const CellK&, const MfmaW&, double*, long, long, int, int, int*, const FuseF&, int, hipStream_t) {
   return hipErrorInvalidValue;
 }
 #endif

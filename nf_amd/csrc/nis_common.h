@@ -175,6 +175,8 @@ struct CellK {
   const float* wrows;                    // null: every column lives in its plane
   long wrows_gs;                         // floats between the row blocks of consecutive g: 2 N
   int x_wcol, xb_wcol;                   // column of w that holds the pass-through / the transformed input, -1: read the plane
+  int wplanar;                           // 1 (in-kernel draws): w is two float32 column planes (column c at wrows + c * wplane_ld), not rows:
+  long wplane_ld;                        //   a pass reads only the column it needs (4 instead of 8 B/sample)
   // ---- training history (for the adjoint kernels): outputs go to the NEXT plane set, BN statistics are kept
   int derive1;                           // 1 (P == 1): BN_1's batch statistics follow analytically from BN_0's
                                          //   (h1_j = W0_j0 * BN_0(x) is affine in the single pass-through column),

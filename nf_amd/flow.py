@@ -122,9 +122,9 @@ class FlowEngine:
         self._token = 0
 
     def fusable(self):
-        """The built-in-integrand rider lives in the narrow (register width <= 8) apply kernels."""
-        last = self.cells[-1]
-        return max([last.pass_through_size] + list(last.hidden_widths)) <= 8
+        """True when a built-in integrand rides in the last cell's kernel: the narrow (register width <= 8) fp64 VALU apply
+        kernels, and the FUSE instantiations of the matrix-core apply kernel for wide conditioners."""
+        return bool(self.L.nis_flow_fusable(self.handle))
 
     # ---- per-call plumbing
     def _pointers(self, dev):

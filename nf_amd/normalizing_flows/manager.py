@@ -418,7 +418,10 @@ class BasicManager(ModelAPI):
                 elif in_kernel:
                     eng.integrate_steps_rng(g, neval, dev, f.nis_kind, f.nis_params, out[i:i + g], seed, i)
                 else:
-                    w = torch.stack([self._uniform(neval, dev, torch.float32, "integrate") for _ in range(g)])
+                    if self.sample_hook is None:        # g batches in one generator launch instead of g launches + a stack copy
+                        w = torch.rand(g, neval, self.n_flow, dtype=torch.float32, device=dev)
+                    else:
+                        w = torch.stack([self._uniform(neval, dev, torch.float32, "integrate") for _ in range(g)])
                     eng.integrate_steps(w, model.training, f.nis_kind, f.nis_params, out[i:i + g])
                 i += g
             return out

@@ -1253,7 +1253,8 @@ def test_c2_full_batch_values_and_bins_vs_oracle():
     np.testing.assert_array_equal(t2n(out[0]), rec)
 
 
-def test_in_kernel_draws_match_documented_mapping_and_oracle():
+@pytest.mark.parametrize("N", [20001, 20002])          # odd: float32 rows; even: two float32 column planes (PLN kernel instantiations)
+def test_in_kernel_draws_match_documented_mapping_and_oracle(N):
     """nis_integrate_steps_rng: the draws are exactly Philox4x32-10 in the documented mapping (NumPy restatement with the
     Random123 known-answer vector), and the records equal the oracle's on those draws."""
     from nf_amd import integrands
@@ -1272,7 +1273,7 @@ def test_in_kernel_draws_match_documented_mapping_and_oracle():
 
     kat = philox([0, 0, 0, 0], [0, 0])
     assert [int(x) for x in kat] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]      # Random123 kat_vectors, philox4x32 10
-    G, N, seed, s0 = 3, 20001, 0x1234567890ABCDEF, 5
+    G, seed, s0 = 3, 0x1234567890ABCDEF, 5
     rows = t2n(philox_rows(seed, s0, G, N, 2, dev()))
     for g in range(G):
         c = np.arange((N + 1) // 2, dtype=np.uint64)
@@ -1448,3 +1449,44 @@ def test_launches_follow_the_tensors_device():
     rm, rw = orambo.generate_kinematics([100.] * 2, [100.] * 4, 1000., t2n(r))
     np.testing.assert_allclose(t2n(wgt), rw, rtol=1e-9)
     assert torch.cuda.current_device() == 0
+
+
+@pytest.mark.parametrize("kind,c,fname", [("pwlin", dict(d=8, P=4, n_cells=4, K=64, NN=[32, 32, 32], roll=4), "normal"),
+                                          ("pwquad", dict(d=10, n_cells=5, K=16, NN=[32, 32, 32]), "normal"),
+                                          ("pwquad", dict(d=4, n_cells=4, K=8, NN=[16, 16]), "camel"),
+                                          ("pwquad", dict(d=16, n_cells=8, K=16, NN=[32, 32, 32]), "one")])
+def test_fused_integrand_rider_on_the_matrix_core_kernels(kind, c, fname):
+    """integrate()'s loop body for wide conditioners: the built-in integrand * J and its moment records come out of the last
+    cell's matrix-core kernel (no X / J planes written) and equal what the unfused route gives from the materialised XJ
+    (oracle integrand on the HIP forward's output), for G = 1 and for batched iterations."""
+    from nf_amd import integrands
+    torch.manual_seed(c["d"] + c["K"])
+    NF = build_manager(dict(kind=kind, **c))
+    model = NF._model.train()
+    eng = model.engine()
+    assert eng.fusable()
+    d = c["d"]
+    f = {"normal": integrands.Normal(0.5, 0.3, d), "camel": integrands.Camel(), "one": integrands.One()}[fname]
+    G, N = 3, 20011
+    w = torch.rand(G, N, d, dtype=torch.float32, device=dev())
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    out = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    eng.integrate_steps(w, True, f.nis_kind, f.nis_params, out)
+    sd_fused = {k: t2n(v) for k, v in model.state_dict().items()}
+    for g in range(G):
+        model.load_state_dict(sd0) if g == 0 else None
+        XJ = t2n(model.flow_forward(w[g], want_xj=True)["xj"])
+        X, J = XJ[:, :-1], XJ[:, -1]
+        fx = {"normal": lambda: oflow.normal(X, 0.5, 0.3, d), "camel": lambda: oflow.camel(X), "one": lambda: np.ones(N)}[fname]()
+        n, mean, var, mx = oflow.moments(fx * J)
+        rec = t2n(out[g])
+        assert rec[0] == n
+        np.testing.assert_allclose(rec[1], mean, rtol=1e-11)
+        np.testing.assert_allclose(rec[2] / (n - 1), var, rtol=1e-9)
+        np.testing.assert_allclose(rec[3], mx, rtol=1e-10)
+    for k, v in model.state_dict().items():                     # the G fused iterations advanced the running statistics like G forwards
+        np.testing.assert_allclose(sd_fused[k], t2n(v), rtol=1e-9, atol=1e-14, err_msg=k)
+    one = torch.zeros((1, 4), dtype=torch.double, device=dev())
+    model.load_state_dict(sd0)
+    eng.integrate_steps(w[0], True, f.nis_kind, f.nis_params, one)
+    np.testing.assert_allclose(t2n(one[0]), t2n(out[0]), rtol=1e-12)
