@@ -91,7 +91,7 @@ __device__ __forceinline__ void bw_forward(const BwdK& k, long i, int upto, doub
 // ---------------------------------------------------------------------------------------------
 template <int KIND, int WM, int KM>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
-  __shared__ double etab[64];
+  __shared__ double etab[NIS_EXP_N];
   nis_exp_init(etab);
   __syncthreads();
   const CellK& c = k.c;

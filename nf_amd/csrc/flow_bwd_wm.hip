@@ -175,7 +175,7 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
   extern __shared__ double mf_dyn[];                 // per wave: [NCB*out rows][16 samples] of exp(Z)
   __shared__ double lds_bn[BNLDS];
   __shared__ int lds_plane[NIS_MAX_DIM];
-  __shared__ double etab[64];
+  __shared__ double etab[NIS_EXP_N];
   __shared__ double sm[NW][SREC];
   const CellK& c = k.c;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;

@@ -715,8 +715,11 @@ __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const do
 // kernels never output them -- tests assert them bit-exact against the oracle on the very code path the bench runs.
 // PLN (ROWS kernels): w is two float32 column planes (CellK::wplanar): the first cell takes one float from each, a later cell one
 // float of its transformed column.
+#ifndef NIS_SPEC_WAVES
+#define NIS_SPEC_WAVES 1      // 4 = allocate the K = 4 SPEC kernels for four waves per SIMD (<= 128 VGPRs): measured 1 % SLOWER than the 129-VGPR / three-wave last cell
+#endif
 template <int KIND, int WM, int KM, bool KEXACT, int WX = WM, int SPEC = 0, bool ROWS = false, bool FIRST = false, bool BINS = false, bool PLN = false>
-__global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
+__global__ __launch_bounds__(NIS_TPB, (SPEC != 0 && KM <= 4) ? NIS_SPEC_WAVES : 1) void k_cell_apply(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                         int* __restrict__ bins_out, FuseF fz) {
   static_assert(!ROWS || SPEC != 0, "row input exists on the SPEC kernels only");
   typedef float nis_f2 __attribute__((ext_vector_type(2)));
@@ -728,7 +731,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_apply(CellK c, double* __restr
   __shared__ double wshift[NW][NF];
   __shared__ double wmom[NW][NF][3];
   __shared__ double fmom[NW][4];
-  __shared__ double etab[64];
+  __shared__ double etab[NIS_EXP_N];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = c.g0 + blockIdx.y;
   planes += (size_t)g * c.plane_gs;

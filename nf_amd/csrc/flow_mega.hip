@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#define NIS_EXP_BITS 6          // the phases below inline the 64-entry / degree-5 exp (LDS budget of the resident batch)
 #include "flow_kernels.h"
 #include "flow_mega.h"
 

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
   __shared__ double lds_coef[(NIS_MAX_HIDDEN + 1) * 2 * WM];
   __shared__ double red[3 * NIS_MF_TPB];
   __shared__ int lds_plane[NIS_MAX_DIM];
-  __shared__ double etab[64];
+  __shared__ double etab[NIS_EXP_N];
   __shared__ double fmom[NW][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
   const int g = c.g0 + blockIdx.y;

@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 
+#if !defined(NIS_EXP_BITS) && defined(NIS_WM) && NIS_WM <= 8
+#define NIS_EXP_BITS 10         // narrow conditioners: VALU-issue bound, LDS to spare -> 1024-entry exp table + cubic (nis_common.h)
+#endif
 #include "flow_kernels.h"
 
 #ifndef NIS_WM

@@ -67,6 +67,31 @@ static __device__ const double NIS_EXP_TAB[64] = {
     0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
     0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
     0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+#ifndef NIS_EXP_BITS
+#define NIS_EXP_BITS 6      // flow_wm.hip selects 10 for the narrow (VALU) units: +2.5 % on the C2 step; the matrix-core kernels lose a workgroup per CU to the 8 KB table
+#endif
+#define NIS_EXP_N (1 << NIS_EXP_BITS)
+#if NIS_EXP_BITS == 10
+// 1024-entry table (8 KB of LDS, tools/gen_exp_table.py): |r| <= ln2/2048 = 3.4e-4, where a CUBIC is enough -- its quadratic
+// coefficient absorbs the r^4/24 term (best b r^2 fit, residual 1e-16) -- two FMAs fewer per exp than the 64-entry / degree-5
+// form; max error 3.1e-16 relative (1.4 ulp; 2.0e7 random arguments in [-700, 700] against expl).
+#include "nis_exp_tab10.h"
+__device__ __forceinline__ void nis_exp_init(double* lds_tab) {
+  for (int i = threadIdx.x; i < NIS_EXP_N; i += blockDim.x) lds_tab[i] = NIS_EXP_TAB10[i];
+}
+__device__ __forceinline__ double nis_exp(double x, const double* lds_tab) {
+  const double kd = fma(x, 0x1.71547652b82fep+10, 0x1.8p+52);     // k = rint(1024 x / ln 2) in the low word (see below)
+  const double k = kd - 0x1.8p+52;
+  double r = fma(k, -0x1.62e42fef00000p-11, x);
+  r = fma(k, -0x1.473de6af278edp-44, r);
+  const int ki = __double2loint(kd);
+  const double T = lds_tab[ki & 1023];
+  double p = fma(r, 1.0 / 6.0, NIS_EXP10_C2);
+  p = fma(r, p, 1.0);
+  p = r * p;
+  return ldexp(fma(T, p, T), ki >> 10);
+}
+#else
 __device__ __forceinline__ void nis_exp_init(double* lds_tab) {
   if (threadIdx.x < 64) lds_tab[threadIdx.x] = NIS_EXP_TAB[threadIdx.x];
 }
@@ -87,6 +112,8 @@ __device__ __forceinline__ double nis_exp(double x, const double* lds_tab) {
   p = r * p;
   return ldexp(fma(T, p, T), ki >> 6);
 }
+
+#endif
 
 // 1 / x and 1 / sqrt(x) for x in the normal range: v_rcp_f64 / v_rsq_f64 (~26 bits) + two Newton steps, no scaling / fix-up
 // sequence (5 / 8 instructions instead of the ~14 of an IEEE division, ~26 of sqrt + division; results within 1-2 ulp).
