@@ -536,6 +536,18 @@ __device__ __forceinline__ double nis_uniform(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// The opposite: pin a (uniform) double into a VGPR pair.  The K = 4 SPEC kernels hold 21 differenced last-layer weights; as scalars
+// they overflow the SGPR file and the compiler parks 16 of them in VGPR lanes, restoring them with 32 v_readlane (+ hazard nops)
+// per sample -- 8 % of the loop's vector instructions.  As vector operands they cost registers (three waves per SIMD instead of
+// four, measured neutral) and no instructions.
+__device__ __forceinline__ double nis_vector(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+#ifndef NIS_WD_VROWS
+#define NIS_WD_VROWS 7        // of the 7 live differenced rows, how many live in VGPRs (7: no SGPR spill left in the loop)
+#endif
+
 // torch.lerp(start, end, weight) as the CPU kernel evaluates it (used at coupling_cells.py:224)
 __device__ __forceinline__ double lerp_torch(double a, double b, double w) {
   const double d = b - a;
@@ -797,7 +809,10 @@ __global__ __launch_bounds__(NIS_TPB, (SPEC != 0 && KM <= 4) ? NIS_SPEC_WAVES : 
       const int ref = r <= KM ? KM : 2 * KM;
       bd[r] = bias[r] - bias[ref];                       // stays in a VGPR: start value of the FMA chain (an SGPR addend would need a v_mov)
 #pragma unroll
-      for (int i = 0; i < WX; ++i) wd[r][i] = nis_uniform(wl[r * WM + i] - wl[ref * WM + i]);
+      for (int i = 0; i < WX; ++i) {
+        const double v = wl[r * WM + i] - wl[ref * WM + i];
+        wd[r][i] = (r - (r > KM ? 1 : 0)) < NIS_WD_VROWS ? nis_vector(v) : nis_uniform(v);     // rows KM and 2 KM are the references (never used)
+      }
     }
   }
   auto rel_exp = [&](int r, const double (&av)[WM]) -> double {

@@ -49,7 +49,7 @@ __device__ __forceinline__ double rb_ipow(double x, int e) {
 // leading-order root) and left of it in the concave part.  8 steps reach the fixed point of the double evaluation
 // (<= few ulp from the lattice bisection's limit; identical conditioning: both stall where g' ~ 0 at v -> 1).
 __device__ __forceinline__ double rb_solve(double v, int e) {
-  if (e == 1) return v / (1.0 + nis_sqrt(1.0 - v));                  // 2u - u^2 = v
+  if (e == 1) return v * nis_rcp(1.0 + nis_sqrt(1.0 - v));            // 2u - u^2 = v
   const double ui = (double)(e - 1) / (double)e;
   const double vi = rb_ipow(ui, e) * ((double)(e + 1) - (double)e * ui);
   const bool convex = v < vi;
@@ -83,6 +83,30 @@ __device__ __forceinline__ double rb_solve(double v, int e) {
 struct V4 {
   double e, x, y, z;
 };
+
+// cos(pi x) for the azimuth (x = 2 r, r uniform in [0, 1)): k = rint(x), g = x - k in [-1/2, 1/2] (exact), and with
+// h = 1/2 - |g| (exact) cos(pi g) = sin(pi h): ONE odd series on [0, 1/2] that keeps full relative accuracy at the zeros of the
+// cosine (h -> 0) -- ~20 instructions against ~50 of the library's cospi (quadrant reduction, both polynomials, select).
+// Coefficients (-1)^n pi^(2n+1) / (2n+1)!, n = 0..10, rounded from 80-digit values; truncation 1.3e-18, measured <= 3.4e-16 relative.
+__device__ __forceinline__ double rb_cospi(double x) {
+  const double k = rint(x);
+  const double h = 0.5 - fabs(x - k);
+  const double z = h * h;
+  double p = 0x1.2877020d52cf0p-31;
+  p = fma(p, z, -0x1.8a404211f9547p-26);
+  p = fma(p, z, 0x1.aaec32af93359p-21);
+  p = fma(p, z, -0x1.6fadb9f155744p-16);
+  p = fma(p, z, 0x1.e8f434d018d63p-12);
+  p = fma(p, z, -0x1.e3074fde8871fp-8);
+  p = fma(p, z, 0x1.50783487ee782p-4);
+  p = fma(p, z, -0x1.32d2cce62bd86p-1);
+  p = fma(p, z, 0x1.466bc6775aae2p+1);
+  p = fma(p, z, -0x1.4abbce625be53p+2);
+  p = fma(p, z, 0x1.921fb54442d18p+1);
+  const double c = h * p;
+  const int odd = (int)k << 31;                                   // cos(pi (g + k)) = (-1)^k cos(pi g)
+  return __hiloint2double(__double2hiint(c) ^ odd, __double2loint(c));
+}
 
 __device__ __forceinline__ void rb_set_square(V4& p, double sq) { p.e = nis_sqrt((p.x * p.x + p.y * p.y + p.z * p.z) + sq); }   // utils.py:5-19
 
@@ -282,15 +306,24 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
       Kk[c] = M[c];
       M[c] += k.msum[c];                                                            // :391-392
     }
-    w_ps *= 8. * rb_rho(M[NF - 2], k.d.final_masses[NF - 1], k.d.final_masses[NF - 2]);   // :394-397
+    // rho numerators and 1 / M_c once: the decays below need the same square roots (q = 4 M rho = num / (2 M)) and reciprocals
+    M[NF - 1] = k.d.final_masses[NF - 1];
+    double rn[NF - 1], iM[NF - 1];
+#pragma unroll
+    for (int c = 0; c < NF - 1; ++c) {
+      rn[c] = rb_rho_num(M[c], M[c + 1], k.d.final_masses[c]);
+      iM[c] = nis_rcp(M[c]);
+    }
+    w_ps *= rn[NF - 2] * (iM[NF - 2] * iM[NF - 2]);                                        // 8 rho(M_n-2, m_n-1, m_n-2)  :394-397
     double prod = 1.0;
 #pragma unroll
     for (int c = 0; c < NF - 2; ++c)
-      // rho(M_c, M_c+1, m_c) / rho(K_c, K_c+1, 0) * (M_c+1 / K_c+1) with ONE reciprocal (the 8 M^2 denominators cross over)   :400-401
-      prod *= (rb_rho_num(M[c], M[c + 1], k.d.final_masses[c]) * (Kk[c] * Kk[c]) * M[c + 1]) *
-              nis_rcp(rb_rho_num(Kk[c], Kk[c + 1], 0.) * (M[c] * M[c]) * Kk[c + 1]);
+      // rho(M_c, M_c+1, m_c) / rho(K_c, K_c+1, 0) * (M_c+1 / K_c+1) with one reciprocal per factor (the 8 M^2 denominators cross
+      // over; every ratio is O(1) although its terms reach 1e-115 in the rows of an exact-zero draw -- one reciprocal for the whole
+      // product underflows there); the massless numerator sqrt((K_c^2 - K_c+1^2)^2) is K_c^2 - K_c+1^2 itself (K decreases)   :400-401
+      prod *= (rn[c] * (Kk[c] * Kk[c]) * M[c + 1]) * nis_rcp((Kk[c] * Kk[c] - Kk[c + 1] * Kk[c + 1]) * (M[c] * M[c]) * Kk[c + 1]);
     w_ps *= prod;
-    w_ps *= rb_ipow(Kk[0] * nis_rcp(M[0]), 2 * NF - 4);                                      // :403
+    w_ps *= rb_ipow(Kk[0] * iM[0], 2 * NF - 4);                                               // :403
     double wtot = wgt * w_ps;
 
     // ---- sequential two-body decays (:223-278)
@@ -306,24 +339,32 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     };
     V4 mom[STREAM ? 1 : NF + 2];
     V4 Q = {M[0], 0., 0., 0.};
-    M[NF - 1] = k.d.final_masses[NF - 1];
     bool bad_boost = false;
 #pragma unroll
     for (int c = 0; c < NF - 1; ++c) {
-      const double q = 4. * M[c] * rb_rho(M[c], M[c + 1], k.d.final_masses[c]);     // :228
+      const double q = rn[c] * (0.5 * iM[c]);                                         // 4 M rho(M_c, M_c+1, m_c)  :228
       const double cos_t = 2. * rv[NF - 2 + 2 * c] - 1.;
       const double sin_t = nis_sqrt(1. - cos_t * cos_t);
       const double phi = 2 * M_PI * rv[NF - 2 + 2 * c + 1];
-      const double cos_p = cospi(2.0 * rv[NF - 2 + 2 * c + 1]);   // = cos(2 pi r) without the large-argument reduction path
+      const double cos_p = rb_cospi(2.0 * rv[NF - 2 + 2 * c + 1]);  // = cos(2 pi r)
       const double sq = nis_sqrt(1. - cos_p * cos_p);
       const double sin_p = phi > M_PI ? -sq : sq;                                   // :241-243
       V4 p = {0., q * sin_t * cos_p, q * sin_t * sin_p, q * cos_t};
       const double m2 = k.d.final_masses[c] * k.d.final_masses[c];
       rb_set_square(p, m2);
       bad_boost |= (Q.e <= 0.) || ((Q.e * Q.e - Q.x * Q.x - Q.y * Q.y - Q.z * Q.z) < 0.);   // utils.py:33
-      const double iQe = nis_rcp(Q.e);                                                 // boostVector_t: Q_space / Q_0 (utils.py:36)
-      rb_boost(p, Q.x * iQe, Q.y * iQe, Q.z * iQe);
-      rb_set_square(p, m2);
+      if (c > 0) {
+        // boost into the frame of Q (boostVector_t + boost_t, utils.py:36, 58-81).  Q is on its mass shell M_c (set_square below), so
+        // gamma = Q_0 / M_c, gamma b = Q / M_c and (gamma - 1) / b^2 = gamma^2 / (gamma + 1): no 1 - b^2 (the reference's own
+        // cancellation), no rsqrt, one reciprocal.  c == 0: Q = (M_0, 0, 0, 0), the boost is the identity.
+        const double nx = Q.x * iM[c], ny = Q.y * iM[c], nz = Q.z * iM[c], gam = Q.e * iM[c];
+        const double np_ = p.x * nx + p.y * ny + p.z * nz;
+        const double f = fma(np_, nis_rcp(gam + 1.0), p.e);
+        p.x += f * nx;
+        p.y += f * ny;
+        p.z += f * nz;
+        rb_set_square(p, m2);                                                         // the boosted energy is re-derived from the mass shell
+      }
       if (STREAM) {
         if (momenta) put_leg(2 + c, p);
       } else {
