@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "nis_common.h"
 
@@ -21,6 +22,7 @@ struct RamboK {
   double mtot;
   double tau_min;
   nis_pdf1d pdf[2];            // per beam: x f(x) at the fixed scale on the grid's x knots (nx == 0: density 1)
+  double cospi_c[11];          // series coefficients of rb_cospi: kernel arguments = scalar operands (as literals they sit in 22 VGPRs)
   int cols[3 * NIS_MAX_LEGS];  // column -> plane (column-major input) or identity
   long r_ld;
   int col_major;
@@ -88,23 +90,19 @@ struct V4 {
 // h = 1/2 - |g| (exact) cos(pi g) = sin(pi h): ONE odd series on [0, 1/2] that keeps full relative accuracy at the zeros of the
 // cosine (h -> 0) -- ~20 instructions against ~50 of the library's cospi (quadrant reduction, both polynomials, select).
 // Coefficients (-1)^n pi^(2n+1) / (2n+1)!, n = 0..10, rounded from 80-digit values; truncation 1.3e-18, measured <= 3.4e-16 relative.
-__device__ __forceinline__ double rb_cospi(double x) {
-  const double k = rint(x);
-  const double h = 0.5 - fabs(x - k);
+static const double RB_COSPI_C[11] = {0x1.921fb54442d18p+1,  -0x1.4abbce625be53p+2, 0x1.466bc6775aae2p+1,  -0x1.32d2cce62bd86p-1,
+                                      0x1.50783487ee782p-4,  -0x1.e3074fde8871fp-8, 0x1.e8f434d018d63p-12, -0x1.6fadb9f155744p-16,
+                                      0x1.aaec32af93359p-21, -0x1.8a404211f9547p-26, 0x1.2877020d52cf0p-31};
+template <typename KT>
+__device__ __forceinline__ double rb_cospi(double x, const KT& k) {
+  const double kk = rint(x);
+  const double h = 0.5 - fabs(x - kk);
   const double z = h * h;
-  double p = 0x1.2877020d52cf0p-31;
-  p = fma(p, z, -0x1.8a404211f9547p-26);
-  p = fma(p, z, 0x1.aaec32af93359p-21);
-  p = fma(p, z, -0x1.6fadb9f155744p-16);
-  p = fma(p, z, 0x1.e8f434d018d63p-12);
-  p = fma(p, z, -0x1.e3074fde8871fp-8);
-  p = fma(p, z, 0x1.50783487ee782p-4);
-  p = fma(p, z, -0x1.32d2cce62bd86p-1);
-  p = fma(p, z, 0x1.466bc6775aae2p+1);
-  p = fma(p, z, -0x1.4abbce625be53p+2);
-  p = fma(p, z, 0x1.921fb54442d18p+1);
+  double p = k.cospi_c[10];
+#pragma unroll
+  for (int n = 9; n >= 0; --n) p = fma(p, z, k.cospi_c[n]);
   const double c = h * p;
-  const int odd = (int)k << 31;                                   // cos(pi (g + k)) = (-1)^k cos(pi g)
+  const int odd = (int)kk << 31;                                  // cos(pi (g + k)) = (-1)^k cos(pi g)
   return __hiloint2double(__double2hiint(c) ^ odd, __double2loint(c));
 }
 
@@ -176,16 +174,38 @@ __global__ __launch_bounds__(256) void k_pdf_xfx(nis_pdf1d t, const double* __re
 // The row-major OUTPUT goes through LDS: the (RB_TPB x 4(n+2)) momenta are written to a padded LDS image and stored as
 // contiguous 8-byte-per-lane streams; without staging every lane would write 16 bytes into its own 128-byte line per
 // instruction (row stride 128-384 B).  Inputs are prefetched into registers one tile ahead (see `fetch`).
+typedef double nis_d2 __attribute__((ext_vector_type(2)));
+// 16-byte global loads the compiler does not track (see k_rambo): NV of them off one row pointer, 16 bytes apart
+template <int NV, int NR>
+__device__ __forceinline__ void rb_issue_row(nis_d2 (&raw)[NR], const double* p) {
+  static_assert(NV <= NR, "row wider than its register image");
+#define RB_ISSUE16(J) \
+  if constexpr (NV > J) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(raw[J]) : "v"(p), "n"(16 * J) : "memory");
+  RB_ISSUE16(0) RB_ISSUE16(1) RB_ISSUE16(2) RB_ISSUE16(3) RB_ISSUE16(4) RB_ISSUE16(5) RB_ISSUE16(6) RB_ISSUE16(7)
+  RB_ISSUE16(8) RB_ISSUE16(9) RB_ISSUE16(10) RB_ISSUE16(11) RB_ISSUE16(12) RB_ISSUE16(13) RB_ISSUE16(14) RB_ISSUE16(15)
+#undef RB_ISSUE16
+  static_assert(NV <= 16, "add RB_ISSUE16 lines");
+}
+// s_waitcnt vmcnt(CNT) that every later use of the row image depends on
+template <int CNT, int NR>
+__device__ __forceinline__ void rb_wait_loads(nis_d2 (&raw)[NR]) {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CNT) : "memory");
+#pragma unroll
+  for (int j = 0; j < NR; ++j) asm volatile("" : "+v"(raw[j]));
+}
+
 // MODE: compile-time copy of the feature switches, because the generic kernel (every switch a scalar branch, the union
 // of all live ranges) needs 256 VGPRs = one wave per SIMD:
 //   0 plain 2 -> n map | 1 + PDF sampling (tau/y or x1,x2), x cut, lab boost | 2 + pT / delta-R / eta cuts
 //   3 + the reference's fixed-depth lattice bisection
 template <int NF, int MODE = 3>
-#ifdef RB_WAVES
-__global__ __launch_bounds__(RB_TPB, RB_WAVES)
-#else
-__global__ __launch_bounds__(RB_TPB)
+#ifndef RB_STORE_CHUNK
+#define RB_STORE_CHUNK 4
 #endif
+#ifndef RB_WAVES
+#define RB_WAVES 3          // waves per SIMD the plain 2 -> (<= 4) map is allocated for (its LDS staging allows three)
+#endif
+__global__ __launch_bounds__(RB_TPB, (MODE == 0 && NF <= 4) ? RB_WAVES : 1)
 void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict__ momenta,
                                                   double* __restrict__ weight, int* __restrict__ status) {
   extern __shared__ double rb_lds[];
@@ -206,23 +226,23 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
   // in flight while the current one is computed.  PDF columns only exist in the PDF modes.
   constexpr int NIN = HAS_PDF ? NPS + 2 : NPS;
   // row-major rows of exactly NIN doubles (NIN even): 16-byte vector loads, NIN / 2 per sample instead of NIN 8-byte ones
-  typedef double nis_d2 __attribute__((ext_vector_type(2)));
   const bool vec_rows = !col_major && (NIN % 2 == 0) && k.r_ld == NIN && k.ncol == NIN && ((unsigned long long)r & 15ull) == 0;
-  auto fetch = [&](long t, double (&dst)[NPS + 2]) {
+  // vec_rows: SOFTWARE-PIPELINED inputs.  The 16-byte loads of the NEXT tile are issued by inline asm (rb_issue16) into registers the
+  // compiler regards as ready, and the one wait that guards them is written by hand at the top of the next iteration:
+  // s_waitcnt vmcnt(<number of stores a whole tile issues after its loads>).  vmcnt counts loads and stores in issue order on
+  // gfx9, so that wait lets the loads land without waiting for the tile's own stores; the compiler's bookkeeping cannot express it
+  // (at the loop header it merges the pre-loop state, no store behind the loads, into vmcnt(0): every wave then sat out the full
+  // HBM latency of its stores once per tile).  Whole tiles only (fixed store count); a ragged last tile waits for vmcnt(0).
+  // More operations behind the loads than counted (status atomics) only make the wait stricter.
+  constexpr int NRAW = (NPS + 3) / 2;
+  auto issue = [&](long t, nis_d2 (&raw)[NRAW]) {
+    const long ii = t * RB_TPB + tid;
+    const double* p = r + (size_t)(ii < N ? ii : 0) * NIN;
+    rb_issue_row<NIN / 2>(raw, p);
+  };
+  auto fetch = [&](long t, double (&dst)[NPS + 2]) {              // strided / column-major inputs: element loads, used at once
     const long ii = t * RB_TPB + tid;
     const bool ok = ii < N;
-    if (vec_rows) {
-      const nis_d2* p = reinterpret_cast<const nis_d2*>(r + (size_t)(ok ? ii : 0) * NIN);
-#pragma unroll
-      for (int c2 = 0; c2 < (NPS + 2) / 2; ++c2) {
-        nis_d2 v = {0.5, 0.5};
-        if (2 * c2 < NIN) v = p[c2];
-        dst[2 * c2] = ok ? v.x : 0.5;
-        dst[2 * c2 + 1] = ok ? v.y : 0.5;
-      }
-      if ((NPS + 2) % 2) dst[NPS + 1] = 0.5;
-      return;
-    }
 #pragma unroll
     for (int c = 0; c < NPS + 2; ++c) {
       double v = 0.5;
@@ -231,17 +251,35 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     }
   };
   double rvn[NPS + 2];
-  if ((long)blockIdx.x < ntiles) fetch(blockIdx.x, rvn);
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  nis_d2 rawn[NRAW];
+#pragma unroll
+  for (int c2 = 0; c2 < NRAW; ++c2) rawn[c2] = nis_d2{0.5, 0.5};
+  // one tile; FULL: all RB_TPB samples exist (no guards, fixed store count), VEC: inputs come through rawn
+  auto process = [&](long tile, auto full_c, auto vec_c) {
+    constexpr bool FULL = decltype(full_c)::value, VEC = decltype(vec_c)::value;
     const long i0 = tile * RB_TPB;
-    const int ns = (int)min((long)RB_TPB, N - i0);
+    const int ns = FULL ? RB_TPB : (int)min((long)RB_TPB, N - i0);
     const long i = i0 + tid;
-    const bool live = tid < ns;
+    const bool live = FULL ? true : tid < ns;
     double rv[NPS + 2];
     bool nan_in = false;
+    if (VEC) {
+      if (FULL && momenta) rb_wait_loads<LM / 2 + 1>(rawn);      // the previous whole tile's stores stay in flight
+      else if (FULL) rb_wait_loads<1>(rawn);                      // weights only: one store per tile
+      else rb_wait_loads<0>(rawn);
 #pragma unroll
-    for (int c = 0; c < NPS + 2; ++c) rv[c] = rvn[c];
-    if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, rvn);
+      for (int c = 0; c < NPS + 2; ++c) {
+        const double v = (c & 1) ? rawn[c / 2].y : rawn[c / 2].x;
+        rv[c] = (live && c < NIN) ? v : 0.5;
+      }
+      // whole tiles prefetch unconditionally (last round: a valid tile again, unused).  The ragged tile is the workgroup's last and
+      // must NOT: the compiler sees the row image as dead there and reuses its registers while the loads would still be landing.
+      if (FULL) issue(min(tile + (long)gridDim.x, ntiles - 1), rawn);
+    } else {
+#pragma unroll
+      for (int c = 0; c < NPS + 2; ++c) rv[c] = rvn[c];
+      if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, rvn);
+    }
 #pragma unroll
     for (int c = 0; c < NPS + 2; ++c) nan_in |= (rv[c] != rv[c]);
     if (nan_in && live) atomicOr(status, 2);                  // the reference raises PhaseSpaceGeneratorError (:147-149)
@@ -346,7 +384,7 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
       const double cos_t = 2. * rv[NF - 2 + 2 * c] - 1.;
       const double sin_t = nis_sqrt(1. - cos_t * cos_t);
       const double phi = 2 * M_PI * rv[NF - 2 + 2 * c + 1];
-      const double cos_p = rb_cospi(2.0 * rv[NF - 2 + 2 * c + 1]);  // = cos(2 pi r)
+      const double cos_p = rb_cospi(2.0 * rv[NF - 2 + 2 * c + 1], k);  // = cos(2 pi r)
       const double sq = nis_sqrt(1. - cos_p * cos_p);
       const double sin_p = phi > M_PI ? -sq : sq;                                   // :241-243
       V4 p = {0., q * sin_t * cos_p, q * sin_t * sin_p, q * cos_t};
@@ -416,7 +454,7 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
       double* dst = momenta + ((size_t)i0 + wv * 64) * LM;
       const double* src = rb_lds + (size_t)wv * 64 * (LM + 1);
       const int tot = nsw * LM;                        // LM is even: a 16-byte pair never straddles two rows
-      for (int e = 2 * ln; e < tot; e += 128) {        // 16 bytes per lane and store: 1 KiB contiguous per wave instruction
+      auto put = [&](int e) {                          // 16 bytes per lane and store: 1 KiB contiguous per wave instruction
         const int s_ = e / LM, q = e - s_ * LM;        // LM is a compile-time constant
         const nis_d2 v = {src[s_ * (LM + 1) + q], src[s_ * (LM + 1) + q + 1]};
 #ifdef RB_ABLATE_STORE                                   // timing-only build: everything but the momenta stores (results wrong)
@@ -424,6 +462,15 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
 #else
         *reinterpret_cast<nis_d2*>(dst + e) = v;
 #endif
+      };
+      if (FULL || nsw == 64) {                         // whole wave tile: a fixed number of stores (the hand-written wait counts them)
+#pragma unroll
+        for (int u = 0; u < LM / 2; ++u) {
+          put(2 * ln + 128 * u);
+          if (u % RB_STORE_CHUNK == RB_STORE_CHUNK - 1) __builtin_amdgcn_sched_barrier(0);   // bound the LDS read-ahead: 4 registers per store in flight
+        }
+      } else {
+        for (int e = 2 * ln; e < tot; e += 128) put(e);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -472,6 +519,22 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     wtot *= factor;
     const double shat = x1 * x2 * (k.d.E_cm * k.d.E_cm);
     if (live) weight[i] = wtot * nis_rcp(2 * shat);
+  };
+  const std::integral_constant<bool, true> yes;
+  const std::integral_constant<bool, false> no;
+  if (vec_rows) {
+    if ((long)blockIdx.x >= ntiles) return;
+    issue(blockIdx.x, rawn);
+    rb_wait_loads<0>(rawn);                            // first tile of the workgroup: nothing is behind its loads yet
+    const long nfull = N / RB_TPB;
+    long tile = blockIdx.x;
+    for (; tile < nfull; tile += gridDim.x) process(tile, yes, yes);
+    if (tile < ntiles) process(tile, no, yes);         // the ragged last tile, if it is this workgroup's
+  } else {
+#ifndef RB_VEC_ONLY                                    // (register-pressure experiments: the pipelined path alone)
+    if ((long)blockIdx.x < ntiles) fetch(blockIdx.x, rvn);
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) process(tile, no, no);
+#endif
   }
 }
 
@@ -518,6 +581,7 @@ extern "C" int nis_rambo_forward_pdf(const nis_rambo_desc* dh, const nis_pdf1d* 
   if (!r_col_major && r_ld < k.ncol) return NIS_E_ARG;
   if (r_col_major && r_ld < N) return NIS_E_ARG;
   for (int c = 0; c < k.ncol; ++c) k.cols[c] = (r_col_major && r_cols_host) ? r_cols_host[c] : c;
+  for (int i = 0; i < 11; ++i) k.cospi_c[i] = RB_COSPI_C[i];
   k.flat_ab = pow(2 * M_PI, 4 - 3 * n) * pow(M_PI / 2.0, n - 1);
   k.flat_fact = host_fact(n - 1) * host_fact(n - 2);
   k.flat_const = k.flat_ab * (pow(dh->E_cm * dh->E_cm, n - 2) / k.flat_fact);
@@ -536,7 +600,12 @@ extern "C" int nis_rambo_forward_pdf(const nis_rambo_desc* dh, const nis_pdf1d* 
   const size_t lds_bytes = (size_t)RB_TPB * (LMh + 1) * sizeof(double);      // output staging only
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
   static const int mult = getenv("NIS_RAMBO_GRID_MULT") ? atoi(getenv("NIS_RAMBO_GRID_MULT")) : 2;
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * 256 * mult, (N + RB_TPB - 1) / RB_TPB));
+  // workgroups: `mult` x what the chip holds at once.  NIS_RAMBO_BALANCE=1: evenly loaded instead -- ceil(tiles / rounds)
+  // workgroups of `rounds` tiles each (no partial last round)
+  const int64_t ntiles_h = (N + RB_TPB - 1) / RB_TPB, cap = (int64_t)per_cu * 256 * mult;
+  const int64_t rounds = std::max<int64_t>(1, (ntiles_h + cap - 1) / cap);
+  static const int balance = getenv("NIS_RAMBO_BALANCE") ? 1 : 0;      // measured 7 % SLOWER (55.1 vs 51.7 us per 1e6): oversubscribed workgroups balance better
+  const int grid = (int)std::max<int64_t>(1, balance ? (ntiles_h + rounds - 1) / rounds : std::min<int64_t>(cap, ntiles_h));
   const bool has_pdf = (dh->flags & (NIS_RAMBO_PDF_ACTIVE | NIS_RAMBO_LAB_BOOST)) != 0;          // TAU only matters with PDFs
   const bool has_cuts = dh->pT_mincut > 0. || dh->delR_mincut > 0. || dh->rap_maxcut > 0.;
   const bool need_gen = dh->bisect_levels > 0;
