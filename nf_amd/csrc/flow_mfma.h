@@ -19,9 +19,22 @@ typedef double nis_d4 __attribute__((ext_vector_type(4)));
 
 #define NIS_MF_TPB 256                 // 4 waves, one per SIMD
 #define NIS_MF_NCB 4                   // transformed columns per bijector batch (4 x 16 samples = 64 lanes)
-#ifndef NIS_MF_CHAINS
-#define NIS_MF_CHAINS 1                // row tiles of the last layer in flight per wave; 2 independent chains measured SLOWER (C5 forward 10.3 vs 9.1 ms, C3 26.3 vs 22.2)
+// (two independent accumulation chains per wave in the last layer measured SLOWER: C5 forward 10.3 vs 9.1 ms, C3 26.3 vs 22.2)
+#ifndef NIS_MF_PREFETCH
+#define NIS_MF_PREFETCH 1              // 0: operands requested where they are used (A/B measurements)
 #endif
+
+// Row tiles of the last layer one column batch touches (its rows [cb NCB out, (cb+1) NCB out) need not start on a tile): the
+// per-wave LDS image holds that many whole tiles, so every accumulator row is written without a guard at a fixed offset.
+__host__ __device__ inline int mf_cb_tiles(int T, int out, int R) {
+  int mx = 1;
+  for (int cb = 0; cb * NIS_MF_NCB < T; ++cb) {
+    const int r0 = cb * NIS_MF_NCB * out, r1 = (r0 + NIS_MF_NCB * out < R) ? r0 + NIS_MF_NCB * out : R;
+    const int n = (r1 + 15) / 16 - r0 / 16;
+    mx = n > mx ? n : mx;
+  }
+  return mx;
+}
 
 template <int WM>
 struct MfCfg {
@@ -202,10 +215,10 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
                                                                 const double* __restrict__ wm_last, const double* __restrict__ bias_pad,
                                                                 FuseF fz) {
   constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ, NW = NIS_MF_TPB / 64, NCB = NIS_MF_NCB;
-  extern __shared__ double mf_dyn[];                 // per wave: [NCB*out rows][16 samples]
+  extern __shared__ double mf_dyn[];                 // per wave: [row tiles of a column batch][16 rows][16 samples]
   __shared__ double lds_coef[(NIS_MAX_HIDDEN + 1) * 2 * WM];
-  __shared__ double red[3 * NIS_MF_TPB];
-  __shared__ int lds_plane[NIS_MAX_DIM];
+  double* const red = mf_dyn;                        // the prologue's reduction scratch (3 * TPB doubles) lives in the image: 6 KB of LDS
+  __shared__ int lds_plane[NIS_MAX_DIM];             // decide between one and two workgroups per CU at K = 16
   __shared__ double etab[NIS_EXP_N];
   __shared__ double fmom[NW][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
@@ -214,6 +227,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
   if (tid < NIS_MAX_DIM) lds_plane[tid] = c.in_plane[tid];
   nis_exp_init(etab);
   load_coefs<WM, NIS_MF_TPB>(c, g, c.L + 1, (bn_train && c.pmerge) ? cellk_fresh(c, c.L + 1) : -1, blockIdx.x == 0, lds_coef, red);
+  __syncthreads();                                   // the image is reused by the waves from here on
   const int out = c.out;
   const bool wplanes = FUSE ? fz.write_planes != 0 : true;
   double fS1 = 0.0, fS2 = 0.0, fcnt = 0.0, fmx = -__builtin_huge_val(), fshift = 0.0;
@@ -221,8 +235,24 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
   // normal(): exp(-sum (x - mu)^2 / (2 sigma^2)) / (sigma sqrt((2 pi)^d)); the constants once per launch, not per sample
   const double f_i2s = FUSE ? 1.0 / (2 * fz.p[1] * fz.p[1]) : 0.0;
   const double f_norm = (FUSE && fz.kind == NIS_F_NORMAL) ? 1.0 / (fz.p[1] * sqrt(pow(2 * M_PI, (double)c.d))) : 1.0;
-  double* ring = mf_dyn + (size_t)wave * NCB * out * 16;
+  const int cb_tiles = mf_cb_tiles(c.T, out, c.R);
+  double* ring = mf_dyn + (size_t)wave * cb_tiles * 256;
   const long wstride = (long)gridDim.x * NW * 16 * ST;
+  // Operand requests ahead of their use.  The last layer walks its row tiles in a fixed cyclic order (the weights do not depend
+  // on the sample): right after a tile's MFMA chain has been issued, the A fragments and bias rows of the NEXT tile are
+  // requested into the same registers, so their L2 round trip (8 x 512 B per tile) runs under the tile's exp phase instead of
+  // in front of the next chain.  The transformed input xb of the next column batch and the incoming Jacobian are requested a
+  // phase ahead as well (an HBM round trip per column batch otherwise).
+  double an[KQ];
+  nis_d4 bnx = {0.0, 0.0, 0.0, 0.0};
+  auto load_tile = [&](int jt) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) an[q] = wm_last[((size_t)jt * KQ + q) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bnx[r] = bias_pad[16 * jt + gq + 4 * r];
+  };
+  const int ncb = (c.T + NCB - 1) / NCB;
+  load_tile(0);
   for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
     double H[KQ][ST];
     {
@@ -244,10 +274,16 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
     for (int st = 0; st < ST; ++st) {
       double jprod = 1.0;                            // this lane's columns (t = NCB*cb + gq) of sample s
       double facc = 0.0, fc0 = 0.0, fc1 = 0.0;       // FUSE: this lane's share of the integrand's argument
+      const long i = base + 16 * st + s;
+      // requests of this sample tile that nothing below has to wait for: first column batch's xb, incoming Jacobian
+      double xbn = 0.0, jinq = 1.0;
+      if (NIS_MF_PREFETCH) {
+        if (gq < c.T && i < N) xbn = planes[(size_t)lds_plane[c.P + gq] * ld + i];
+        if (!c.first && gq == 0 && i < N) jinq = planes[(size_t)c.jplane * ld + i];
+      }
       if (FUSE) {
-        const long ip = base + 16 * st + s;
         for (int p = gq; p < c.P; p += 4) {          // pass-through columns, spread over the four lanes of the sample
-          const double xp = ip < N ? planes[(size_t)lds_plane[p] * ld + ip] : 0.0;
+          const double xp = i < N ? planes[(size_t)lds_plane[p] * ld + i] : 0.0;
           if (fz.kind == NIS_F_NORMAL) facc = fma((xp - fz.p[0]) * (xp - fz.p[0]), f_i2s, facc);
           if (fz.kind == NIS_F_CAMEL) {
             fc0 = (p == fz.loc0) ? xp : fc0;
@@ -263,51 +299,37 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
         for (int u = 1; u < ST; ++u) Hs[q] = (st == u) ? H[q][u] : Hs[q];
       }
 #pragma unroll 1
-      for (int cb = 0; cb * NCB < c.T; ++cb) {
+      for (int cb = 0; cb < ncb; ++cb) {
         const int r0 = cb * NCB * out;
         const int r1 = min(c.R, r0 + NCB * out);
-        // two row tiles at a time: two independent accumulation chains per wave (a chain of dependent f64 MFMAs leaves the
-        // pipe idle between issues; with the other wave's chain that made two per SIMD, now four) sharing the B operands
-        for (int jt = r0 / 16; jt * 16 < r1; jt += NIS_MF_CHAINS) {
-          const bool two = NIS_MF_CHAINS > 1 && (jt + 1) * 16 < r1;
-          const int jb = two ? jt + 1 : jt;              // single tail tile: the second chain repeats it (results discarded)
-          nis_d4 z, zb;
+        const int t = cb * NCB + gq;
+        const double xbq = xbn;                        // requested one column batch ago
+        if (NIS_MF_PREFETCH) {
+          const int tn = t + NCB;
+          xbn = (tn < c.T && i < N) ? planes[(size_t)lds_plane[c.P + (tn < c.T ? tn : 0)] * ld + i] : 0.0;
+        }
+        const int jt_first_next = (cb + 1 < ncb) ? ((cb + 1) * NCB * out) / 16 : 0;      // cyclic: the next sample tile starts at row tile 0
+        const int jt0 = r0 / 16;
+        const bool raw_row = KIND == NIS_AFFINE && (((jt0 * 16 + gq - r0) & 1) != 0);      // affine: odd rows of a column = raw shift (row parity is fixed per lane: 16 jt + 4 r is even)
+        double* rw = ring + lane;                      // row (16 (jt - jt0) + gq + 4 r), sample s  ->  rw[256 (jt - jt0) + 64 r]
+        for (int jt = jt0; jt * 16 < r1; ++jt) {
+          nis_d4 z = bnx;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            z[r] = bias_pad[16 * jt + gq + 4 * r];
-            zb[r] = bias_pad[16 * jb + gq + 4 * r];
-          }
+          for (int q = 0; q < KQ; ++q) z = __builtin_amdgcn_mfma_f64_16x16x4f64(an[q], Hs[q], z, 0, 0, 0);
+          load_tile((jt + 1) * 16 < r1 ? jt + 1 : jt_first_next);
+          // every row of the tile goes to the image (rows of the neighbouring batch and the zero-padded rows past R land in
+          // entries nobody reads): no guards, no address arithmetic -- immediate offsets off one pointer
 #pragma unroll
-          for (int q = 0; q < KQ; ++q) {
-            const double a = wm_last[((size_t)jt * KQ + q) * 64 + lane];
-            const double ab = wm_last[((size_t)jb * KQ + q) * 64 + lane];
-            z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Hs[q], z, 0, 0, 0);
-            zb = __builtin_amdgcn_mfma_f64_16x16x4f64(ab, Hs[q], zb, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = 16 * jt + gq + 4 * r - r0;
-            if (j >= 0 && j < NCB * out && 16 * jt + gq + 4 * r < c.R)
-              ring[j * 16 + s] = (KIND == NIS_AFFINE && (j & 1)) ? z[r] : nis_exp(z[r], etab);   // affine: odd rows = raw shift
-          }
-          if (two) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int j = 16 * jb + gq + 4 * r - r0;
-              if (j >= 0 && j < NCB * out && 16 * jb + gq + 4 * r < c.R)
-                ring[j * 16 + s] = (KIND == NIS_AFFINE && (j & 1)) ? zb[r] : nis_exp(zb[r], etab);
-            }
-          }
+          for (int r = 0; r < 4; ++r) rw[64 * r] = raw_row ? z[r] : nis_exp(z[r], etab);
+          rw += 256;
         }
         // (sample s, column t) per lane.  A wave executes in lock step and its LDS operations complete in order:
         // the image written above is complete; the wave barriers only pin the compiler's schedule.
         __builtin_amdgcn_wave_barrier();
-        const int t = cb * NCB + gq;
-        const long i = base + 16 * st + s;
         if (t < c.T && i < N) {
           double* col = planes + (size_t)lds_plane[c.P + t] * ld;
-          const double xb = col[i];
-          const double* zr = ring + (size_t)gq * out * 16 + s;
+          const double xb = NIS_MF_PREFETCH ? xbq : col[i];
+          const double* zr = ring + (size_t)((r0 & 15) + gq * out) * 16 + s;
           double y, jf;
           int bin;
           if (KIND == NIS_PWQUAD) {
@@ -357,11 +379,10 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
       jprod *= __shfl_xor(jprod, 16, 64);
       jprod *= __shfl_xor(jprod, 32, 64);
       if (KIND == NIS_AFFINE) jprod *= 1.0 / (M_PI / 2);       // the reference applies 2/pi ONCE per cell (:68)
-      const long i = base + 16 * st + s;
       double jout = 1.0;
       if (gq == 0 && i < N) {
         double* jp = planes + (size_t)c.jplane * ld;
-        jout = (c.first ? 1.0 : jp[i]) * jprod;
+        jout = (c.first ? 1.0 : NIS_MF_PREFETCH ? jinq : jp[i]) * jprod;
         if (wplanes) jp[c.out_off + i] = jout;
       }
       if (FUSE) {

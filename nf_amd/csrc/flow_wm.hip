@@ -262,7 +262,11 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
 #if NIS_WM >= 16
 #include "flow_mfma.h"
 
-static size_t mf_ring_bytes(const CellK& c) { return (size_t)(NIS_MF_TPB / 64) * NIS_MF_NCB * c.out * 16 * sizeof(double); }
+// per wave: the whole row tiles of one column batch (flow_mfma.h, mf_cb_tiles); at least the prologue's reduction scratch
+static size_t mf_ring_bytes(const CellK& c) {
+  const size_t ring = (size_t)(NIS_MF_TPB / 64) * mf_cb_tiles(c.T, c.out, c.R) * 256 * sizeof(double);
+  return std::max<size_t>(ring, 3 * NIS_MF_TPB * sizeof(double));
+}
 
 template <>
 bool mfma_supported<NIS_WM>(const CellK& c) {
@@ -271,7 +275,7 @@ bool mfma_supported<NIS_WM>(const CellK& c) {
 
 template <>
 int mfma_blocks_per_cu<NIS_WM>(const CellK& c) {
-  const size_t lds = mf_ring_bytes(c) + 12 * 1024;
+  const size_t lds = mf_ring_bytes(c) + 6 * 1024;           // static LDS of k_cell_apply_mfma: 5.4 KB
   int n = (int)(160 * 1024 / lds);
   return n < 1 ? 1 : n > 2 ? 2 : n;               // <= 256 VGPR+AGPR per lane: two waves per SIMD when the LDS images fit
 }
