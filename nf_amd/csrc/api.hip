@@ -989,7 +989,7 @@ static SidePool* side_pool(int n) {
 
 template <int WM>
 static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, long ld, long N, int bn_mode, int km, int* bins,
-                    const FuseF& fz, bool need_stats0, int grid_stats, int grid_apply, int grid_mf, hipStream_t s,
+                    const FuseF& fz, bool need_stats0, int grid_stats, int grid_apply, int grid_mf, int grid_mf_stats, hipStream_t s,
                     const RunOpts& o, hipEvent_t pre_apply = nullptr) {
   if (bn_mode == NIS_BN_TRAIN) {
     if (need_stats0) {
@@ -1003,7 +1003,7 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
       {
         NisProfScope ps(NIS_K_STATS, s);
         if (mfma)
-          HIP_OK(launch_stats_mfma<WM>(c, mw, planes, ld, N, l, grid_mf, s));
+          HIP_OK(launch_stats_mfma<WM>(c, mw, planes, ld, N, l, grid_mf_stats, s));
         else
           HIP_OK(launch_stats<WM>(c, planes, ld, N, l, grid_stats, s));
         if (int rc = sync_records(o, c.partials + (size_t)l * c.G * c.maxb * WM * 3, c.nparts[l], WM, s)) return rc;
@@ -1023,12 +1023,17 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
 }
 
 template <int WM>
-static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid) {
+static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid, int* grid_stats) {
   *ok = WM >= 16 && use_mfma() && mfma_supported<WM>(c);
   // one wave owns 2 tiles of 16 samples per pass; 4 waves per workgroup
   const int per_wg = 4 * 16 * 2;
   static const int bpc = env_int("NIS_MFMA_BPC", 0);          // tuning override
   *grid = *ok ? grid_for(bpc > 0 ? bpc : mfma_blocks_per_cu<WM>(c), G, N, per_wg) : 1;
+  // the statistics kernels run on the apply kernel's grid.  They hold no LDS image and ~100 VGPRs, but more workgroups per CU
+  // (NIS_MFMA_STATS_BPC = 4, 6, 8) measured 0 ... 8 % SLOWER (C3 13.9 -> 14.2 ms, C5 7.6 -> 8.2 ms per iteration): every
+  // workgroup's prologue merges the previous layer's records, one per workgroup
+  static const int bpc_s = env_int("NIS_MFMA_STATS_BPC", 0);
+  *grid_stats = *ok ? (bpc_s > 0 ? std::max(*grid, grid_for(bpc_s, G, N, per_wg)) : *grid) : 1;
 }
 
 // Descriptor-level mirror of launch_apply's SPEC conditions (flow_wm.hip): every cell of a d = 2 PWQuad chain with 3-wide
@@ -1301,15 +1306,15 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       c.Gy = Gy;
       c.g0 = g0;
       bool mfma = false;
-      int grid_mf = 1;
+      int grid_mf = 1, grid_mf_stats = 1;
       switch (L.WM) {
-        case 16: mfma_plan<16>(c, Gg, N, &mfma, &grid_mf); break;
-        case 32: mfma_plan<32>(c, Gg, N, &mfma, &grid_mf); break;
-        case 64: mfma_plan<64>(c, Gg, N, &mfma, &grid_mf); break;
+        case 16: mfma_plan<16>(c, Gg, N, &mfma, &grid_mf, &grid_mf_stats); break;
+        case 32: mfma_plan<32>(c, Gg, N, &mfma, &grid_mf, &grid_mf_stats); break;
+        case 64: mfma_plan<64>(c, Gg, N, &mfma, &grid_mf, &grid_mf_stats); break;
         default: break;
       }
       c.nparts[0] = have_stats0 ? prev_records : grid_stats;
-      for (int l = 1; l <= cd.n_hidden; ++l) c.nparts[l] = mfma ? grid_mf : grid_stats;
+      for (int l = 1; l <= cd.n_hidden; ++l) c.nparts[l] = mfma ? grid_mf_stats : grid_stats;
       c.maxb = NIS_MAXB;
       c.bins_row = f->bins_row[ci];
       c.wp = body + L.off_wp;
@@ -1393,11 +1398,11 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       int rc;
       const bool need0 = !have_stats0;
       switch (L.WM) {
-        case 4: rc = run_cell<4>(c, mw, false, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, cs, o, ci == 0 ? stagger : nullptr); break;
-        case 8: rc = run_cell<8>(c, mw, false, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, cs, o, ci == 0 ? stagger : nullptr); break;
-        case 16: rc = run_cell<16>(c, mw, mfma, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, cs, o, ci == 0 ? stagger : nullptr); break;
-        case 32: rc = run_cell<32>(c, mw, mfma, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, cs, o, ci == 0 ? stagger : nullptr); break;
-        case 64: rc = run_cell<64>(c, mw, mfma, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, cs, o, ci == 0 ? stagger : nullptr); break;
+        case 4: rc = run_cell<4>(c, mw, false, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, 1, cs, o, ci == 0 ? stagger : nullptr); break;
+        case 8: rc = run_cell<8>(c, mw, false, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, 1, 1, cs, o, ci == 0 ? stagger : nullptr); break;
+        case 16: rc = run_cell<16>(c, mw, mfma, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, grid_mf_stats, cs, o, ci == 0 ? stagger : nullptr); break;
+        case 32: rc = run_cell<32>(c, mw, mfma, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, grid_mf_stats, cs, o, ci == 0 ? stagger : nullptr); break;
+        case 64: rc = run_cell<64>(c, mw, mfma, pl, ld, N, o.bn_mode, L.KM, o.bins_out, fz, need0, grid_stats, grid_apply, grid_mf, grid_mf_stats, cs, o, ci == 0 ? stagger : nullptr); break;
         default: rc = NIS_E_UNSUPPORTED;
       }
       if (rc != NIS_OK) return rc;

@@ -18,7 +18,8 @@
 typedef double nis_d4 __attribute__((ext_vector_type(4)));
 
 #define NIS_MF_TPB 256                 // 4 waves, one per SIMD
-#define NIS_MF_NCB 4                   // transformed columns per bijector batch (4 x 16 samples = 64 lanes)
+#define NIS_MF_NCB 4                   // transformed columns per bijector batch (4 x 16 samples = 64 lanes); CellK::mf_ncb lowers it to 2 or 1 when
+                                       // the LDS image of four columns would leave ONE workgroup per CU (C3: 64 heights per column = 32 KB per wave)
 // (two independent accumulation chains per wave in the last layer measured SLOWER: C5 forward 10.3 vs 9.1 ms, C3 26.3 vs 22.2)
 #ifndef NIS_MF_PREFETCH
 #define NIS_MF_PREFETCH 1              // 0: operands requested where they are used (A/B measurements)
@@ -26,10 +27,10 @@ typedef double nis_d4 __attribute__((ext_vector_type(4)));
 
 // Row tiles of the last layer one column batch touches (its rows [cb NCB out, (cb+1) NCB out) need not start on a tile): the
 // per-wave LDS image holds that many whole tiles, so every accumulator row is written without a guard at a fixed offset.
-__host__ __device__ inline int mf_cb_tiles(int T, int out, int R) {
+__host__ __device__ inline int mf_cb_tiles(int T, int out, int R, int ncb_cols) {
   int mx = 1;
-  for (int cb = 0; cb * NIS_MF_NCB < T; ++cb) {
-    const int r0 = cb * NIS_MF_NCB * out, r1 = (r0 + NIS_MF_NCB * out < R) ? r0 + NIS_MF_NCB * out : R;
+  for (int cb = 0; cb * ncb_cols < T; ++cb) {
+    const int r0 = cb * ncb_cols * out, r1 = (r0 + ncb_cols * out < R) ? r0 + ncb_cols * out : R;
     const int n = (r1 + 15) / 16 - r0 / 16;
     mx = n > mx ? n : mx;
   }
@@ -214,7 +215,8 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
                                                                 int* __restrict__ bins_out, const double* __restrict__ wm_all,
                                                                 const double* __restrict__ wm_last, const double* __restrict__ bias_pad,
                                                                 FuseF fz) {
-  constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ, NW = NIS_MF_TPB / 64, NCB = NIS_MF_NCB;
+  constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ, NW = NIS_MF_TPB / 64;
+  const int NCB = c.mf_ncb;                          // columns per bijector batch: lane groups gq >= NCB idle in the bijector phase
   extern __shared__ double mf_dyn[];                 // per wave: [row tiles of a column batch][16 rows][16 samples]
   __shared__ double lds_coef[(NIS_MAX_HIDDEN + 1) * 2 * WM];
   double* const red = mf_dyn;                        // the prologue's reduction scratch (3 * TPB doubles) lives in the image: 6 KB of LDS
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
   // normal(): exp(-sum (x - mu)^2 / (2 sigma^2)) / (sigma sqrt((2 pi)^d)); the constants once per launch, not per sample
   const double f_i2s = FUSE ? 1.0 / (2 * fz.p[1] * fz.p[1]) : 0.0;
   const double f_norm = (FUSE && fz.kind == NIS_F_NORMAL) ? 1.0 / (fz.p[1] * sqrt(pow(2 * M_PI, (double)c.d))) : 1.0;
-  const int cb_tiles = mf_cb_tiles(c.T, out, c.R);
+  const int cb_tiles = mf_cb_tiles(c.T, out, c.R, NCB);
   double* ring = mf_dyn + (size_t)wave * cb_tiles * 256;
   const long wstride = (long)gridDim.x * NW * 16 * ST;
   // Operand requests ahead of their use.  The last layer walks its row tiles in a fixed cyclic order (the weights do not depend
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
       // requests of this sample tile that nothing below has to wait for: first column batch's xb, incoming Jacobian
       double xbn = 0.0, jinq = 1.0;
       if (NIS_MF_PREFETCH) {
-        if (gq < c.T && i < N) xbn = planes[(size_t)lds_plane[c.P + gq] * ld + i];
+        if (gq < NCB && gq < c.T && i < N) xbn = planes[(size_t)lds_plane[c.P + gq] * ld + i];
         if (!c.first && gq == 0 && i < N) jinq = planes[(size_t)c.jplane * ld + i];
       }
       if (FUSE) {
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
         const double xbq = xbn;                        // requested one column batch ago
         if (NIS_MF_PREFETCH) {
           const int tn = t + NCB;
-          xbn = (tn < c.T && i < N) ? planes[(size_t)lds_plane[c.P + (tn < c.T ? tn : 0)] * ld + i] : 0.0;
+          xbn = (gq < NCB && tn < c.T && i < N) ? planes[(size_t)lds_plane[c.P + (tn < c.T ? tn : 0)] * ld + i] : 0.0;
         }
         const int jt_first_next = (cb + 1 < ncb) ? ((cb + 1) * NCB * out) / 16 : 0;      // cyclic: the next sample tile starts at row tile 0
         const int jt0 = r0 / 16;
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
         // (sample s, column t) per lane.  A wave executes in lock step and its LDS operations complete in order:
         // the image written above is complete; the wave barriers only pin the compiler's schedule.
         __builtin_amdgcn_wave_barrier();
-        if (t < c.T && i < N) {
+        if (gq < NCB && t < c.T && i < N) {
           double* col = planes + (size_t)lds_plane[c.P + t] * ld;
           const double xb = NIS_MF_PREFETCH ? xbq : col[i];
           const double* zr = ring + (size_t)((r0 & 15) + gq * out) * 16 + s;
@@ -346,21 +348,35 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfm
             const double bf = floor(ak);
             const double alpha = (ak - bf) / c.K;
             bin = (int)bf;
-            double tot = 0.0, below = 0.0, qb = 0.0;
-            for (int k = 0; k < c.K; ++k) {
-              const double e = zr[k * 16];
-              const bool hit = k == bin;
-              below = hit ? tot : below;
-              qb = hit ? e : qb;
+            // heights streamed from the image EIGHT reads at a time (one read per trip left the LDS round trip, ~130 cycles, in
+            // front of every height: at K = 64 that loop was as long as the MFMA phase and pure latency); the bin's own height
+            // is read back by index.  Same sequential sums as before.
+            double tot = 0.0, below = 0.0;
+            int k0 = 0;
+            for (; k0 + 8 <= c.K; k0 += 8) {
+              double e[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) e[u] = zr[(k0 + u) * 16];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                below = (k0 + u == bin) ? tot : below;
+                tot += e[u];                                                              // :117
+              }
+            }
+            for (; k0 < c.K; ++k0) {
+              const double e = zr[k0 * 16];
+              below = (k0 == bin) ? tot : below;
               tot += e;
             }
+            double qb = zr[(bin < 0 ? 0 : bin >= c.K ? c.K - 1 : bin) * 16];
             if (bin < 0 || bin >= c.K) {
               if (c.status) atomicOr(c.status, 1);
               qb = __builtin_nan("");
             }
-            const double qn = qb / (tot / c.K);
-            y = qn * alpha + below / tot;
-            jf = qn;
+            const double itot = nis_rcp(tot);                                             // one Newton-refined reciprocal for both
+            const double qn = qb * (c.K * itot);                                          // normalisations (<= 1-2 ulp)  :121
+            y = qn * alpha + below * itot;                                                // :123,136-139
+            jf = qn;                                                                      // :141
           }
           if (wplanes) col[c.out_off + i] = y;
           jprod *= jf;

@@ -263,10 +263,21 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
 #include "flow_mfma.h"
 
 // per wave: the whole row tiles of one column batch (flow_mfma.h, mf_cb_tiles); at least the prologue's reduction scratch
-static size_t mf_ring_bytes(const CellK& c) {
-  const size_t ring = (size_t)(NIS_MF_TPB / 64) * mf_cb_tiles(c.T, c.out, c.R) * 256 * sizeof(double);
+static size_t mf_ring_bytes_n(const CellK& c, int ncb) {
+  const size_t ring = (size_t)(NIS_MF_TPB / 64) * mf_cb_tiles(c.T, c.out, c.R, ncb) * 256 * sizeof(double);
   return std::max<size_t>(ring, 3 * NIS_MF_TPB * sizeof(double));
 }
+static const size_t MF_STATIC_LDS = 6 * 1024;            // static LDS of k_cell_apply_mfma: 5.4 KB
+// columns per bijector batch: four (every lane busy in the bijector phase) unless the image of four columns leaves ONE workgroup
+// per CU while two or one column(s) would admit two -- one wave per SIMD hides nothing (C3 ran at 2x its MFMA + VALU time)
+static int mf_pick_ncb(const CellK& c) {
+  static const int forced = getenv("NIS_MF_NCB") ? atoi(getenv("NIS_MF_NCB")) : 0;
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  for (int n = NIS_MF_NCB; n >= 1; n >>= 1)
+    if (2 * (mf_ring_bytes_n(c, n) + MF_STATIC_LDS) <= 160 * 1024) return n;
+  return NIS_MF_NCB;
+}
+static size_t mf_ring_bytes(const CellK& c) { return mf_ring_bytes_n(c, mf_pick_ncb(c)); }
 
 template <>
 bool mfma_supported<NIS_WM>(const CellK& c) {
@@ -275,7 +286,7 @@ bool mfma_supported<NIS_WM>(const CellK& c) {
 
 template <>
 int mfma_blocks_per_cu<NIS_WM>(const CellK& c) {
-  const size_t lds = mf_ring_bytes(c) + 6 * 1024;           // static LDS of k_cell_apply_mfma: 5.4 KB
+  const size_t lds = mf_ring_bytes(c) + MF_STATIC_LDS;
   int n = (int)(160 * 1024 / lds);
   return n < 1 ? 1 : n > 2 ? 2 : n;               // <= 256 VGPR+AGPR per lane: two waves per SIMD when the LDS images fit
 }
@@ -295,8 +306,10 @@ hipError_t launch_stats_mfma<NIS_WM>(const CellK& c, const MfmaW& w, const doubl
                      ld, N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad, fz)
 
 template <>
-hipError_t launch_apply_mfma<NIS_WM>(const CellK& c, const MfmaW& w, double* planes, long ld, long N, int bn_train, int km, int* bins,
+hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* planes, long ld, long N, int bn_train, int km, int* bins,
                                      const FuseF& fz, int grid, hipStream_t s) {
+  CellK c = c_in;
+  c.mf_ncb = mf_pick_ncb(c_in);
   if (fz.kind >= 0) {                      // last cell of an integrate step: integrand * J + moment records fused (FUSE instantiations)
     if (!nis_mfma_fusable(c.kind, km) || bins || fz.fres) return hipErrorInvalidValue;
     if (c.kind == NIS_PWLIN) {

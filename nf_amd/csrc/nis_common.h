@@ -165,6 +165,7 @@ struct FuseF {
 // wave-uniform, so plane indices / sizes live in SGPRs).
 struct CellK {
   int kind, d, P, T, K, L, out, R;       // out = conditioner outputs per transformed column, R = T*out
+  int mf_ncb;                            // matrix-core apply kernel: transformed columns per bijector batch (4, 2 or 1; set at launch)
   int width[NIS_MAX_HIDDEN];
   int in_plane[NIS_MAX_DIM];             // local column j -> state plane
   int jplane;                            // plane of the running Jacobian
