@@ -426,6 +426,26 @@ class BasicManager(ModelAPI):
                 i += g
             return out
         planar = hasattr(f, "from_planes") and isinstance(model, FlowSequential)
+        if planar and model.engine().fusable():
+            # e.g. RAMBO weight: reads the flow's column planes, X is never assembled.  The flow part of G iterations runs as ONE
+            # launch set that keeps its planes (the rider integrates f == 1, i.e. <J>, and is ignored); the weight kernel and the
+            # moment reduction then take one batch of planes each.
+            eng = model.engine()
+            G = max(1, min(int(self.batch_iterations), nitn, max(1, (1 << 27) // max(1, neval * (self.n_flow + 1)))))
+            scratch = torch.empty((G, 4), dtype=torch.double, device=dev)
+            planes = torch.empty((G, eng.d + 1, neval), dtype=torch.double, device=dev)
+            i = 0
+            while i < nitn:
+                g = min(G, nitn - i)
+                if self.sample_hook is None:
+                    w = torch.rand(g, neval, self.n_flow, dtype=torch.float32, device=dev)
+                else:
+                    w = torch.stack([self._uniform(neval, dev, torch.float32, "integrate") for _ in range(g)])
+                eng.integrate_steps(w, model.training, _lib.NIS_F_ONE, [], scratch[:g], planes=planes[:g])
+                for k in range(g):
+                    out[i + k] = hip_moments(f.from_planes(planes[k], eng.out_col, neval), planes[k][eng.d])
+                i += g
+            return out
         for i in range(nitn):
             w = self._uniform(neval, dev, torch.float32, "integrate")
             if planar:                      # e.g. RAMBO weight: reads the flow's column planes, X is never assembled
