@@ -147,7 +147,10 @@ __device__ __forceinline__ double nis_sqrt(double x) {
 static inline int nis_pick_wm(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 16 ? 16 : m <= 32 ? 32 : m <= 64 ? 64 : -1; }
 static inline int nis_pick_km(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : -1; }
 // workgroup size of the statistics kernel: as many waves as the register budget of width WM allows
-__host__ __device__ constexpr int nis_stats_tpb(int wm) { return wm <= 8 ? 512 : wm <= 16 ? 512 : 256; }
+#ifndef NIS_STATS_TPB_NARROW
+#define NIS_STATS_TPB_NARROW 1024     // statistics kernels of the narrow conditioners: ONE workgroup per CU (the prologue is paid per workgroup) of 16 waves
+#endif
+__host__ __device__ constexpr int nis_stats_tpb(int wm) { return wm <= 8 ? NIS_STATS_TPB_NARROW : wm <= 16 ? 512 : 256; }
 
 // Built-in integrand evaluated inside the last apply kernel (f(X)*J never leaves the chip).
 struct FuseF {
