@@ -6,6 +6,8 @@
 
 #if !defined(NIS_EXP_BITS) && defined(NIS_WM) && NIS_WM <= 8
 #define NIS_EXP_BITS 10         // narrow conditioners: VALU-issue bound, LDS to spare -> 1024-entry exp table + cubic (nis_common.h)
+#elif !defined(NIS_EXP_BITS)
+#define NIS_EXP_BITS 8          // matrix-core units: 256 entries + quartic fit beside the LDS image of the apply kernel
 #endif
 #include "flow_kernels.h"
 
@@ -267,7 +269,7 @@ static size_t mf_ring_bytes_n(const CellK& c, int ncb) {
   const size_t ring = (size_t)(NIS_MF_TPB / 64) * mf_cb_tiles(c.T, c.out, c.R, ncb) * 256 * sizeof(double);
   return std::max<size_t>(ring, 3 * NIS_MF_TPB * sizeof(double));
 }
-static const size_t MF_STATIC_LDS = 6 * 1024;            // static LDS of k_cell_apply_mfma: 5.4 KB
+static const size_t MF_STATIC_LDS = 7 * 1024;            // static LDS of k_cell_apply_mfma: 6.8 KB (2 KB of it the exp table)
 // columns per bijector batch: four (every lane busy in the bijector phase) unless the image of four columns leaves ONE workgroup
 // per CU while two or one column(s) would admit two -- one wave per SIMD hides nothing (C3 ran at 2x its MFMA + VALU time)
 static int mf_pick_ncb(const CellK& c) {

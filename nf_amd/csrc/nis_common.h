@@ -71,10 +71,27 @@ static __device__ const double NIS_EXP_TAB[64] = {
 #define NIS_EXP_BITS 6      // flow_wm.hip selects 10 for the narrow (VALU) units: +2.5 % on the C2 step; the matrix-core kernels lose a workgroup per CU to the 8 KB table
 #endif
 #define NIS_EXP_N (1 << NIS_EXP_BITS)
-#if NIS_EXP_BITS == 10
-// 1024-entry table (8 KB of LDS, tools/gen_exp_table.py): |r| <= ln2/2048 = 3.4e-4, where a CUBIC is enough -- its quadratic
-// coefficient absorbs the r^4/24 term (best b r^2 fit, residual 1e-16) -- two FMAs fewer per exp than the 64-entry / degree-5
-// form; max error 3.1e-16 relative (1.4 ulp; 2.0e7 random arguments in [-700, 700] against expl).
+#if NIS_EXP_BITS == 8
+// 256-entry table (2 KB of LDS) + degree-4 Taylor polynomial: one FMA fewer per exp than the 64-entry / degree-5 form, and small
+// enough to sit beside the matrix-core apply kernel's LDS image without costing the second workgroup per CU.
+#include "nis_exp_tab10.h"
+__device__ __forceinline__ void nis_exp_init(double* lds_tab) {
+  for (int i = threadIdx.x; i < NIS_EXP_N; i += blockDim.x) lds_tab[i] = NIS_EXP_TAB8[i];
+}
+__device__ __forceinline__ double nis_exp(double x, const double* lds_tab) {
+  const double kd = fma(x, 0x1.71547652b82fep+8, 0x1.8p+52);      // k = rint(256 x / ln 2) in the low word (see below)
+  const double k = kd - 0x1.8p+52;
+  double r = fma(k, -0x1.62e42fef00000p-9, x);
+  r = fma(k, -0x1.473de6af278edp-42, r);
+  const int ki = __double2loint(kd);
+  const double T = lds_tab[ki & 255];
+  double p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
+  p = fma(r, p, 0.5);
+  p = fma(r, p, 1.0);
+  p = r * p;
+  return ldexp(fma(T, p, T), ki >> 8);
+}
+#elif NIS_EXP_BITS == 10
 #include "nis_exp_tab10.h"
 __device__ __forceinline__ void nis_exp_init(double* lds_tab) {
   for (int i = threadIdx.x; i < NIS_EXP_N; i += blockDim.x) lds_tab[i] = NIS_EXP_TAB10[i];
