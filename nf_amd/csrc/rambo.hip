@@ -174,13 +174,21 @@ __global__ __launch_bounds__(256) void k_pdf_xfx(nis_pdf1d t, const double* __re
 // The row-major OUTPUT goes through LDS: the (RB_TPB x 4(n+2)) momenta are written to a padded LDS image and stored as
 // contiguous 8-byte-per-lane streams; without staging every lane would write 16 bytes into its own 128-byte line per
 // instruction (row stride 128-384 B).  Inputs are prefetched into registers one tile ahead (see `fetch`).
+#ifndef RB_NT
+#define RB_NT 0             // 1: non-temporal hints on the streamed rows in / momenta out (A/B)
+#endif
 typedef double nis_d2 __attribute__((ext_vector_type(2)));
 // 16-byte global loads the compiler does not track (see k_rambo): NV of them off one row pointer, 16 bytes apart
 template <int NV, int NR>
 __device__ __forceinline__ void rb_issue_row(nis_d2 (&raw)[NR], const double* p) {
   static_assert(NV <= NR, "row wider than its register image");
+#if RB_NT
+#define RB_LOAD_MOD " nt"
+#else
+#define RB_LOAD_MOD ""
+#endif
 #define RB_ISSUE16(J) \
-  if constexpr (NV > J) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(raw[J]) : "v"(p), "n"(16 * J) : "memory");
+  if constexpr (NV > J) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" RB_LOAD_MOD : "=&v"(raw[J]) : "v"(p), "n"(16 * J) : "memory");
   RB_ISSUE16(0) RB_ISSUE16(1) RB_ISSUE16(2) RB_ISSUE16(3) RB_ISSUE16(4) RB_ISSUE16(5) RB_ISSUE16(6) RB_ISSUE16(7)
   RB_ISSUE16(8) RB_ISSUE16(9) RB_ISSUE16(10) RB_ISSUE16(11) RB_ISSUE16(12) RB_ISSUE16(13) RB_ISSUE16(14) RB_ISSUE16(15)
 #undef RB_ISSUE16
@@ -459,6 +467,8 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
         const nis_d2 v = {src[s_ * (LM + 1) + q], src[s_ * (LM + 1) + q + 1]};
 #ifdef RB_ABLATE_STORE                                   // timing-only build: everything but the momenta stores (results wrong)
         if (v.x == 1.2345e300) *reinterpret_cast<nis_d2*>(dst + e) = v;
+#elif RB_NT
+        __builtin_nontemporal_store(v, reinterpret_cast<nis_d2*>(dst + e));
 #else
         *reinterpret_cast<nis_d2*>(dst + e) = v;
 #endif
