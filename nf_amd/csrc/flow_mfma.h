@@ -37,9 +37,15 @@ __host__ __device__ inline int mf_cb_tiles(int T, int out, int R, int ncb_cols) 
   return mx;
 }
 
+#ifndef NIS_MF_ST
+#define NIS_MF_ST 2
+#endif
+#ifndef NIS_MF_WAVES
+#define NIS_MF_WAVES 2                 // waves per SIMD the apply kernel is allocated for (K <= 16)
+#endif
 template <int WM>
 struct MfCfg {
-  static constexpr int ST = 2;                     // sample tiles (of 16) per wave: keeps VGPR+AGPR <= 256 -> 2 waves/SIMD,
+  static constexpr int ST = NIS_MF_ST;             // sample tiles (of 16) per wave: keeps VGPR+AGPR <= 256 -> 2 waves/SIMD,
                                                    // so one wave's MFMA phase overlaps the other's VALU (exp / bijector) phase
   static constexpr int JT = WM / 16;               // output row tiles of a hidden layer
   static constexpr int KQ = WM / 4;                // k-steps of a hidden layer
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(NIS_MF_TPB) void k_bn_stats_mfma(CellK c, const dou
 // pass-through: column p of lane group p % 4) and combine them with two shuffles, like the Jacobian product -- and with
 // fz.write_planes == 0 neither the transformed columns nor the Jacobian are stored (nothing reads them).
 template <int KIND, int WM, int KM, bool KEXACT, bool FUSE = false>
-__global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? 2 : 1) void k_cell_apply_mfma(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
+__global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? NIS_MF_WAVES : 1) void k_cell_apply_mfma(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                                 int* __restrict__ bins_out, const double* __restrict__ wm_all,
                                                                 const double* __restrict__ wm_last, const double* __restrict__ bias_pad,
                                                                 FuseF fz) {

@@ -276,7 +276,7 @@ static int mf_pick_ncb(const CellK& c) {
   static const int forced = getenv("NIS_MF_NCB") ? atoi(getenv("NIS_MF_NCB")) : 0;
   if (forced == 1 || forced == 2 || forced == 4) return forced;
   for (int n = NIS_MF_NCB; n >= 1; n >>= 1)
-    if (2 * (mf_ring_bytes_n(c, n) + MF_STATIC_LDS) <= 160 * 1024) return n;
+    if (NIS_MF_WAVES * (mf_ring_bytes_n(c, n) + MF_STATIC_LDS) <= 160 * 1024) return n;
   return NIS_MF_NCB;
 }
 static size_t mf_ring_bytes(const CellK& c) { return mf_ring_bytes_n(c, mf_pick_ncb(c)); }
@@ -290,7 +290,7 @@ template <>
 int mfma_blocks_per_cu<NIS_WM>(const CellK& c) {
   const size_t lds = mf_ring_bytes(c) + MF_STATIC_LDS;
   int n = (int)(160 * 1024 / lds);
-  return n < 1 ? 1 : n > 2 ? 2 : n;               // <= 256 VGPR+AGPR per lane: two waves per SIMD when the LDS images fit
+  return n < 1 ? 1 : n > NIS_MF_WAVES ? NIS_MF_WAVES : n;   // <= 256 VGPR+AGPR per lane: two waves per SIMD when the LDS images fit
 }
 
 template <>
