@@ -994,7 +994,7 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
   if (bn_mode == NIS_BN_TRAIN) {
     if (need_stats0) {
       NisProfScope ps(NIS_K_STATS, s);
-      HIP_OK(launch_stats<WM>(c, planes, ld, N, 0, grid_stats, s));
+      HIP_OK(launch_stats<WM>(c, planes, ld, N, 0, c.dcov ? c.nparts[0] : grid_stats, s));
       if (int rc = sync_records(o, c.partials, c.nparts[0], WM, s)) return rc;
     }
     if (!c.pmerge) HIP_OK(launch_finalize<WM>(c, 0, s));
@@ -1330,6 +1330,16 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       c.coef_gs = train ? (cd.n_hidden + 1) * 2 * L.WM : 0;     // eval: every batch shares the running-stat coefficients
       c.plane_gs = plane_gs;
       c.derive1 = (train && cd.P == 1 && !env_int("NIS_NO_DERIVE1", 0)) ? 1 : 0;
+      // matrix-core cells with 2..8 pass-through columns: BN_0's records carry the co-moments of the block, BN_1 is derived from
+      // them and the layer-1 statistics launch is skipped (not with the multi-rank record exchange: its records are per feature)
+      c.dcov = (train && mfma && cd.P >= 2 && cd.P <= 8 && cd.n_hidden >= 2 && 3 * cd.P + cd.P * (cd.P - 1) / 2 <= 3 * L.WM && !o.sync_fn &&
+                have_stats0 == false && !env_int("NIS_NO_DERIVE1", 0) && !env_int("NIS_NO_DCOV", 0)) ? 1 : 0;
+      if (c.dcov) {
+        c.derive1 = 1;
+        // the covariance pass is a latency-bound stream (8 loads, 44 FMAs per sample, <= 128 VGPRs): two workgroups per CU (four: equal at G = 3, slower at G = 1 -- every consumer merges the records)
+        static const int bpc_cov = env_int("NIS_COV_BPC", 2);
+        c.nparts[0] = grid_for(bpc_cov, Gg, N, 256);
+      }
       // single pass-through column on the fp64 VALU kernels: BN_0, Linear_0 and BN_1 collapse into one affine map of x
       // (needs the layer-1 statistics launch to be gone: train mode with derive1, or eval mode)
       c.fold = (cd.P == 1 && !mfma && (c.derive1 || !train) && !env_int("NIS_NO_FOLD", 0)) ? 1 : 0;

@@ -129,7 +129,102 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
         red[3 * TPB - 2] = fmax(s2 - s1 * s1 / n, 0.0) / n;
         red[3 * TPB - 1] = scale;
       }
+      if (WM >= 16 && fresh == 0 && c.derive1 && c.dcov && j < F) {     // covariance form: every pass-through feature's statistics
+        red[3 * TPB - 64 + j] = ref + s1 / n;                            // mean_a
+        red[3 * TPB - 48 + j] = fmax(s2 - s1 * s1 / n, 0.0) / n;         // biased variance
+        red[3 * TPB - 32 + j] = scale;                                   // scale0_a
+      }
     }
+    if (WM >= 16 && d1 && c.dcov) {
+      // 2 <= P <= 8: h1_j = sum_a W0[j][a] (scale0_a x_a + shift0_a) is affine in the pass-through block, hence
+      //   mean(h1_j) = sum_a W0[j][a] beta0_a,   var_b(h1_j) = sum_ab (W0[j][a] scale0_a) (W0[j][b] scale0_b) Cov(x_a, x_b)
+      // The co-moments C_ab sit behind the P feature records of every BN_0 record (k_bn_stats0_cov); merged like the M2's:
+      //   C_ab = sum_blocks [C_ab^blk + n_blk dl_a dl_b] - n (M_a - ref_a)(M_b - ref_b),   dl = block mean - ref.
+      __syncthreads();
+      const int P = c.P, npair = P * (P - 1) / 2;
+      int pa = 0, pb = 1;
+      {
+        int m = j;                                    // pair index -> (a, b), a < b
+        for (int a = 0; a < P - 1; ++a) {
+          const int row = P - 1 - a;
+          if (m < row) { pa = a; pb = a + 1 + m; break; }
+          m -= row;
+        }
+      }
+      double acc = 0.0;
+      if (j < npair) {
+        const double ra = part[pa * 3 + 1], rb = part[pb * 3 + 1];
+        for (int b = s; b < np; b += S) {
+          const double* q = part + (size_t)b * WM * 3;
+          const double nb = q[0];
+          acc += fma(nb * (q[pa * 3 + 1] - ra), q[pb * 3 + 1] - rb, q[3 * P + j]);
+        }
+      }
+      red[s * WM + j] = acc;
+      __syncthreads();
+#pragma unroll
+      for (int h = S / 2; h > 0; h >>= 1) {
+        if (s < h) red[s * WM + j] += red[(s + h) * WM + j];
+        __syncthreads();
+      }
+      if (s == 0 && j < npair) {
+        const double n = red[3 * TPB - 4];
+        const double ra = part[pa * 3 + 1], rb = part[pb * 3 + 1];
+        const double cab = (red[j] - n * (red[3 * TPB - 64 + pa] - ra) * (red[3 * TPB - 64 + pb] - rb)) / n;
+        red[3 * TPB - 128 + pa * 8 + pb] = cab;
+        red[3 * TPB - 128 + pb * 8 + pa] = cab;
+      }
+      if (s == 0 && j < P) red[3 * TPB - 128 + j * 8 + j] = red[3 * TPB - 48 + j];
+      __syncthreads();
+      if (tid < WM) {
+        const double n = red[3 * TPB - 4];
+        const int F1 = cellk_feat(c, 1);
+        double scale = 0.0, shift = 0.0, mean1 = 0.0, var1 = 0.0;
+        if (tid < F1) {
+          double t[8];
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            const double w = a < P ? c.wp[(size_t)tid * WM + a] : 0.0;
+            mean1 = fma(w, a < P ? c.gb[1 * WM + a] : 0.0, mean1);                 // scale0_a mean_a + shift0_a = beta0_a
+            t[a] = a < P ? w * red[3 * TPB - 32 + a] : 0.0;
+          }
+#pragma unroll
+          for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+              if (a < P && b < P) var1 = fma(t[a] * t[b], red[3 * TPB - 128 + a * 8 + b], var1);
+          var1 = fmax(var1, 0.0);
+          const double gam = c.gb[(1 * 2 + 0) * WM + tid], be = c.gb[(1 * 2 + 1) * WM + tid];
+          scale = gam / sqrt(var1 + NIS_BN_EPS);
+          shift = be - mean1 * scale;
+          if (writer) {
+            const double unb = n > 1.0 ? var1 * (n / (n - 1.0)) : var1;
+            const double mean1_r = mean1 + (c.hb ? c.hb[1 * WM + tid] : 0.0);
+            if (c.G == 1) {
+              double* run = c.running + cellk_running_off(c, 1);
+              run[tid] = (1.0 - NIS_BN_MOM) * run[tid] + NIS_BN_MOM * mean1_r;
+              run[F1 + tid] = (1.0 - NIS_BN_MOM) * run[F1 + tid] + NIS_BN_MOM * unb;
+              if (tid == 0 && c.tracked) c.tracked[1] += 1;
+            } else {
+              c.gstat[(((size_t)1 * c.G + g) * 2 + 0) * WM + tid] = mean1_r;
+              c.gstat[(((size_t)1 * c.G + g) * 2 + 1) * WM + tid] = unb;
+            }
+          }
+        }
+        lds_coef[(1 * 2 + 0) * WM + tid] = scale;
+        lds_coef[(1 * 2 + 1) * WM + tid] = shift;
+        if (writer) {
+          coef_g[(1 * 2 + 0) * WM + tid] = scale;
+          coef_g[(1 * 2 + 1) * WM + tid] = shift;
+          if (c.bnsave && c.G == 1) {
+            c.bnsave[(1 * 4 + 0) * WM + tid] = scale;
+            c.bnsave[(1 * 4 + 1) * WM + tid] = shift;
+            c.bnsave[(1 * 4 + 2) * WM + tid] = mean1;
+            c.bnsave[(1 * 4 + 3) * WM + tid] = tid < F1 ? 1.0 / sqrt(var1 + NIS_BN_EPS) : 0.0;
+          }
+        }
+      }
+    } else
     if (d1) {
       // P == 1: the pre-BN_1 activation h1_j = W0[j][0] * (scale0 * x + shift0) is affine in x, hence
       //   mean(h1_j) = W0[j][0] * (scale0 * mean0 + shift0),   var_b(h1_j) = (W0[j][0] * scale0)^2 * var_b(x)
@@ -507,6 +602,90 @@ __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __
     cnt += valid ? 1.0 : 0.0;
   }
   emit_records<WM, NW>(S1, S2, cnt, wshift, wmom, WM, c.partials + (((size_t)LAYER * c.G + g) * c.maxb + blockIdx.x) * WM * 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BN_0 records WITH the co-moments of the pass-through block (2 <= P <= 8): (n, mean_a, M2_a) per feature as k_bn_stats writes
+// them, and behind them C_ab = sum (x_a - mean_a)(x_b - mean_b) for a < b (slot 3 P + cellk_pair(P, a, b)).  BN_1's batch
+// statistics follow from these (load_coefs, CellK::dcov), so the layer-1 statistics launch of a matrix-core cell -- a full
+// launch with its prologue for 8 MFMAs per 32 samples -- is gone.  Sums are taken about the workgroup's first sample.
+template <int WM, int TPB>
+__global__ __launch_bounds__(TPB) void k_bn_stats0_cov(CellK c, const double* __restrict__ planes, long ld, long N) {
+  constexpr int PM = 8, NS2 = PM * (PM + 1) / 2, NV = PM + NS2 + 1, NW = TPB / 64;
+  __shared__ double wsum[NW][NV];
+  __shared__ double tot[NV];
+  __shared__ double lsh[PM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = c.g0 + blockIdx.y, P = c.P;
+  planes += (size_t)g * c.plane_gs;
+  const long i_blk = (long)blockIdx.x * TPB;
+  double sh[PM];
+#pragma unroll
+  for (int p = 0; p < PM; ++p) sh[p] = (p < P && i_blk < N) ? planes[(size_t)c.in_plane[p] * ld + i_blk] : 0.0;
+  if (tid == 0) {
+#pragma unroll
+    for (int p = 0; p < PM; ++p) lsh[p] = sh[p];
+  }
+  double S1[PM], S2[NS2];
+#pragma unroll
+  for (int p = 0; p < PM; ++p) S1[p] = 0.0;
+#pragma unroll
+  for (int k = 0; k < NS2; ++k) S2[k] = 0.0;
+  double cnt = 0.0;
+  const long stride = (long)gridDim.x * TPB;
+  for (long i = i_blk + tid; i < N; i += stride) {
+    double x[PM];
+#pragma unroll
+    for (int p = 0; p < PM; ++p) x[p] = p < P ? planes[(size_t)c.in_plane[p] * ld + i] - sh[p] : 0.0;
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < PM; ++a) {
+      S1[a] += x[a];
+#pragma unroll
+      for (int b = a; b < PM; ++b, ++k) S2[k] = fma(x[a], x[b], S2[k]);
+    }
+    cnt += 1.0;
+  }
+#pragma unroll
+  for (int p = 0; p < PM; ++p) {
+    const double v = wave_sum(S1[p]);
+    if (lane == 0) wsum[wave][p] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < NS2; ++k) {
+    const double v = wave_sum(S2[k]);
+    if (lane == 0) wsum[wave][PM + k] = v;
+  }
+  {
+    const double v = wave_sum(cnt);
+    if (lane == 0) wsum[wave][NV - 1] = v;
+  }
+  __syncthreads();
+  if (tid < NV) {
+    double v = 0.0;
+    for (int w = 0; w < NW; ++w) v += wsum[w][tid];
+    tot[tid] = v;
+  }
+  __syncthreads();
+  double* out = c.partials + (((size_t)0 * c.G + g) * c.maxb + blockIdx.x) * WM * 3;
+  const double n = tot[NV - 1];
+  auto s2at = [&](int a, int b) { return tot[PM + a * PM - a * (a - 1) / 2 + (b - a)]; };      // a <= b
+  if (tid < P) {
+    const double s1 = tot[tid];
+    out[tid * 3 + 0] = n;
+    out[tid * 3 + 1] = n > 0.0 ? lsh[tid] + s1 / n : 0.0;
+    out[tid * 3 + 2] = n > 0.0 ? fmax(s2at(tid, tid) - s1 * s1 / n, 0.0) : 0.0;
+  }
+  const int npair = P * (P - 1) / 2;
+  if (tid >= 64 && tid < 64 + npair) {
+    int m = tid - 64, pa = 0, pb = 1;
+    for (int a = 0; a < P - 1; ++a) {
+      const int row = P - 1 - a;
+      if (m < row) { pa = a; pb = a + 1 + m; break; }
+      m -= row;
+    }
+    out[3 * P + (tid - 64)] = n > 0.0 ? s2at(pa, pb) - tot[pa] * tot[pb] / n : 0.0;
+  }
 }
 
 // G > 1: one workgroup per batch merges the records of BN layer `layer` and publishes scale / shift (+ the batch

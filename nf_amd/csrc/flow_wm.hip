@@ -17,6 +17,12 @@
 
 template <>
 hipError_t launch_stats<NIS_WM>(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s) {
+#if NIS_WM >= 16
+  if (layer == 0 && c.dcov) {                      // BN_0 records with the pass-through co-moments (BN_1 is derived from them)
+    hipLaunchKernelGGL((k_bn_stats0_cov<NIS_WM, 256>), dim3(grid, c.Gy), dim3(256), 0, s, c, planes, ld, N);
+    return hipGetLastError();
+  }
+#endif
   constexpr int TPB = nis_stats_tpb(NIS_WM);
 #if NIS_WM == 4
   if (c.wx == 3) {                       // every layer at most 3 wide (README / C1 / C2 nets): 3x3 blocks instead of 4x4

@@ -226,7 +226,9 @@ struct CellK {
   int wplanar;                           // 1 (in-kernel draws): w is two float32 column planes (column c at wrows + c * wplane_ld), not rows:
   long wplane_ld;                        //   a pass reads only the column it needs (4 instead of 8 B/sample)
   // ---- training history (for the adjoint kernels): outputs go to the NEXT plane set, BN statistics are kept
-  int derive1;                           // 1 (P == 1): BN_1's batch statistics follow analytically from BN_0's
+  int derive1;                           // 1: BN_1's batch statistics follow analytically from BN_0's (P == 1, or dcov)
+  int dcov;                              // 1 (matrix-core cells, 2 <= P <= 8): BN_0's records carry the P x P co-moments of the pass-through block
+                                         //   (k_bn_stats0_cov) and BN_1 is derived from them: h1 = W0 bn0(x) is affine in x
                                          //   (h1_j = W0_j0 * BN_0(x) is affine in the single pass-through column),
                                          //   so the layer-1 statistics launch is skipped
   int fold;                              // 1 (P == 1, fp64 VALU kernels): BN_0, Linear_0, BN_1 evaluated as ONE affine map of x (fold_coefs)
@@ -237,6 +239,8 @@ struct CellK {
 
 __host__ __device__ static inline int cellk_feat(const CellK& c, int l) { return l == 0 ? c.P : c.width[l - 1]; }
 // BN layer whose records the prologue of a launch that needs the coefficients of layers < upto has to merge (G == 1)
+// co-moment slot of the pair (a < b) behind the P feature records of a BN_0 record with covariance (CellK::dcov)
+__host__ __device__ static inline int cellk_pair(int P, int a, int b) { return a * P - a * (a + 1) / 2 + (b - a - 1); }
 __host__ __device__ static inline int cellk_fresh(const CellK& c, int upto) { return (c.derive1 && upto == 2) ? 0 : upto - 1; }
 // offset (in doubles) of BN layer l inside the reference-order running-stat blob
 __host__ __device__ static inline int cellk_running_off(const CellK& c, int l) {

@@ -1174,6 +1174,41 @@ def test_wide_forward_large_batch_vs_reference(tag, g_wide):
 
 
 @pytest.mark.parametrize("tag", ["C3", "C5"])
+def test_bn1_derived_from_the_pass_through_covariance(tag, g_wide, monkeypatch):
+    """Matrix-core cells with 2..8 pass-through columns skip the layer-1 statistics launch: BN_0's records carry the co-moments of
+    the block (k_bn_stats0_cov) and BN_1's batch mean / variance follow from h1 = W0 bn0(x) (load_coefs, CellK::dcov).  Against
+    the measured path (NIS_NO_DCOV=1) on the same batch: values, Jacobians and every running statistic, G = 1 and G = 3."""
+    case = f"fwd_{tag}"
+    m = g_wide.meta[case]
+    N = 50_000 + 37
+
+    def run(no_dcov, G):
+        if no_dcov:
+            monkeypatch.setenv("NIS_NO_DCOV", "1")
+        else:
+            monkeypatch.delenv("NIS_NO_DCOV", raising=False)
+        NF = build_manager(m, g_wide.sub(case, "sd"))
+        model = NF._model
+        model.train()
+        eng = model.engine()
+        w = torch.as_tensor(kronecker_w(G * N, m["d"]).reshape(G, N, m["d"])).to(dev())
+        planes = torch.empty((G, eng.d + 1, N), dtype=torch.double, device=dev())
+        out4 = torch.zeros((G, 4), dtype=torch.double, device=dev())
+        from nf_amd import _lib
+        eng.integrate_steps(w, True, _lib.NIS_F_ONE, [], out4, planes=planes)
+        torch.cuda.synchronize()
+        return t2n(planes), t2n(out4), {k: t2n(v) for k, v in model.state_dict().items()}
+
+    for G in (1, 3):
+        pa, oa, sa = run(False, G)
+        pb, ob, sb = run(True, G)
+        np.testing.assert_allclose(pa, pb, rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(oa, ob, rtol=1e-10)
+        for k in sb:
+            np.testing.assert_allclose(sa[k], sb[k], rtol=1e-10, atol=1e-14, err_msg=k)
+
+
+@pytest.mark.parametrize("tag", ["C3", "C5"])
 def test_wide_adjoint_vs_reference_autograd(tag, g_wide):
     """The matrix-core adjoint kernels (flow_bwd_wm.hip) against the REFERENCE's autograd: gradients of every parameter and
     of the input for a fixed random cotangent on XJ, C3 / C5 topologies, train-mode BN, N = 512."""
