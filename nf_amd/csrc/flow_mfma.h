@@ -57,17 +57,24 @@ __device__ __forceinline__ void mf_load_input(const CellK& c, const double* plan
                                               const double* lds_coef, double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST]) {
   constexpr int ST = MfCfg<WM>::ST, KQ = MfCfg<WM>::KQ;
   const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+  const int nq = (c.P + 3) / 4;                      // k-steps that hold pass-through columns (wave-uniform: no exec-masked loads)
+  const bool whole = base + 16 * ST <= N;            // wave-uniform: every sample of the wave's tiles exists
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
-    const int k = 4 * q + g;
-    const bool kv = k < c.P;
-    const size_t pl = kv ? (size_t)lds_plane[k] * ld : 0;
-    const double sc = kv ? lds_coef[k] : 0.0, sh = kv ? lds_coef[WM + k] : 0.0;
+    if (q < nq) {
+      const int k = 4 * q + g;
+      const bool kv = k < c.P;
+      const size_t pl = (size_t)lds_plane[kv ? k : 0] * ld;
+      const double sc = kv ? lds_coef[k] : 0.0, sh = kv ? lds_coef[WM + k] : 0.0;
 #pragma unroll
-    for (int st = 0; st < ST; ++st) {
-      const long i = base + 16 * st + s;
-      const double x = (kv && i < N && 4 * q < c.P) ? planes[pl + i] : 0.0;
-      H[q][st] = kv ? fma(x, sc, sh) : 0.0;
+      for (int st = 0; st < ST; ++st) {
+        const long i = base + 16 * st + s;
+        const double x = planes[pl + (whole || i < N ? i : base)];       // a ragged tile re-reads an existing sample (masked below)
+        H[q][st] = (whole || i < N) ? fma(x, sc, sh) : 0.0;              // sc = sh = 0 for the padding columns
+      }
+    } else {
+#pragma unroll
+      for (int st = 0; st < ST; ++st) H[q][st] = 0.0;
     }
   }
 }
@@ -123,8 +130,11 @@ __device__ __forceinline__ void mf_hidden(const CellK& c, const double* wm_all, 
 
 // ---------------------------------------------------------------------------------------------
 // Batch statistics of BN layer `layer` >= 1 (pre-BN accumulators of Linear_{layer-1}).
+#ifndef NIS_MF_STATS_WAVES
+#define NIS_MF_STATS_WAVES 1
+#endif
 template <int WM>
-__global__ __launch_bounds__(NIS_MF_TPB) void k_bn_stats_mfma(CellK c, const double* __restrict__ planes, long ld, long N, int layer,
+__global__ __launch_bounds__(NIS_MF_TPB, NIS_MF_STATS_WAVES) void k_bn_stats_mfma(CellK c, const double* __restrict__ planes, long ld, long N, int layer,
                                                               const double* __restrict__ wm_all) {
   constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ, NW = NIS_MF_TPB / 64;
   __shared__ double lds_coef[NIS_MAX_HIDDEN * 2 * WM];
@@ -157,18 +167,32 @@ __global__ __launch_bounds__(NIS_MF_TPB) void k_bn_stats_mfma(CellK c, const dou
         for (int r = 0; r < 4; ++r) shf[jt][r] = __shfl(acc[jt][0][r], lane & 48, 64);
       first = false;
     }
+    if (base + 16 * ST <= N) {                       // whole tiles (wave-uniform): no per-lane masks
+      if (gq == 0) cnt += (double)ST;
 #pragma unroll
-    for (int st = 0; st < ST; ++st) {
-      const bool ok = base + 16 * st + s < N;
-      if (gq == 0 && ok) cnt += 1.0;
+      for (int st = 0; st < ST; ++st)
 #pragma unroll
-      for (int jt = 0; jt < JT; ++jt)
+        for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double t = ok ? acc[jt][st][r] - shf[jt][r] : 0.0;
-          S1[jt][r] += t;
-          S2[jt][r] = fma(t, t, S2[jt][r]);
-        }
+          for (int r = 0; r < 4; ++r) {
+            const double t = acc[jt][st][r] - shf[jt][r];
+            S1[jt][r] += t;
+            S2[jt][r] = fma(t, t, S2[jt][r]);
+          }
+    } else {
+#pragma unroll
+      for (int st = 0; st < ST; ++st) {
+        const bool ok = base + 16 * st + s < N;
+        if (gq == 0 && ok) cnt += 1.0;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double t = ok ? acc[jt][st][r] - shf[jt][r] : 0.0;
+            S1[jt][r] += t;
+            S2[jt][r] = fma(t, t, S2[jt][r]);
+          }
+      }
     }
   }
   // reduce over the 16 samples of a row group (lanes with equal lane>>4), then over the count (held by group 0)
