@@ -79,6 +79,45 @@ __device__ __forceinline__ void mf_load_input(const CellK& c, const double* plan
   }
 }
 
+// The same in two halves for a software-pipelined caller (P <= 4 PQ): `mf_issue_input` only requests the raw pass-through values of
+// the tiles at `base` (a ragged tile re-reads an existing sample), `mf_finish_input` turns them into B operands one iteration later.
+template <int WM, int PQ>
+__device__ __forceinline__ void mf_issue_input(const CellK& c, const double* planes, long ld, long N, long base, const int* lds_plane,
+                                               double (&xr)[PQ][MfCfg<WM>::ST]) {
+  constexpr int ST = MfCfg<WM>::ST;
+  const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+  const bool whole = base + 16 * ST <= N;
+#pragma unroll
+  for (int q = 0; q < PQ; ++q) {
+    const int k = 4 * q + g;
+    const size_t pl = (size_t)lds_plane[k < c.P ? k : 0] * ld;
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+      const long i = base + 16 * st + s;
+      xr[q][st] = planes[pl + ((whole || i < N) ? i : base)];
+    }
+  }
+}
+template <int WM, int PQ>
+__device__ __forceinline__ void mf_finish_input(const CellK& c, long N, long base, const double* lds_coef, const double (&xr)[PQ][MfCfg<WM>::ST],
+                                                double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST]) {
+  constexpr int ST = MfCfg<WM>::ST, KQ = MfCfg<WM>::KQ;
+  const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+  const bool whole = base + 16 * ST <= N;
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+#pragma unroll
+    for (int st = 0; st < ST; ++st) H[q][st] = 0.0;
+    if (q < PQ) {
+      const int k = 4 * q + g;
+      const bool kv = k < c.P;
+      const double sc = kv ? lds_coef[k] : 0.0, sh = kv ? lds_coef[WM + k] : 0.0;
+#pragma unroll
+      for (int st = 0; st < ST; ++st) H[q][st] = (whole || base + 16 * st + s < N) ? fma(xr[q < PQ ? q : 0][st], sc, sh) : 0.0;
+    }
+  }
+}
+
 // One hidden Linear on the matrix cores: acc[jt][st] = sum_q Wm[jt][q] (x) H[q][st];  nq = k-steps actually populated.
 template <int WM>
 __device__ __forceinline__ void mf_dense(const double* __restrict__ wm, int nq, const double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST],
@@ -155,10 +194,21 @@ __global__ __launch_bounds__(NIS_MF_TPB, NIS_MF_STATS_WAVES) void k_bn_stats_mfm
   double cnt = 0.0;
   bool first = true;
   const long wstride = (long)gridDim.x * NW * 16 * ST;
-  for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
+  // the pass-through block of the NEXT pair of sample tiles is requested one iteration ahead (cells with P <= 8: two k-steps)
+  constexpr int PQ = 2;
+  const bool pin = NIS_MF_PREFETCH && c.P <= 4 * PQ;
+  double xin[PQ][ST];
+  const long base0 = ((long)blockIdx.x * NW + wave) * 16 * ST;
+  if (pin && base0 < N) mf_issue_input<WM, PQ>(c, planes, ld, N, base0, lds_plane, xin);
+  for (long base = base0; base < N; base += wstride) {
     double H[KQ][ST];
     nis_d4 acc[JT][ST];
-    mf_load_input<WM>(c, planes, ld, N, base, lds_plane, lds_coef, H);
+    if (pin) {
+      mf_finish_input<WM, PQ>(c, N, base, lds_coef, xin, H);
+      mf_issue_input<WM, PQ>(c, planes, ld, N, base + wstride < N ? base + wstride : base, lds_plane, xin);
+    } else {
+      mf_load_input<WM>(c, planes, ld, N, base, lds_plane, lds_coef, H);
+    }
     mf_hidden<WM>(c, wm_all, lds_coef, layer, H, acc);
     if (first) {                       // shift = value of the wave's first sample (lane with s == 0 of each row group)
 #pragma unroll
@@ -285,11 +335,22 @@ __global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? NIS_MF_WAVES : 1) void k_cel
   };
   const int ncb = (c.T + NCB - 1) / NCB;
   load_tile(0);
-  for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
+  // the pass-through block of the NEXT pair of sample tiles is requested one iteration ahead (cells with P <= 8: two k-steps)
+  constexpr int PQ = 2;
+  const bool pin = NIS_MF_PREFETCH && c.P <= 4 * PQ;
+  double xin[PQ][ST];
+  const long base0 = ((long)blockIdx.x * NW + wave) * 16 * ST;
+  if (pin && base0 < N) mf_issue_input<WM, PQ>(c, planes, ld, N, base0, lds_plane, xin);
+  for (long base = base0; base < N; base += wstride) {
     double H[KQ][ST];
     {
       nis_d4 acc[JT][ST];
-      mf_load_input<WM>(c, planes, ld, N, base, lds_plane, lds_coef, H);
+      if (pin) {
+        mf_finish_input<WM, PQ>(c, N, base, lds_coef, xin, H);
+        mf_issue_input<WM, PQ>(c, planes, ld, N, base + wstride < N ? base + wstride : base, lds_plane, xin);
+      } else {
+        mf_load_input<WM>(c, planes, ld, N, base, lds_plane, lds_coef, H);
+      }
       mf_hidden<WM>(c, wm_all, lds_coef, c.L, H, acc);
       mf_bn_relu<WM>(lds_coef + (size_t)c.L * 2 * WM, acc, H);
     }
