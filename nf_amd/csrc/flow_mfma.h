@@ -167,10 +167,70 @@ __device__ __forceinline__ void mf_hidden(const CellK& c, const double* wm_all, 
   }
 }
 
+// Register-resident hidden weights for the statistics kernel (<= 3 BN layers below the one measured, P <= 4 PQ): the fragments
+// of Linear_0 .. Linear_2 do not depend on the sample, and the kernel has ~90 VGPRs to spare at its two waves per SIMD, so they are
+// loaded ONCE per workgroup instead of 16 x 512 B from L2 per layer and pair of sample tiles (the loop's only memory traffic then
+// is the pass-through block).
+template <int WM, int PQ>
+struct MfWreg {
+  double w0[MfCfg<WM>::JT][PQ];
+  double w[2][MfCfg<WM>::JT][MfCfg<WM>::KQ];
+};
+template <int WM, int PQ>
+__device__ __forceinline__ void mf_wreg_load(const double* __restrict__ wm_all, int upto, MfWreg<WM, PQ>& W) {
+  constexpr int JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) W.w0[jt][q] = wm_all[((size_t)jt * KQ + q) * 64 + lane];
+#pragma unroll
+    for (int l = 1; l <= 2; ++l)
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) W.w[l - 1][jt][q] = l < upto ? wm_all[(size_t)l * WM * WM + ((size_t)jt * KQ + q) * 64 + lane] : 0.0;
+  }
+}
+template <int WM, int PQ>
+__device__ __forceinline__ void mf_hidden_reg(const CellK& c, const MfWreg<WM, PQ>& W, const double* lds_coef, int upto,
+                                              double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST], nis_d4 (&acc)[MfCfg<WM>::JT][MfCfg<WM>::ST]) {
+  constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ;
+  const int nq = (c.P + 3) / 4;
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+    for (int st = 0; st < ST; ++st) acc[jt][st] = nis_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < PQ; ++q)
+      if (q < nq) {
+#pragma unroll
+        for (int st = 0; st < ST; ++st) acc[jt][st] = __builtin_amdgcn_mfma_f64_16x16x4f64(W.w0[jt][q], H[q][st], acc[jt][st], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int l = 1; l <= 2; ++l) {
+    if (l < upto) {
+      mf_bn_relu<WM>(lds_coef + (size_t)l * 2 * WM, acc, H);
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+        for (int st = 0; st < ST; ++st) acc[jt][st] = nis_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+#pragma unroll
+          for (int st = 0; st < ST; ++st) acc[jt][st] = __builtin_amdgcn_mfma_f64_16x16x4f64(W.w[l - 1][jt][q], H[q][st], acc[jt][st], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Batch statistics of BN layer `layer` >= 1 (pre-BN accumulators of Linear_{layer-1}).
+#ifndef NIS_MF_WREG
+#define NIS_MF_WREG 1
+#endif
 #ifndef NIS_MF_STATS_WAVES
-#define NIS_MF_STATS_WAVES 1
+#define NIS_MF_STATS_WAVES 2
 #endif
 template <int WM>
 __global__ __launch_bounds__(NIS_MF_TPB, NIS_MF_STATS_WAVES) void k_bn_stats_mfma(CellK c, const double* __restrict__ planes, long ld, long N, int layer,
@@ -200,6 +260,9 @@ __global__ __launch_bounds__(NIS_MF_TPB, NIS_MF_STATS_WAVES) void k_bn_stats_mfm
   double xin[PQ][ST];
   const long base0 = ((long)blockIdx.x * NW + wave) * 16 * ST;
   if (pin && base0 < N) mf_issue_input<WM, PQ>(c, planes, ld, N, base0, lds_plane, xin);
+  const bool wres = NIS_MF_WREG && pin && layer <= 3;         // hidden weights resident in registers (mf_hidden_reg)
+  MfWreg<WM, PQ> Wr;
+  if (wres) mf_wreg_load<WM, PQ>(wm_all, layer, Wr);
   for (long base = base0; base < N; base += wstride) {
     double H[KQ][ST];
     nis_d4 acc[JT][ST];
@@ -209,7 +272,8 @@ __global__ __launch_bounds__(NIS_MF_TPB, NIS_MF_STATS_WAVES) void k_bn_stats_mfm
     } else {
       mf_load_input<WM>(c, planes, ld, N, base, lds_plane, lds_coef, H);
     }
-    mf_hidden<WM>(c, wm_all, lds_coef, layer, H, acc);
+    if (wres) mf_hidden_reg<WM, PQ>(c, Wr, lds_coef, layer, H, acc);
+    else mf_hidden<WM>(c, wm_all, lds_coef, layer, H, acc);
     if (first) {                       // shift = value of the wave's first sample (lane with s == 0 of each row group)
 #pragma unroll
       for (int jt = 0; jt < JT; ++jt)
