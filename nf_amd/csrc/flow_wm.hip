@@ -283,7 +283,9 @@ static int mf_pick_ncb(const CellK& c) {
   if (forced == 1 || forced == 2 || forced == 4) return forced;
   for (int n = NIS_MF_NCB; n >= 1; n >>= 1)
     if (NIS_MF_WAVES * (mf_ring_bytes_n(c, n) + MF_STATIC_LDS) <= 160 * 1024) return n;
-  return NIS_MF_NCB;
+  for (int n = NIS_MF_NCB; n >= 1; n >>= 1)                  // no batch size admits two workgroups: the largest that fits at all
+    if (mf_ring_bytes_n(c, n) + 24 * 1024 <= 160 * 1024) return n;
+  return 1;
 }
 static size_t mf_ring_bytes(const CellK& c) { return mf_ring_bytes_n(c, mf_pick_ncb(c)); }
 

@@ -76,7 +76,10 @@ def test_cell_vs_reference_golden(case, g_cells):
 
 @pytest.mark.parametrize("kind,d,P,K,NN,N", [("pwquad", 2, 1, 4, [3, 3, 3], 5000), ("pwquad", 6, 2, 9, [12, 5], 3001),
                                              ("pwlin", 4, 2, 50, [9], 4097), ("pwquad", 12, 5, 20, [40, 33], 2500),
-                                             ("pwlin", 9, 3, 128, [64, 64], 700), ("pwquad", 3, 2, 32, [2, 2, 2, 2], 999)])
+                                             ("pwlin", 9, 3, 128, [64, 64], 700), ("pwquad", 3, 2, 32, [2, 2, 2, 2], 999),
+                                             # matrix-core heads whose LDS image decides the columns per bijector batch (CellK::mf_ncb)
+                                             ("pwlin", 5, 2, 128, [32, 32], 600), ("pwquad", 6, 3, 32, [32, 32], 800),
+                                             ("pwlin", 8, 4, 64, [32, 32, 32], 1500)])
 @pytest.mark.parametrize("train", [True, False])
 def test_cell_vs_oracle_seeded(kind, d, P, K, NN, N, train):
     from nf_amd.normalizing_flows.layers.coupling_cells import PWLin, PWQuad
