@@ -513,11 +513,28 @@ __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __
   const long stride = (long)gridDim.x * TPB;
   long wbase = (long)blockIdx.x * TPB + wave * NIS_WAVE;          // wave-uniform: index of lane 0's next sample
   bool full = wbase + (U - 1) * stride + NIS_WAVE <= N;           // wave-uniform: U whole tiles ahead
-  double x_first = 0.0, x[U];
+  // raw loads (no conversion on them): the values of the NEXT trip are requested before the current one is computed and first
+  // touched one whole trip later, so the wave waits on nothing but its own arithmetic (a float -> double conversion right behind
+  // the load put the full memory latency in front of every trip)
+  struct Raw {
+    double d;
+    float f;
+    nis_f2 r;
+  };
+  auto load_raw = [&](long tile0, int l) -> Raw {                // tile0 wave-uniform, l = lane
+    Raw v = {0.0, 0.f, {0.f, 0.f}};
+    if (!ROWS) v.d = (px + tile0)[l];
+    else if (PLN) v.f = (wpl + tile0)[l];
+    else v.r = (wr + tile0)[l];
+    return v;
+  };
+  auto to_x = [&](const Raw& v) -> double { return !ROWS ? v.d : PLN ? (double)v.f : (double)(wcol1 ? v.r.y : v.r.x); };
+  double x_first = 0.0;
+  Raw xr[U];
   auto first_loads = [&]() {
     x_first = wbase < N ? sample(wbase, 0) : 0.0;
 #pragma unroll
-    for (int u = 0; u < U; ++u) x[u] = full ? sample(wbase + u * stride, lane) : 0.0;
+    for (int u = 0; u < U; ++u) xr[u] = load_raw(full ? wbase + u * stride : 0, lane);       // not full: a valid address, unused
   };
   load_coefs<WM, TPB>(c, g, LAYER, c.pmerge ? cellk_fresh(c, LAYER) : -1, blockIdx.x == 0, lds_coef, red, first_loads);
   fold_coefs<WM>(c, lds_coef, LAYER, w_fold);
@@ -569,8 +586,16 @@ __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __
 #pragma unroll
   for (int j = 0; j < WM; ++j) S1[j] = S2[j] = 0.0;
   double cnt = 0.0;
-  // whole tiles, no guards (U loads of 512 B in flight per wave; the first U were requested above the prologue)
+  // whole tiles, no guards (U loads in flight per wave, requested one trip ahead; the first U above the prologue)
   while (full) {
+    double x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = to_x(xr[u]);
+    const long nbase = wbase + U * stride;
+    const bool fulln = nbase + (U - 1) * stride + NIS_WAVE <= N;
+    const long pbase = fulln ? nbase : wbase;                    // last round: re-request the current tiles (unused)
+#pragma unroll
+    for (int u = 0; u < U; ++u) xr[u] = load_raw(pbase + u * stride, lane);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       double t[WX];
@@ -582,12 +607,8 @@ __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __
       }
     }
     cnt += (double)U;
-    wbase += U * stride;
-    full = wbase + (U - 1) * stride + NIS_WAVE <= N;
-    if (full) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) x[u] = sample(wbase + u * stride, lane);
-    }
+    wbase = nbase;
+    full = fulln;
   }
   for (; wbase < N; wbase += stride) {                                         // the ragged rest, one tile at a time
     const bool valid = wbase + lane < N;
