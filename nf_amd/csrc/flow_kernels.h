@@ -471,6 +471,9 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
 #ifndef NIS_STATS_U
 #define NIS_STATS_U 4
 #endif
+#ifndef NIS_STATS_PIN
+#define NIS_STATS_PIN 0
+#endif
 // ROWS: the pass-through column is column c.x_wcol of the float32 (N, 2) rows of w (CellK::wrows), not a plane.
 // PLN (ROWS kernels): w is two float32 column planes (CellK::wplanar) -- one 4-byte load per sample.
 template <int WM, int TPB, int WX, int LAYER, bool ROWS = false, bool PLN = false>
@@ -589,6 +592,14 @@ __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __
   // whole tiles, no guards (U loads in flight per wave, requested one trip ahead; the first U above the prologue)
   while (full) {
     double x[U];
+#if NIS_STATS_PIN
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                                // keep the conversions (= the wait) at the top of the trip
+      if (!ROWS) asm volatile("" : "+v"(xr[u].d));
+      else if (PLN) asm volatile("" : "+v"(xr[u].f));
+      else asm volatile("" : "+v"(xr[u].r));
+    }
+#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) x[u] = to_x(xr[u]);
     const long nbase = wbase + U * stride;
