@@ -1092,7 +1092,12 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   ist.status = status;
   ist.maxb = NIS_MAXB;
   ist.plane_gs = plane_gs;
-  const bool ingest_stats = train && c0.P <= NIS_PMAX_FUSED;
+  // a matrix-core first cell with 2..8 pass-through columns takes its BN_0 records from the covariance pass (CellK::dcov: BN_1 is
+  // derived, the layer-1 statistics launch disappears) instead of the ingest rider, which has no co-moments
+  const bool cell0_cov = train && lay[0].WM >= 16 && use_mfma() && c0.P >= 2 && c0.P <= 8 && c0.n_hidden >= 2 &&
+                         3 * c0.P + c0.P * (c0.P - 1) / 2 <= 3 * lay[0].WM && !o.sync_fn && !env_int("NIS_NO_DERIVE1", 0) &&
+                         !env_int("NIS_NO_DCOV", 0);
+  const bool ingest_stats = train && c0.P <= NIS_PMAX_FUSED && !cell0_cov;
   if (ingest_stats) {
     ist.P = c0.P;
     for (int p = 0; p < c0.P; ++p) ist.sel[p] = c0.in_col[p];

@@ -233,7 +233,7 @@ __device__ __forceinline__ void mf_hidden_reg(const CellK& c, const MfWreg<WM, P
 #define NIS_MF_STATS_WAVES 2
 #endif
 template <int WM>
-__global__ __launch_bounds__(NIS_MF_TPB, NIS_MF_STATS_WAVES) void k_bn_stats_mfma(CellK c, const double* __restrict__ planes, long ld, long N, int layer,
+__global__ __launch_bounds__(NIS_MF_TPB, WM <= 32 ? NIS_MF_STATS_WAVES : 1) void k_bn_stats_mfma(CellK c, const double* __restrict__ planes, long ld, long N, int layer,
                                                               const double* __restrict__ wm_all) {
   constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ, NW = NIS_MF_TPB / 64;
   __shared__ double lds_coef[NIS_MAX_HIDDEN * 2 * WM];
@@ -260,9 +260,12 @@ __global__ __launch_bounds__(NIS_MF_TPB, NIS_MF_STATS_WAVES) void k_bn_stats_mfm
   double xin[PQ][ST];
   const long base0 = ((long)blockIdx.x * NW + wave) * 16 * ST;
   if (pin && base0 < N) mf_issue_input<WM, PQ>(c, planes, ld, N, base0, lds_plane, xin);
-  const bool wres = NIS_MF_WREG && pin && layer <= 3;         // hidden weights resident in registers (mf_hidden_reg)
-  MfWreg<WM, PQ> Wr;
-  if (wres) mf_wreg_load<WM, PQ>(wm_all, layer, Wr);
+  constexpr bool WREG_OK = NIS_MF_WREG && WM <= 32;           // width 64: 136 fragments per lane do not fit (1.7 KB of scratch)
+  const bool wres = WREG_OK && pin && layer <= 3;             // hidden weights resident in registers (mf_hidden_reg)
+  MfWreg<WM, WREG_OK ? PQ : 1> Wr;
+  if constexpr (WREG_OK) {
+    if (wres) mf_wreg_load<WM, PQ>(wm_all, layer, Wr);
+  }
   for (long base = base0; base < N; base += wstride) {
     double H[KQ][ST];
     nis_d4 acc[JT][ST];
@@ -272,8 +275,14 @@ __global__ __launch_bounds__(NIS_MF_TPB, NIS_MF_STATS_WAVES) void k_bn_stats_mfm
     } else {
       mf_load_input<WM>(c, planes, ld, N, base, lds_plane, lds_coef, H);
     }
-    if (wres) mf_hidden_reg<WM, PQ>(c, Wr, lds_coef, layer, H, acc);
-    else mf_hidden<WM>(c, wm_all, lds_coef, layer, H, acc);
+    bool done = false;
+    if constexpr (WREG_OK) {
+      if (wres) {
+        mf_hidden_reg<WM, PQ>(c, Wr, lds_coef, layer, H, acc);
+        done = true;
+      }
+    }
+    if (!done) mf_hidden<WM>(c, wm_all, lds_coef, layer, H, acc);
     if (first) {                       // shift = value of the wave's first sample (lane with s == 0 of each row group)
 #pragma unroll
       for (int jt = 0; jt < JT; ++jt)
