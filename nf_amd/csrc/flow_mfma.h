@@ -40,6 +40,9 @@ __host__ __device__ inline int mf_cb_tiles(int T, int out, int R, int ncb_cols) 
 #ifndef NIS_MF_ST
 #define NIS_MF_ST 2
 #endif
+#ifndef NIS_MF_WAVES_LIN
+#define NIS_MF_WAVES_LIN 0             // 3: allocate the PWLin apply kernel for three waves per SIMD (one column per bijector batch)
+#endif
 #ifndef NIS_MF_WAVES
 #define NIS_MF_WAVES 2                 // waves per SIMD the apply kernel is allocated for (K <= 16)
 #endif
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, WM <= 32 ? NIS_MF_STATS_WAVES : 1) void
 // pass-through: column p of lane group p % 4) and combine them with two shuffles, like the Jacobian product -- and with
 // fz.write_planes == 0 neither the transformed columns nor the Jacobian are stored (nothing reads them).
 template <int KIND, int WM, int KM, bool KEXACT, bool FUSE = false>
-__global__ __launch_bounds__(NIS_MF_TPB, KM <= 16 ? NIS_MF_WAVES : 1) void k_cell_apply_mfma(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
+__global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN) ? NIS_MF_WAVES_LIN : KM <= 16 ? NIS_MF_WAVES : 1) void k_cell_apply_mfma(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                                 int* __restrict__ bins_out, const double* __restrict__ wm_all,
                                                                 const double* __restrict__ wm_last, const double* __restrict__ bias_pad,
                                                                 FuseF fz) {

@@ -281,8 +281,9 @@ static const size_t MF_STATIC_LDS = 7 * 1024;            // static LDS of k_cell
 static int mf_pick_ncb(const CellK& c) {
   static const int forced = getenv("NIS_MF_NCB") ? atoi(getenv("NIS_MF_NCB")) : 0;
   if (forced == 1 || forced == 2 || forced == 4) return forced;
+  const int waves = (c.kind == NIS_PWLIN && NIS_MF_WAVES_LIN) ? NIS_MF_WAVES_LIN : NIS_MF_WAVES;
   for (int n = NIS_MF_NCB; n >= 1; n >>= 1)
-    if (NIS_MF_WAVES * (mf_ring_bytes_n(c, n) + MF_STATIC_LDS) <= 160 * 1024) return n;
+    if (waves * (mf_ring_bytes_n(c, n) + MF_STATIC_LDS) <= 160 * 1024) return n;
   for (int n = NIS_MF_NCB; n >= 1; n >>= 1)                  // no batch size admits two workgroups: the largest that fits at all
     if (mf_ring_bytes_n(c, n) + 24 * 1024 <= 160 * 1024) return n;
   return 1;
@@ -298,7 +299,8 @@ template <>
 int mfma_blocks_per_cu<NIS_WM>(const CellK& c) {
   const size_t lds = mf_ring_bytes(c) + MF_STATIC_LDS;
   int n = (int)(160 * 1024 / lds);
-  return n < 1 ? 1 : n > NIS_MF_WAVES ? NIS_MF_WAVES : n;   // <= 256 VGPR+AGPR per lane: two waves per SIMD when the LDS images fit
+  const int waves = (c.kind == NIS_PWLIN && NIS_MF_WAVES_LIN) ? NIS_MF_WAVES_LIN : NIS_MF_WAVES;
+  return n < 1 ? 1 : n > waves ? waves : n;   // <= 256 VGPR+AGPR per lane: two waves per SIMD when the LDS images fit
 }
 
 template <>
