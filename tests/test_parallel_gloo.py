@@ -76,6 +76,30 @@ def test_merge_moments_handles_empty_and_uneven_shards():
     assert [shard_size(10, r, 4) for r in range(4)] == [3, 3, 2, 2]
 
 
+def test_device_side_merge_equals_the_sequential_chan_merge():
+    """`merge_moments_t` (torch ops, what the timed job runs on the device) against the NumPy sequential merge: uneven and
+    empty shards, several iterations at once, max slots of empty shards ignored."""
+    from nf_amd.parallel import merge_moments_t
+    rng = np.random.default_rng(3)
+    v = rng.normal(2.0, 1e-2, (5, 4000))
+    cuts = [0, 0, 1, 1200, 1200, 3999, 4000]
+    recs = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            x = v[:, a:b]
+            m = x.mean(1)
+            recs.append(np.stack([np.full(5, b - a, float), m, ((x - m[:, None]) ** 2).sum(1), x.max(1)], -1))
+        else:
+            recs.append(np.tile(np.array([0.0, 123.0, 0.0, 0.0]), (5, 1)))        # sanitised empty slot with junk in its mean
+    R = np.stack(recs, -2)                                                        # (5, shards, 4)
+    ref = merge_moments(np.where(R[..., :1] > 0, R, np.array([0.0, 0.0, 0.0, -np.inf])))
+    got = merge_moments_t(torch.as_tensor(R)).numpy()
+    np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=1e-12)
+    np.testing.assert_array_equal(got[:, 3], v.max(1))
+    np.testing.assert_allclose(got[:, 1], v.mean(1), rtol=1e-13)
+    np.testing.assert_allclose(got[:, 2] / (4000 - 1), v.var(1, ddof=1), rtol=1e-10)
+
+
 class _FakeManager:
     """What DataParallel touches of a manager: `_model` and the `data_parallel` slot."""
 
