@@ -463,11 +463,18 @@ class IntegratePlan:
                 c._tracked.copy_(t)
             eng._stats_bump(-1)
             eng._planes_scratch(self.G, self.N, self.dev)
+            # thread_local: other threads of the process (the RCCL watchdog of a multi-rank job polls its events) must not
+            # invalidate the capture.  If the capture fails anyway the plan launches eagerly -- same launches, same results.
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=side):
-                call(self.N)
+            try:
+                with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+                    call(self.N)
+                eng._stats_bump(-1)                  # capturing executed nothing
+            except Exception as exc:                 # noqa: BLE001 - any capture failure: keep going without the graph
+                import sys
+                print(f"nf_amd: launch-set capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
+                self.graph = None
         torch.cuda.current_stream(self.dev).wait_stream(side)
-        eng._stats_bump(-1)                          # capturing executed nothing
 
     def reset(self, seed, stream0=0):
         """Generator state for the next replay: batch g of it is Philox stream `stream0 + g` of key `seed`."""
@@ -480,7 +487,7 @@ class IntegratePlan:
         launches: tools/plan_check.py).  Both forms run the same launches on the same device-resident generator state."""
         if replay is None:
             replay = torch.cuda.current_stream(self.dev).query()
-        if replay:
+        if replay and self.graph is not None:
             self.graph.replay()
             self.eng._stats_bump(1)
         else:
