@@ -218,6 +218,11 @@ int nis_integrand_eval(int32_t f_kind, const double* f_params_host, const double
 size_t nis_moments_workspace_bytes(void);
 int nis_moments(const double* a, const double* b, int64_t N, double* out4,
                 void* workspace, size_t workspace_bytes, void* stream);
+/* Merge of moment records over the shards of a multi-GPU job (nf_amd/parallel.py; the reference has no distributed code, this is
+ * the one reduction of the sample-sharded path): recs (world, steps, 4) = every rank's {count, mean, M2, max} per iteration as
+ * gathered by ONE all-gather, out (steps, 4).  n = sum n_r, mean = sum n_r mean_r / n, M2 = sum M2_r + sum n_r (mean_r - mean)^2,
+ * max over the non-empty shards; one launch, ranks in index order (identical on every rank). */
+int nis_merge_moments(const double* recs, int32_t world, int32_t steps, double* out, void* stream);
 
 /* RAMBO on diet, FlatInvertiblePhasespace.generateKinematics_batch with pdf=None
  * (PhaseSpace/flat_phase_space_generator.py:139-308 and helpers :313-441, PhaseSpace/utils.py).

@@ -29,7 +29,7 @@ EXPORTS = ["nis_cell_param_count", "nis_cell_running_count", "nis_flow_create", 
            "nis_integrate_resident", "nis_philox_rows", "nis_integrate_steps_bins", "nis_flow_fusable", "nis_flow_backward_supported",
            "nis_flow_bnsave_count", "nis_flow_forward_train", "nis_flow_backward_workspace_bytes", "nis_flow_backward", "nis_integrand_moments", "nis_integrand_eval",
            "nis_moments_workspace_bytes",
-           "nis_moments", "nis_rambo_forward", "nis_rambo_forward_pdf", "nis_pdf_xfx", "nis_prof_enable", "nis_prof_read", "nis_prof_disable", "nis_last_error", "nis_version", "nis_device_count"]
+           "nis_moments", "nis_merge_moments", "nis_rambo_forward", "nis_rambo_forward_pdf", "nis_pdf_xfx", "nis_prof_enable", "nis_prof_read", "nis_prof_disable", "nis_last_error", "nis_version", "nis_device_count"]
 
 
 SYNC_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)       # nis_sync_fn
@@ -115,6 +115,8 @@ def lib():
     L.nis_moments_workspace_bytes.argtypes = []
     L.nis_moments.restype = i32
     L.nis_moments.argtypes = [vp, vp, i64, vp, vp, sz, vp]
+    L.nis_merge_moments.restype = i32
+    L.nis_merge_moments.argtypes = [vp, i32, i32, vp, vp]
     L.nis_rambo_forward.restype = i32
     L.nis_rambo_forward.argtypes = [C.POINTER(RamboDesc), vp, i64, i32, C.POINTER(i32), i64, vp, vp, vp, vp]
     L.nis_rambo_forward_pdf.restype = i32

@@ -812,6 +812,40 @@ __global__ __launch_bounds__(NIS_TPB) void k_group_epilogue(EpiJob job) {
 
 static int stream_grid(int64_t N) { return (int)std::max<int64_t>(1, std::min<int64_t>(NIS_MAXB, (N + NIS_TPB - 1) / NIS_TPB)); }
 
+__global__ __launch_bounds__(64) void k_merge_moments(const double* __restrict__ recs, int world, int steps, double* __restrict__ out) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= steps) return;
+  double n = 0.0, s1 = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double* q = recs + ((size_t)r * steps + i) * 4;
+    if (q[0] > 0.0) {
+      n += q[0];
+      s1 = fma(q[0], q[1], s1);
+    }
+  }
+  const double mean = n > 0.0 ? s1 / n : 0.0;
+  double m2 = 0.0, mx = -__builtin_huge_val();
+  for (int r = 0; r < world; ++r) {
+    const double* q = recs + ((size_t)r * steps + i) * 4;
+    if (q[0] > 0.0) {
+      const double d = q[1] - mean;
+      m2 += fma(q[0] * d, d, q[2]);
+      mx = fmax(mx, q[3]);
+    }
+  }
+  out[i * 4 + 0] = n;
+  out[i * 4 + 1] = mean;
+  out[i * 4 + 2] = m2;
+  out[i * 4 + 3] = mx;
+}
+
+extern "C" int nis_merge_moments(const double* recs, int32_t world, int32_t steps, double* out, void* stream) {
+  if (!recs || !out || world < 1 || steps < 1) return NIS_E_ARG;
+  hipLaunchKernelGGL(k_merge_moments, dim3((steps + 63) / 64), dim3(64), 0, (hipStream_t)stream, recs, (int)world, (int)steps, out);
+  HIP_OK(hipGetLastError());
+  return NIS_OK;
+}
+
 extern "C" size_t nis_moments_workspace_bytes(void) { return (size_t)NIS_MAXB * 4 * sizeof(double); }
 
 extern "C" int nis_moments(const double* a, const double* b, int64_t N, double* out4, void* workspace, size_t workspace_bytes,

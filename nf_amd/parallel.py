@@ -92,12 +92,37 @@ def init_from_env(backend=None, timeout_s=300):
     return rank, ws, local
 
 
+def merge_gathered(buf):
+    """(world, nitn, 4) gathered records on a GPU -> (nitn, 4), one launch (`nis_merge_moments`)."""
+    from . import _lib
+    ws = buf.shape[0]
+    out = torch.empty(tuple(buf.shape[1:]), dtype=torch.double, device=buf.device)
+    steps = out.numel() // 4
+    with _lib.on_device(buf.device):
+        _lib.check(_lib.lib().nis_merge_moments(buf.data_ptr(), ws, steps, out.data_ptr(), _lib.stream_ptr(buf.device)),
+                   "nis_merge_moments")
+    return out
+
+
 def allreduce_moments(local, group=None):
     """local: (nitn, 4) float64 records of this rank (any device).  Returns the merged (nitn, 4) records,
-    identical on every rank.  One all-reduce."""
+    identical on every rank.  One collective.
+
+    On a GPU: ONE all-gather of the records (world x nitn x 32 bytes) and ONE merge launch (`nis_merge_moments`) -- the
+    collective and the merge are inside the job's timed region, so they are two launches, not a dozen tensor operations.
+    On the CPU (gloo rehearsals, tests): all-reduce (SUM) of a zero-padded (world, nitn, 4) buffer = an exact gather, merged in
+    torch ops."""
     rank, ws = world()
     if ws == 1:
         return local
+    if local.is_cuda and dist.get_backend(group) == "nccl":
+        from . import _lib
+        loc = local.contiguous()
+        buf = torch.empty((ws,) + tuple(loc.shape), dtype=torch.double, device=loc.device)
+        gather = getattr(dist, "all_gather_into_tensor", None)
+        if gather is not None:
+            gather(buf, loc, group=group)
+            return merge_gathered(buf)
     buf = torch.zeros((ws,) + tuple(local.shape), dtype=torch.double, device=local.device)
     buf[rank] = local
     # max slot: an empty rank holds -inf there, which must not poison the SUM -> sanitise per slot

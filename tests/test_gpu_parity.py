@@ -1176,6 +1176,27 @@ def test_wide_forward_large_batch_vs_reference(tag, g_wide):
         np.testing.assert_allclose(t2n(sd[k]), v, rtol=1e-10, atol=1e-13, err_msg=k)
 
 
+def test_merge_of_gathered_moment_records_one_launch():
+    """`nis_merge_moments` (what a multi-GPU job runs behind its one all-gather) against the NumPy sequential Chan merge: uneven
+    and empty shards (count 0, max -inf), 37 iterations, 8 ranks."""
+    from nf_amd.parallel import merge_gathered, merge_moments
+    rng = np.random.default_rng(5)
+    world, steps = 8, 37
+    recs = np.zeros((world, steps, 4))
+    for r in range(world):
+        for i in range(steps):
+            n = 0 if (r + i) % 5 == 0 else int(rng.integers(1, 2000))
+            if n == 0:
+                recs[r, i] = [0.0, 0.0, 0.0, -np.inf]
+            else:
+                x = rng.normal(3.0, 1e-2, n)
+                recs[r, i] = [n, x.mean(), ((x - x.mean()) ** 2).sum(), x.max()]
+    got = t2n(merge_gathered(torch.as_tensor(recs).to(dev())))
+    ref = merge_moments(np.moveaxis(recs, 0, -2))
+    np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=1e-12)
+    np.testing.assert_array_equal(got[:, 3], ref[:, 3])
+
+
 @pytest.mark.parametrize("tag", ["C3", "C5"])
 def test_bn1_derived_from_the_pass_through_covariance(tag, g_wide, monkeypatch):
     """Matrix-core cells with 2..8 pass-through columns skip the layer-1 statistics launch: BN_0's records carry the co-moments of
