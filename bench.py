@@ -44,17 +44,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, ch
 VALU_F64_PEAK = 256 * 4 * 16 * 2.4e9     # fp64 vector issue: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 3.93e13 lane-instr/s (78.6 TFLOP/s FMA)
 MFMA_F64_PEAK_TF = 78.6        # v_mfma_f64_16x16x4_f64: same datapath as the fp64 vector pipe
 BATCH = 1_000_000
+ALG_BYTES_C2 = 16.0            # fused integrate reads w only, 8 d bytes per sample
+ALG_FLOP_CELL_C2 = 180.0       # 2 (3 + 9 + 9 + 27) + ~80 flop per cell and sample
 K_CLASS = {"apply": 0, "stats": 1, "ingest": 2, "integrand": 3, "rambo": 4}
 
 
-def profile_json(name):
-    """A committed rocprofv3 PMC summary (profiles/<name>.json, written by tools/profile_round.sh), or {}."""
-    for tag in ("r02", "r01"):
+def profile_json(name, with_name=False):
+    """The newest committed rocprofv3 PMC summary (profiles/rNN_<name>.json, written by tools/profile_round*.sh), or {}."""
+    for tag in ("r03", "r02", "r01"):
         try:
-            return json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{name}.json")))
+            d = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{name}.json")))
+            return (d, f"{tag}_{name}.json") if with_name else d
         except Exception:
             continue
-    return {}
+    return ({}, "") if with_name else {}
 
 
 def barrier_sync(ws):
@@ -136,36 +139,44 @@ def bench_flow(args, rank, ws, dev):
     torch.cuda.synchronize()
     kern_ms, kern_n = prof_read()
     L.nis_prof_disable()
-    pmc = profile_json("pmc_c2")                         # {"steps_per_launch": g, "kernels": {name: {"valu_insts":, "hbm_bytes":, "launches":}}}
-    roof = roof_hbm = None
+    pmc, pmc_file = profile_json("pmc_c2", with_name=True)   # {"steps_per_launch": g, "kernels": {name: {"valu_insts":, "hbm_bytes":, "launches":}}}
+    roof = roof_hbm = roof_issue = None
     if kern_n > 0:
         avg_s = kern_ms / kern_n / 1e3
         kname = {"apply": "k_cell_apply", "stats": "k_bn_stats_fold", "ingest": "k_ingest2_rng"}.get(args.roofline_kernel, "")
         rec = pmc.get("kernels", {}).get(kname, {})
         scale = G / max(1, pmc.get("steps_per_launch", G))
-        # (a) the binding resource: fp64 vector issue.  achieved = lane-instructions per launch (SQ_INSTS_VALU x 64) / measured duration
-        if rec.get("valu_insts"):
-            lane = rec["valu_insts"] * 64.0 * scale
-            roof = {"kernel": kname, "bound": "valu_f64", "achieved": round(lane / avg_s / 1e9, 1), "peak": round(VALU_F64_PEAK / 1e9, 1),
-                    "unit": "Glane-instr/s", "frac": round(lane / avg_s / VALU_F64_PEAK, 4),
-                    "traffic": rec.get("hbm_bytes") and rec["hbm_bytes"] * scale, "avg_launch_us": round(avg_s * 1e6, 2), "launches": kern_n,
-                    "steps_per_launch": G, "valu_insts_per_sample": round(rec["valu_insts"] * 64.0 / (pmc.get("steps_per_launch", G) * BATCH), 1),
-                    "note": "both apply launches of a set (cell 0, last cell with the fused camel) averaged"}
-        # (b) against HBM: SURVEY 8(d)'s algorithmic bytes of the fused step are 8 d = 16 B/sample (float64 w read once); with
-        #     the draw in the kernel nothing has to be read at all.  step_traffic_B_per_sample = PMC bytes of all kernels of a set.
+        units = BATCH * G                                   # samples one launch of the kernel processes (one cell of G steps)
+        # ALGORITHMIC roofline: the fused step reads 8 d = 16 B/sample (nothing at all with the draw inside) and
+        # does 180 flop per cell and sample; one apply launch = one cell of `units` samples.  The larger fraction names the bound.
+        ach_hbm = ALG_BYTES_C2 * units / avg_s / 1e9
+        ach_tf = ALG_FLOP_CELL_C2 * units / avg_s / 1e12
+        f_hbm, f_flop = ach_hbm / HBM_PEAK_GBS, ach_tf / MFMA_F64_PEAK_TF
+        traffic = rec.get("hbm_bytes") and rec["hbm_bytes"] * scale
+        common = {"kernel": kname, "avg_launch_us": round(avg_s * 1e6, 2), "launches": kern_n, "steps_per_launch": G, "units_per_launch": units}
+        roof_hbm = dict(common, bound="hbm", achieved=round(ach_hbm, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(f_hbm, 4), traffic=traffic,
+                        algorithmic_bytes_per_sample=ALG_BYTES_C2)
+        roof_flop = dict(common, bound="valu_f64", achieved=round(ach_tf, 2), peak=MFMA_F64_PEAK_TF, unit="TFLOP/s", frac=round(f_flop, 4),
+                         traffic=traffic, algorithmic_flop_per_sample_and_cell=ALG_FLOP_CELL_C2,
+                         note="narrow (width-3) conditioners run on the fp64 vector pipe, whose peak equals the dense f64 MFMA peak (78.6 TFLOP/s)")
+        roof = roof_flop if f_flop >= f_hbm else roof_hbm
+        roof["other_bound"] = {"bound": "hbm" if roof is roof_flop else "valu_f64", "frac": round(f_hbm if roof is roof_flop else f_flop, 4)}
+        # whole step against HBM, with the PMC traffic of all kernels of a set
         step_bytes = sum(k.get("hbm_bytes", 0) * k.get("launches_per_set", 1) for k in pmc.get("kernels", {}).values())
         per_sample = step_bytes / (pmc.get("steps_per_launch", G) * BATCH) if step_bytes else None
-        ach = 16.0 * BATCH * G / avg_s / 1e9
-        roof_hbm = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(avg_s * 1e6, 2), "launches": kern_n, "steps_per_launch": G,
-                    "algorithmic_bytes_per_sample": 16.0,
-                    "step_traffic_B_per_sample": per_sample and round(per_sample, 1),
-                    "traffic_ratio": per_sample and round(per_sample / 16.0, 2),
-                    "step_frac": round(16.0 * BATCH * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4)}
-        if roof is None:
-            roof = dict(roof_hbm)
-            roof["note"] = "no PMC instruction counts committed for this kernel: HBM figure only"
-    return dict(dt=dt, samples=BATCH * args.steps * ws, sig=sig, sig_err=sig_err, sig_mc=sig_mc, roofline=roof, roofline_hbm=roof_hbm, G=G)
+        roof_hbm.update(step_traffic_B_per_sample=per_sample and round(per_sample, 1), traffic_ratio=per_sample and round(per_sample / ALG_BYTES_C2, 2),
+                        step_frac=round(ALG_BYTES_C2 * BATCH * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4),
+                        step_flop_frac=round(2 * ALG_FLOP_CELL_C2 * BATCH * args.steps / dt / 1e12 / MFMA_F64_PEAK_TF, 4))
+        # DIAGNOSIS (not the roofline): fp64 issue-slot utilisation = lane-instructions per launch (SQ_INSTS_VALU x 64, counted in the
+        # committed PMC pass named in insts_from, not in this run) / the duration measured here
+        if rec.get("valu_insts"):
+            lane = rec["valu_insts"] * 64.0 * scale
+            roof_issue = dict(common, bound="valu_f64_issue", achieved=round(lane / avg_s / 1e9, 1), peak=round(VALU_F64_PEAK / 1e9, 1),
+                              unit="Glane-instr/s", frac=round(lane / avg_s / VALU_F64_PEAK, 4), insts_from="profiles/" + pmc_file,
+                              valu_insts_per_sample=round(rec["valu_insts"] * 64.0 / (pmc.get("steps_per_launch", G) * BATCH), 1),
+                              note="both apply launches of a set (cell 0, last cell with the fused camel) averaged")
+    return dict(dt=dt, samples=BATCH * args.steps * ws, sig=sig, sig_err=sig_err, sig_mc=sig_mc, roofline=roof, roofline_hbm=roof_hbm,
+                roofline_issue=roof_issue, G=G)
 
 
 def bench_rambo(args, rank, ws, dev):
@@ -305,14 +316,14 @@ def cpu_baseline():
     t1 = time.perf_counter()
     orambo.generate_kinematics([100.] * 2, [100.] * 4, 1000., r, 0, 0, -1)
     dtr = time.perf_counter() - t1
-    return {"value": BATCH / t_all, "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": BATCH / t_all, "unit": "samples/s", "cores": cores, "kind": "port",     # cores = threads used; host_cpus = os.cpu_count()
             "sample": f"oracle.flow_torch.integrate (PyTorch CPU float64, torch.set_num_threads({cores}), fastest of {cands} on this host): C2 model, "
                       f"1e6 samples per iteration, 1 warm-up + median of 5 ({t_all * 1e3:.0f} ms per iteration)",
             "one_core": {"value": n_it * BATCH / dt1, "unit": "samples/s", "cores": 1,
                          "sample": f"oracle.flow.integrate (NumPy float64): {n_it} iterations x 1e6 samples ({dt1:.1f} s)",
                          "integral": float(sig), "sigma": float(sig_err)},
             "rambo": {"value": n_rb / dtr, "unit": "samples/s", "cores": 1, "sample": f"oracle.rambo 2->4 massive (NumPy), {n_rb} points ({dtr:.1f} s)"},
-            "host_cpus": cores}
+            "host_cpus": host}
 
 
 def main():
@@ -357,11 +368,14 @@ def main():
                                "lattice), fused camel*J + moments",
                    "batch_per_gpu": BATCH, "global_batch": BATCH * ws, "parallelism": f"sample-shard x{ws}",
                    "collective": "one all-reduce of (steps,4) moment records", "steps_per_launch_set": flow["G"],
-                   "rccl_ranks": dist.get_world_size() if ws > 1 else 1, "samples_per_rank": BATCH * args.steps},
+                   "backend": (dist.get_backend() if ws > 1 else "none"),
+                   "rccl_ranks": (dist.get_world_size() if ws > 1 and dist.get_backend() == "nccl" else 0 if ws > 1 else 1),
+                   "samples_per_rank": BATCH * args.steps},
         "integral": {"value": flow["sig"], "sigma": flow["sig_err"], "sigma_mc": flow["sig_mc"], "truth": 0.2323235706,
                      "note": "sigma = the reference's formula (manager.py:403); sigma_mc = 1/sqrt(sum_i N/var_i)"},
         "roofline": flow["roofline"],
         "roofline_hbm": flow["roofline_hbm"],
+        "roofline_issue": flow["roofline_issue"],
         "rambo": rambo,
         "configs": configs,
     }

@@ -137,24 +137,29 @@ int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_b
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same loop body with the draw INSIDE the step (manager.py:395 `uniform_(w)` is part of integrate()'s loop): batch g
- * is drawn on the device from the counter-based generator Philox4x32-10 (Salmon et al. 2011, Random123 constants),
- *   w[g][n][c] = (philox(ctr = {n>>1 lo, n>>1 hi, s lo, s hi}, key = {seed lo, seed hi})[2 (n & 1) + c] >> 8) * 2^-24,
- *   s = stream0 + g   (the float32 lattice torch's uniform_ produces, manager.py:390),
- * by the launch that gathers BN_0's records (the rows are written once, 8 B/sample, into the state plane the d = 2
- * direct-row chain leaves unused, and read from there by the cells) -- no input buffer, no separate generator pass.
- * Defined for the d = 2 PWQuad chain with a fused camel (nis_integrate_steps' direct-row class); other models return
- * NIS_E_UNSUPPORTED and the caller materialises the same draws with nis_philox_rows.  w_out (n_batches, N, 2) optional:
- * the draws that were used (tests replay them through the oracle).  planes as for nis_integrate_steps.
+ * is drawn on the device from the counter-based generator Philox4x32-10 (Salmon et al. 2011, Random123 constants) on the
+ * float32 lattice torch's uniform_ produces (manager.py:390), by the launch that gathers BN_0's records -- no input buffer,
+ * no separate generator pass.  With s = stream0 + g and u24(r) = (r >> 8) * 2^-24:
+ *   d == 2:  w[g][n][c] = u24(philox(ctr = {n>>1 lo, n>>1 hi, s lo, s hi}, key = {seed lo, seed hi})[2 (n & 1) + c])
+ *   d != 2:  w[g][n][c] = u24(philox(ctr = {q lo, q hi, s lo, s hi}, key)[c & 3]),  q = n * ceil(d / 4) + (c >> 2)
+ * The d = 2 PWQuad chain with a fused camel (nis_integrate_steps' direct-row class, nis_integrate_rng_mode == 2) keeps the
+ * draws as float32 rows in the state plane it leaves unused (8 B/sample) and its cells read them from there; every other
+ * model (mode 1) gets its d float64 state planes written directly, with the first cell's BN_0 records -- and, for a
+ * matrix-core first cell with 2..8 pass-through columns, their co-moments, so that BN_1 is derived as well -- riding along.
+ * w_out (n_batches, N, d) float32 optional: the draws that were used (tests replay them through the oracle; nis_philox_rows
+ * materialises the same numbers).  planes / keep_planes as for nis_integrate_steps.
  * rng_state (optional, device): {seed, next stream} as two uint64 -- when given it overrides seed / stream0, is read by the
  * drawing launch and advanced by n_batches in the set's last launch, so a launch set captured into a hipGraph draws fresh
  * numbers on every replay.
- * nis_integrate_resident: 1 when the calls run the opt-in persistent whole-step kernel (NIS_MEGA=1, flow_mega.hip: the
- * batch lives in LDS from its draw to its moment record); `planes` may then be NULL. */
+ * nis_integrate_resident: 1 when the calls run the persistent whole-step kernel of the DIAGNOSTICS build (libnis_hip_diag.so,
+ * NIS_MEGA=1, flow_mega.hip); always 0 in the product library.  nis_diag_build: 1 in the diagnostics build. */
 int nis_integrate_steps_rng(nis_flow* f, int32_t n_batches, int64_t N,
                             const double* const* params, double* const* running, long long* const* tracked,
                             int32_t bn_mode, int64_t pack_token, int32_t f_kind, const double* f_params_host,
-                            uint64_t seed, uint64_t stream0, uint64_t* rng_state, float* w_out, double* planes, int64_t ld, double* out4,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            uint64_t seed, uint64_t stream0, uint64_t* rng_state, float* w_out, double* planes, int64_t ld,
+                            int32_t keep_planes, double* out4, void* workspace, size_t workspace_bytes, void* stream);
+/* 2: direct-row class, 1: generated planes (any model), 0: invalid arguments. */
+int nis_integrate_rng_mode(const nis_flow* f, int32_t n_batches, int64_t N, int32_t bn_mode, int32_t f_kind, int32_t keep_planes);
 /* Test entry: ONE iteration of the fused step on the production direct-row kernels that additionally writes the bin index
  * selected for every cell's transformed column, bins_out int32 [n_cells][ld] (K = 4 PWQuad chains of that kernel class;
  * others: NIS_E_UNSUPPORTED).  The parity tests assert the bins bit-exact against the oracle at the bench's batch size. */
@@ -166,7 +171,8 @@ int nis_integrate_steps_bins(nis_flow* f, const void* w, int32_t w_dtype, int64_
 /* 1 when the built-in integrand of nis_integrate_steps is fused into the last cell's kernel for this model. */
 int nis_flow_fusable(const nis_flow* f);
 int nis_integrate_resident(const nis_flow* f, int32_t n_batches, int64_t N, int32_t bn_mode, int32_t f_kind);
-int nis_philox_rows(uint64_t seed, uint64_t stream0, int32_t n_batches, int64_t N, float* out, void* stream);
+int nis_philox_rows(uint64_t seed, uint64_t stream0, int32_t n_batches, int64_t N, int32_t d, float* out /* (n_batches, N, d) */, void* stream);
+int nis_diag_build(void);
 
 /* Train-mode forward whose BatchNorm statistics are those of the batch that is SHARDED over `world` ranks (SURVEY.md 8(e)
  * option 1, "SyncBN-exact": every rank passes its N rows; results equal the reference's single-batch forward of the
@@ -265,6 +271,17 @@ typedef struct nis_pdf1d {
 int nis_rambo_forward_pdf(const nis_rambo_desc* desc_host, const nis_pdf1d* pdf_beams_host /* [2] */,
                           const double* r, int64_t r_ld, int32_t r_col_major, const int32_t* r_cols_host, int64_t N,
                           double* momenta, double* weight, int32_t* status, void* stream);
+/* Flow -> RAMBO weight -> moments as ONE launch per launch set: the integrand side of integrate()'s loop body (manager.py:397-400)
+ * with f = the phase-space weight of generateKinematics_batch (flat_phase_space_generator.py:139-308, unit matrix element).
+ * planes: n_batches plane sets, plane_gs doubles apart, each (d+1, ld) as nis_integrate_steps leaves them with keep_planes;
+ * phase-space column c is plane cols_host[c], the flow's Jacobian is plane jplane.  No momenta and (unless weight_out
+ * (n_batches, N) is given) no weights are written: weight * J is reduced to out4 (n_batches, 4) = {count, mean, M2, max}.
+ * status (device int32) ACCUMULATES the bits of nis_rambo_forward over the calls; the caller reads it once per integrate().
+ * workspace >= nis_rambo_moments_workspace_bytes(n_batches). */
+size_t nis_rambo_moments_workspace_bytes(int32_t n_batches);
+int nis_rambo_moments(const nis_rambo_desc* desc_host, const nis_pdf1d* pdf_beams_host /* [2] or NULL */, const double* planes,
+                      int64_t ld, int64_t plane_gs, const int32_t* cols_host, int32_t jplane, int64_t N, int32_t n_batches,
+                      double* weight_out, double* out4, int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 int nis_pdf_xfx(const nis_pdf1d* table_host, const double* x, int64_t N, double* out, void* stream);
 
 /* Live timing of ONE kernel class with HIP events recorded on the launch stream around every launch of

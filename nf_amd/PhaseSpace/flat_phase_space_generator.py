@@ -165,3 +165,41 @@ class FlatInvertiblePhasespace(VirtualPhaseSpaceGenerator):
         if st & 8:
             print("Invalid boost")    # utils.py:33-34
         return weight, status
+
+    def moments_from_planes(self, E_cm, planes, cols, jplane, N, out4, status, pT_mincut=-1, delR_mincut=-1, rap_maxcut=-1, pdgs=(0, 0),
+                            lab_boost=None):
+        """weight * J -> (count, mean, M2, max) for G plane sets in ONE launch + one merge launch (`nis_rambo_moments`): the
+        integrand side of integrate()'s loop body with f = this generator's weight (manager.py:397-400).  planes: (G, d+1, N)
+        as `FlowEngine.integrate_steps*` leaves them with keep_planes; out4: (G, 4) device view; status: device int32[1] that
+        ACCUMULATES the kernel's status bits -- nothing is read back here (no host sync, no allocation besides the cached
+        workspace); the caller inspects `status` once per integrate() call (`check_status`)."""
+        _lib.require_gpu()
+        ncol = self.nDimPhaseSpace() + (2 if self.pdf_active else 0)
+        assert len(cols) == ncol, f"the flow has {len(cols)} columns, the phase space needs {ncol}"
+        L = _lib.lib()
+        G = planes.shape[0]
+        dev = planes.device
+        wsb = L.nis_rambo_moments_workspace_bytes(G)
+        ws = getattr(self, "_mom_ws", None)
+        if ws is None or ws.device != dev or ws.numel() < wsb:
+            self._mom_ws = ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        self.collider_energy = E_cm
+        lab = bool(self.pdf_active) if lab_boost is None else bool(lab_boost)
+        desc = self._desc(E_cm, pT_mincut, delR_mincut, rap_maxcut, lab)
+        cp = (C.c_int32 * len(cols))(*cols)
+        tabs = self._pdf_tables(pdgs, dev)
+        with _lib.on_device(dev):
+            rc = L.nis_rambo_moments(C.byref(desc), tabs, planes.data_ptr(), planes.shape[2], planes.stride(0), cp, int(jplane), int(N), G,
+                                     None, out4.data_ptr(), status.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+        _lib.check(rc, "nis_rambo_moments")
+
+    def check_status(self, status):
+        """Honour the accumulated status word exactly as `generateKinematics_batch` does per call: NaN guard (reference :147-149)
+        raises; returns True when some sample had x1 == x2 under the lab boost -- the reference then skips the boost for that
+        whole batch (utils.py:139-144), so the caller has to redo its estimate batch by batch."""
+        st = int(status.item())
+        if st & 2:
+            raise PhaseSpaceGeneratorError("Some of the random variables passed to the phase-space generator are NaN")
+        if st & 8:
+            print("Invalid boost")    # utils.py:33-34
+        return bool(self.pdf_active) and bool(st & 4)

@@ -26,10 +26,10 @@ LIB_PATH = os.environ.get("NIS_LIB") or os.path.join(os.path.dirname(os.path.abs
 
 EXPORTS = ["nis_cell_param_count", "nis_cell_running_count", "nis_flow_create", "nis_flow_destroy",
            "nis_flow_workspace_bytes", "nis_flow_forward", "nis_flow_forward_sync", "nis_integrate_steps", "nis_integrate_steps_rng",
-           "nis_integrate_resident", "nis_philox_rows", "nis_integrate_steps_bins", "nis_flow_fusable", "nis_flow_backward_supported",
+           "nis_integrate_resident", "nis_integrate_rng_mode", "nis_diag_build", "nis_philox_rows", "nis_integrate_steps_bins", "nis_flow_fusable", "nis_flow_backward_supported",
            "nis_flow_bnsave_count", "nis_flow_forward_train", "nis_flow_backward_workspace_bytes", "nis_flow_backward", "nis_integrand_moments", "nis_integrand_eval",
            "nis_moments_workspace_bytes",
-           "nis_moments", "nis_merge_moments", "nis_rambo_forward", "nis_rambo_forward_pdf", "nis_pdf_xfx", "nis_prof_enable", "nis_prof_read", "nis_prof_disable", "nis_last_error", "nis_version", "nis_device_count"]
+           "nis_moments", "nis_merge_moments", "nis_rambo_forward", "nis_rambo_forward_pdf", "nis_rambo_moments", "nis_rambo_moments_workspace_bytes", "nis_pdf_xfx", "nis_prof_enable", "nis_prof_read", "nis_prof_disable", "nis_last_error", "nis_version", "nis_device_count"]
 
 
 SYNC_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)       # nis_sync_fn
@@ -83,7 +83,11 @@ def lib():
     u64 = C.c_uint64
     L.nis_integrate_steps_rng.restype = i32
     L.nis_integrate_steps_rng.argtypes = [vp, i32, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, i32,
-                                          C.POINTER(C.c_double), u64, u64, vp, vp, vp, i64, vp, vp, sz, vp]
+                                          C.POINTER(C.c_double), u64, u64, vp, vp, vp, i64, i32, vp, vp, sz, vp]
+    L.nis_integrate_rng_mode.restype = i32
+    L.nis_integrate_rng_mode.argtypes = [vp, i32, i64, i32, i32, i32]
+    L.nis_diag_build.restype = i32
+    L.nis_diag_build.argtypes = []
     L.nis_integrate_steps_bins.restype = i32
     L.nis_integrate_steps_bins.argtypes = [vp, vp, i32, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64, i32,
                                            C.POINTER(C.c_double), vp, i64, vp, vp, vp, sz, vp]
@@ -92,7 +96,7 @@ def lib():
     L.nis_integrate_resident.restype = i32
     L.nis_integrate_resident.argtypes = [vp, i32, i64, i32, i32]
     L.nis_philox_rows.restype = i32
-    L.nis_philox_rows.argtypes = [u64, u64, i32, i64, vp, vp]
+    L.nis_philox_rows.argtypes = [u64, u64, i32, i64, i32, vp, vp]
     L.nis_flow_backward_supported.restype = i32
     L.nis_flow_backward_supported.argtypes = [vp]
     L.nis_flow_bnsave_count.restype = sz
@@ -121,6 +125,10 @@ def lib():
     L.nis_rambo_forward.argtypes = [C.POINTER(RamboDesc), vp, i64, i32, C.POINTER(i32), i64, vp, vp, vp, vp]
     L.nis_rambo_forward_pdf.restype = i32
     L.nis_rambo_forward_pdf.argtypes = [C.POINTER(RamboDesc), vp, vp, i64, i32, C.POINTER(i32), i64, vp, vp, vp, vp]
+    L.nis_rambo_moments_workspace_bytes.restype = sz
+    L.nis_rambo_moments_workspace_bytes.argtypes = [i32]
+    L.nis_rambo_moments.restype = i32
+    L.nis_rambo_moments.argtypes = [C.POINTER(RamboDesc), vp, vp, i64, i64, C.POINTER(i32), i32, i64, i32, vp, vp, vp, vp, sz, vp]
     L.nis_pdf_xfx.restype = i32
     L.nis_pdf_xfx.argtypes = [vp, vp, i64, vp, vp]
     L.nis_prof_enable.restype = i32

@@ -1,7 +1,11 @@
-"""Build libnis_hip.so (gfx950) in-tree with hipcc.  `python -m nf_amd.build [--force]`.
+"""Build libnis_hip.so (gfx950) in-tree with hipcc.  `python -m nf_amd.build [--force] [--diag]`.
 
 The per-conditioner-width translation units (forward: 5, wide adjoint: 3) compile in parallel; objects go to nf_amd/csrc/build/,
 the shared library to nf_amd/lib/libnis_hip.so (git-ignored, travels to the GPU box with the snapshot).
+
+`--diag` additionally builds nf_amd/lib/libnis_hip_diag.so: the same library with -DNIS_DIAG, i.e. plus the measured dead ends kept for
+A/B measurements only -- the persistent LDS-resident C2 kernel (flow_mega.hip, NIS_MEGA=1) and the multi-chain launch sets
+(NIS_STREAMS=n).  Select it with NIS_LIB=<path>; the product library contains neither.
 """
 import os
 import subprocess
@@ -18,7 +22,10 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"] + \
         os.environ.get("NIS_EXTRA_FLAGS", "").split()          # diagnostics only (e.g. -DNIS_MEGA_STAMPS), never for the shipped library
 
-UNITS = [("api", "api.hip", []), ("rambo", "rambo.hip", []), ("flow_bwd", "flow_bwd.hip", []), ("flow_mega", "flow_mega.hip", [])] + \
+LIB_DIAG = os.path.join(LIBDIR, "libnis_hip_diag.so")
+API_UNITS = [("api", "api.hip", []), ("api_pack", "api_pack.hip", []), ("api_ingest", "api_ingest.hip", []), ("api_moments", "api_moments.hip", [])]
+DIAG_UNITS = [("diag_api", "api.hip", ["-DNIS_DIAG"]), ("diag_api_pack", "api_pack.hip", ["-DNIS_DIAG"]), ("diag_flow_mega", "flow_mega.hip", ["-DNIS_DIAG"])]
+UNITS = API_UNITS + [("rambo", "rambo.hip", []), ("flow_bwd", "flow_bwd.hip", [])] + \
         [(f"flow_wm{w}", "flow_wm.hip", [f"-DNIS_WM={w}"]) for w in (4, 8, 16, 32, 64)] + \
         [(f"flow_bwd_wm{w}", "flow_bwd_wm.hip", [f"-DNIS_WM={w}"]) for w in (16, 32, 64)]
 
@@ -46,26 +53,34 @@ def _compile(unit):
     return obj, r.stderr
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ, exist_ok=True)
-    os.makedirs(LIBDIR, exist_ok=True)
-    deps = _sources()
-    if not force and not _stale(LIB, deps):
-        return LIB
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
-        results = list(ex.map(_compile, UNITS))
-    objs = [o for o, _ in results]
-    if verbose:
-        for _, err in results:
-            if err.strip():
-                print(err, file=sys.stderr)
-    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+def _link(lib, objs):
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+
+
+def build(force=False, verbose=False, diag=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    deps = _sources()
+    if force or _stale(LIB, deps):
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+            results = list(ex.map(_compile, UNITS))
+        if verbose:
+            for _, err in results:
+                if err.strip():
+                    print(err, file=sys.stderr)
+        _link(LIB, [o for o, _ in results])
+    if diag and (force or _stale(LIB_DIAG, deps + [LIB])):
+        with ThreadPoolExecutor(max_workers=3) as ex:
+            dres = list(ex.map(_compile, DIAG_UNITS))
+        swapped = {"api.o", "api_pack.o"}
+        objs = [os.path.join(OBJ, n + ".o") for n, _, _ in UNITS if n + ".o" not in swapped] + [o for o, _ in dres]
+        _link(LIB_DIAG, objs)
     return LIB
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose=True)
+    path = build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv)
     print(path)

@@ -1,0 +1,224 @@
+// Model handle, workspace layout and parameter packing of libnis_hip.so (see api_internal.h for the split).
+#include "api_internal.h"
+#ifdef NIS_DIAG
+#include "flow_mega.h"
+#endif
+
+extern "C" size_t nis_cell_param_count(const nis_cell_desc* c) {
+  size_t n = 0;
+  for (int l = 0; l <= c->n_hidden; ++l) {
+    const int F = cell_feat(*c, l);
+    const int O = l < c->n_hidden ? c->width[l] : cell_R(*c);
+    n += 2 * (size_t)F + (size_t)O * F;
+    if (l < c->n_hidden && cell_hidden_bias(*c)) n += O;
+  }
+  return n + cell_R(*c);
+}
+extern "C" size_t nis_cell_running_count(const nis_cell_desc* c) {
+  size_t n = 0;
+  for (int l = 0; l <= c->n_hidden; ++l) n += 2 * (size_t)cell_feat(*c, l);
+  return n;
+}
+
+// Workspace body for G batched iterations: per cell the zero-padded parameter image (shared by all batches),
+// then per-batch BN coefficients, partial records and batch statistics; finally the integrand's moment records.
+// The persistent whole-step kernel (flow_mega.hip) covers the README / C1 / C2 model: d = 2, two PWQuad cells with 4 bins,
+// one pass-through column, three hidden layers at most 3 wide.
+bool nis_mega_model(const nis_flow* f) {
+  if (f->d != 2 || f->n_cells != 2) return false;
+  for (int ci = 0; ci < 2; ++ci) {
+    const nis_cell_desc& c = f->cells[ci];
+    if (c.kind != NIS_PWQUAD || c.P != 1 || c.K != 4 || c.n_hidden != 3) return false;
+    for (int l = 0; l < 3; ++l)
+      if (c.width[l] > 3) return false;
+  }
+  return true;
+}
+
+size_t nis_flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay, size_t* off_fpart, size_t* off_mega) {
+  size_t off = 0;
+  for (int i = 0; i < f->n_cells; ++i) {
+    const nis_cell_desc& c = f->cells[i];
+    int m = c.P;
+    for (int l = 0; l < c.n_hidden; ++l) m = std::max(m, c.width[l]);
+    CellLayout L;
+    L.WM = nis_pick_wm(m);
+    L.KM = c.kind == NIS_PWQUAD ? nis_pick_km(c.K) : 4;
+    if (c.kind == NIS_PWQUAD && L.KM == c.K) L.KM = -L.KM;        // K == KM: guard-free specialisation
+    const size_t WM = L.WM, R = cell_R(c), nl = c.n_hidden;
+    L.off_wp = off;      off += nl * WM * WM;
+    L.off_wlast = off;   off += R * WM;
+    L.off_bias = off;    off += (R + 7) / 8 * 8;
+    L.off_gb = off;      off += (nl + 1) * 2 * WM;
+    L.off_hb = off;      off += (nl + 1) * WM;        // bias of the Linear in front of BN layer l (zero unless NIS_AFFINE)
+    L.off_coef = off;    off += (size_t)G * (nl + 1) * 2 * WM;
+    L.off_gstat = off;   off += (size_t)G * (nl + 1) * 2 * WM;
+    L.off_part = off;    off += (nl + 1) * (size_t)G * NIS_MAXB * WM * 3;
+    L.RT = (int)((R + 15) / 16);
+    L.off_wm = L.off_wmlast = L.off_biaspad = 0;
+    if (WM >= 16) {
+      L.off_wm = off;      off += nl * WM * WM;
+      L.off_wmlast = off;  off += (size_t)L.RT * 16 * WM;
+      L.off_biaspad = off; off += (size_t)L.RT * 16;
+    }
+    if (lay) lay->push_back(L);
+  }
+  if (off_fpart) *off_fpart = off;
+  off += (size_t)G * NIS_MAXB * 4;
+  off = (off + 31) / 32 * 32;                                   // 256-byte aligned: the scratch starts with its counter block
+  if (off_mega) *off_mega = off;
+#ifdef NIS_DIAG
+  if (nis_mega_model(f)) off += (nis_mega_scratch_bytes() + 7) / 8;
+#endif
+  return off;
+}
+
+static int validate_cell(const nis_cell_desc& c, int d) {
+  if (c.kind != NIS_PWLIN && c.kind != NIS_PWQUAD && c.kind != NIS_AFFINE) return NIS_E_ARG;
+  if (c.d != d || c.P < 1 || c.P >= d || (c.K < 1 && c.kind != NIS_AFFINE)) return NIS_E_ARG;
+  if (c.n_hidden < 1 || c.n_hidden > NIS_MAX_HIDDEN) return NIS_E_UNSUPPORTED;
+  int m = c.P;
+  for (int l = 0; l < c.n_hidden; ++l) {
+    if (c.width[l] < 1) return NIS_E_ARG;
+    m = std::max(m, c.width[l]);
+  }
+  if (nis_pick_wm(m) < 0) return NIS_E_UNSUPPORTED;
+  if (c.kind == NIS_PWQUAD && nis_pick_km(c.K) < 0) return NIS_E_UNSUPPORTED;
+  if (c.kind == NIS_PWLIN && c.K > NIS_MAX_BINS) return NIS_E_UNSUPPORTED;
+  for (int j = 0; j < d; ++j)
+    if (c.in_col[j] < 0 || c.in_col[j] >= d) return NIS_E_ARG;
+  return NIS_OK;
+}
+
+extern "C" int nis_flow_create(const nis_cell_desc* cells, int32_t n_cells, int32_t d, const int32_t* out_col, nis_flow** out) {
+  if (!cells || !out || !out_col || n_cells < 1 || n_cells > NIS_MAX_CELLS || d < 2 || d > NIS_MAX_DIM) return NIS_E_ARG;
+  nis_flow* f = new nis_flow();
+  f->d = d;
+  f->n_cells = n_cells;
+  int brow = 0;
+  for (int i = 0; i < n_cells; ++i) {
+    int rc = validate_cell(cells[i], d);
+    if (rc != NIS_OK) {
+      delete f;
+      return rc;
+    }
+    f->cells.push_back(cells[i]);
+    f->bins_row.push_back(brow);
+    brow += cell_T(cells[i]);
+  }
+  for (int j = 0; j < d; ++j) {
+    if (out_col[j] < 0 || out_col[j] >= d) {
+      delete f;
+      return NIS_E_ARG;
+    }
+    f->out_col[j] = out_col[j];
+  }
+  f->packed_params.assign(n_cells, nullptr);
+  f->packed_running.assign(n_cells, nullptr);
+  *out = f;
+  return NIS_OK;
+}
+
+extern "C" void nis_flow_destroy(nis_flow* f) { delete f; }
+
+extern "C" size_t nis_flow_workspace_bytes(const nis_flow* f, int64_t n_batches) {
+  const int G = (int)std::max<int64_t>(1, n_batches);
+  return WS_HEADER + nis_flow_layout(f, G, nullptr, nullptr) * sizeof(double);
+}
+// ---------------------------------------------------------------------------------------------
+// k_pack: reference-order parameter blob -> zero-padded WM-strided weights (+ eval-mode BN affine).
+__global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double* __restrict__ prm, const double* __restrict__ run,
+                                                  int eval_mode, double* wp, double* wlast, double* bias, double* gb, double* hb,
+                                                  int hidden_bias) {
+  const int tid = blockIdx.x * NIS_TPB + threadIdx.x, nth = gridDim.x * NIS_TPB;
+  size_t off = 0;
+  int roff = 0;
+  for (int l = 0; l <= c.L; ++l) {
+    const int F = cellk_feat(c, l);
+    const int O = l < c.L ? c.width[l] : c.R;
+    const double* gam = prm + off;
+    const double* bet = prm + off + F;
+    const double* W = prm + off + 2 * F;
+    // bias of the Linear that FEEDS this BN layer (NIS_AFFINE): the kernels evaluate the Linear without it -- a constant
+    // in front of a BatchNorm cancels -- and account for it where it is visible: the running mean and the eval-mode shift
+    const double* hbin = (hidden_bias && l >= 1) ? prm + off - F : nullptr;
+    for (int j = tid; j < WM; j += nth) {
+      const double g = j < F ? gam[j] : 0.0, b = j < F ? bet[j] : 0.0;
+      const double hbv = (hbin && j < F) ? hbin[j] : 0.0;
+      gb[(l * 2 + 0) * WM + j] = g;
+      gb[(l * 2 + 1) * WM + j] = b;
+      if (hb) hb[l * WM + j] = hbv;
+      if (eval_mode) {                       // BatchNorm1d.eval(): running statistics
+        double sc = 0.0, sh = 0.0;
+        if (j < F) {
+          sc = g / sqrt(run[roff + F + j] + NIS_BN_EPS);
+          sh = b - (run[roff + j] - hbv) * sc;
+        }
+        c.coef[(l * 2 + 0) * WM + j] = sc;
+        c.coef[(l * 2 + 1) * WM + j] = sh;
+      }
+    }
+    if (l < c.L) {
+      double* dst = wp + (size_t)l * WM * WM;
+      for (int e = tid; e < WM * WM; e += nth) {
+        const int j = e / WM, i = e % WM;
+        dst[e] = (j < O && i < F) ? W[(size_t)j * F + i] : 0.0;
+      }
+    } else {
+      for (size_t e = tid; e < (size_t)c.R * WM; e += nth) {
+        const int r = (int)(e / WM), i = (int)(e % WM);
+        wlast[e] = (i < F) ? W[(size_t)r * F + i] : 0.0;
+      }
+      const double* bs = W + (size_t)O * F;
+      for (int r = tid; r < c.R; r += nth) bias[r] = bs[r];
+    }
+    off += 2 * (size_t)F + (size_t)O * F;
+    if (l < c.L && hidden_bias) off += O;
+    roff += 2 * F;
+  }
+}
+
+// k_pack_mfma: padded row-major images -> per-(row tile, k-step) fragments of 64 contiguous doubles, lane l holding
+// W[16 jt + (l & 15)][4 q + (l >> 4)]  (the A operand of v_mfma_f64_16x16x4_f64).
+// affT > 0 (NIS_AFFINE with T transformed columns): the last layer's rows [scale | shift][T] are interleaved to
+// [t][scale, shift], so that a column's outputs are contiguous like those of the piecewise cells.
+__global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int RT, const double* __restrict__ wp,
+                                                       const double* __restrict__ wlast, const double* __restrict__ bias,
+                                                       double* __restrict__ wm_all, double* __restrict__ wm_last,
+                                                       double* __restrict__ bias_pad, int affT) {
+  const size_t tid = (size_t)blockIdx.x * NIS_TPB + threadIdx.x, nth = (size_t)gridDim.x * NIS_TPB;
+  const int JT = WM / 16, KQ = WM / 4;
+  const size_t nh = (size_t)L * WM * WM;
+  for (size_t e = tid; e < nh; e += nth) {
+    const int lane = (int)(e & 63);
+    const size_t frag = e >> 6;
+    const int q = (int)(frag % KQ), jt = (int)((frag / KQ) % JT), l = (int)(frag / ((size_t)KQ * JT));
+    const int j = 16 * jt + (lane & 15), k = 4 * q + (lane >> 4);
+    wm_all[e] = wp[(size_t)l * WM * WM + (size_t)j * WM + k];
+  }
+  const size_t nl = (size_t)RT * KQ * 64;
+  for (size_t e = tid; e < nl; e += nth) {
+    const int lane = (int)(e & 63);
+    const size_t frag = e >> 6;
+    const int q = (int)(frag % KQ), jt = (int)(frag / KQ);
+    const int j = 16 * jt + (lane & 15), k = 4 * q + (lane >> 4);
+    const int jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;          // packed row j <- blob row jo
+    wm_last[e] = j < R ? wlast[(size_t)jo * WM + k] : 0.0;
+  }
+  for (size_t e = tid; e < (size_t)RT * 16; e += nth) {
+    const int j = (int)e, jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;
+    bias_pad[e] = e < (size_t)R ? bias[jo] : 0.0;
+  }
+}
+
+hipError_t nis_launch_pack(const CellK& c, int WM, const double* prm, const double* run, int eval_mode, double* wp, double* wlast,
+                           double* bias, double* gb, double* hb, int hidden_bias, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack, dim3(std::max(1, grid)), dim3(NIS_TPB), 0, s, c, WM, prm, run, eval_mode, wp, wlast, bias, gb, hb, hidden_bias);
+  return hipGetLastError();
+}
+
+hipError_t nis_launch_pack_mfma(int WM, int L, int R, int RT, const double* wp, const double* wlast, const double* bias, double* wm_all,
+                                double* wm_last, double* bias_pad, int affT, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_mfma, dim3(std::max(1, grid)), dim3(NIS_TPB), 0, s, WM, L, R, RT, wp, wlast, bias, wm_all, wm_last, bias_pad, affT);
+  return hipGetLastError();
+}

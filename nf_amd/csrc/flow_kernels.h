@@ -641,13 +641,63 @@ __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __
 // them, and behind them C_ab = sum (x_a - mean_a)(x_b - mean_b) for a < b (slot 3 P + cellk_pair(P, a, b)).  BN_1's batch
 // statistics follow from these (load_coefs, CellK::dcov), so the layer-1 statistics launch of a matrix-core cell -- a full
 // launch with its prologue for 8 MFMAs per 32 samples -- is gone.  Sums are taken about the workgroup's first sample.
-template <int WM, int TPB>
-__global__ __launch_bounds__(TPB) void k_bn_stats0_cov(CellK c, const double* __restrict__ planes, long ld, long N) {
-  constexpr int PM = 8, NS2 = PM * (PM + 1) / 2, NV = PM + NS2 + 1, NW = TPB / 64;
+// Workgroup reduction + record store shared by every producer of such records (k_bn_stats0_cov, the in-kernel-draw ingest): every
+// thread holds sums about the per-feature shifts lsh[p] -- S1[a] = sum (x_a - lsh_a), S2[tri(a, b)] = sum (x_a - lsh_a)(x_b - lsh_b).
+#define NIS_COV_PM 8
+#define NIS_COV_NS2 (NIS_COV_PM * (NIS_COV_PM + 1) / 2)
+template <int TPB>
+__device__ __forceinline__ void cov_records_emit(const double (&S1)[NIS_COV_PM], const double (&S2)[NIS_COV_NS2], double cnt, const double* lsh,
+                                                 int P, double* out) {
+  constexpr int PM = NIS_COV_PM, NS2 = NIS_COV_NS2, NV = PM + NS2 + 1, NW = TPB / 64;
   __shared__ double wsum[NW][NV];
   __shared__ double tot[NV];
-  __shared__ double lsh[PM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int p = 0; p < PM; ++p) {
+    const double v = wave_sum(S1[p]);
+    if (lane == 0) wsum[wave][p] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < NS2; ++k) {
+    const double v = wave_sum(S2[k]);
+    if (lane == 0) wsum[wave][PM + k] = v;
+  }
+  {
+    const double v = wave_sum(cnt);
+    if (lane == 0) wsum[wave][NV - 1] = v;
+  }
+  __syncthreads();
+  if (tid < NV) {
+    double v = 0.0;
+    for (int w = 0; w < NW; ++w) v += wsum[w][tid];
+    tot[tid] = v;
+  }
+  __syncthreads();
+  const double n = tot[NV - 1];
+  auto s2at = [&](int a, int b) { return tot[PM + a * PM - a * (a - 1) / 2 + (b - a)]; };      // a <= b
+  if (tid < P) {
+    const double s1 = tot[tid];
+    out[tid * 3 + 0] = n;
+    out[tid * 3 + 1] = n > 0.0 ? lsh[tid] + s1 / n : 0.0;
+    out[tid * 3 + 2] = n > 0.0 ? fmax(s2at(tid, tid) - s1 * s1 / n, 0.0) : 0.0;
+  }
+  const int npair = P * (P - 1) / 2;
+  if (tid >= 64 && tid < 64 + npair) {
+    int m = tid - 64, pa = 0, pb = 1;
+    for (int a = 0; a < P - 1; ++a) {
+      const int row = P - 1 - a;
+      if (m < row) { pa = a; pb = a + 1 + m; break; }
+      m -= row;
+    }
+    out[3 * P + (tid - 64)] = n > 0.0 ? s2at(pa, pb) - tot[pa] * tot[pb] / n : 0.0;
+  }
+}
+
+template <int WM, int TPB>
+__global__ __launch_bounds__(TPB) void k_bn_stats0_cov(CellK c, const double* __restrict__ planes, long ld, long N) {
+  constexpr int PM = NIS_COV_PM, NS2 = NIS_COV_NS2;
+  __shared__ double lsh[PM];
+  const int tid = threadIdx.x;
   const int g = c.g0 + blockIdx.y, P = c.P;
   planes += (size_t)g * c.plane_gs;
   const long i_blk = (long)blockIdx.x * TPB;
@@ -694,46 +744,8 @@ __global__ __launch_bounds__(TPB) void k_bn_stats0_cov(CellK c, const double* __
       cnt += i < N ? 1.0 : 0.0;
     }
   }
-#pragma unroll
-  for (int p = 0; p < PM; ++p) {
-    const double v = wave_sum(S1[p]);
-    if (lane == 0) wsum[wave][p] = v;
-  }
-#pragma unroll
-  for (int k = 0; k < NS2; ++k) {
-    const double v = wave_sum(S2[k]);
-    if (lane == 0) wsum[wave][PM + k] = v;
-  }
-  {
-    const double v = wave_sum(cnt);
-    if (lane == 0) wsum[wave][NV - 1] = v;
-  }
-  __syncthreads();
-  if (tid < NV) {
-    double v = 0.0;
-    for (int w = 0; w < NW; ++w) v += wsum[w][tid];
-    tot[tid] = v;
-  }
-  __syncthreads();
-  double* out = c.partials + (((size_t)0 * c.G + g) * c.maxb + blockIdx.x) * WM * 3;
-  const double n = tot[NV - 1];
-  auto s2at = [&](int a, int b) { return tot[PM + a * PM - a * (a - 1) / 2 + (b - a)]; };      // a <= b
-  if (tid < P) {
-    const double s1 = tot[tid];
-    out[tid * 3 + 0] = n;
-    out[tid * 3 + 1] = n > 0.0 ? lsh[tid] + s1 / n : 0.0;
-    out[tid * 3 + 2] = n > 0.0 ? fmax(s2at(tid, tid) - s1 * s1 / n, 0.0) : 0.0;
-  }
-  const int npair = P * (P - 1) / 2;
-  if (tid >= 64 && tid < 64 + npair) {
-    int m = tid - 64, pa = 0, pb = 1;
-    for (int a = 0; a < P - 1; ++a) {
-      const int row = P - 1 - a;
-      if (m < row) { pa = a; pb = a + 1 + m; break; }
-      m -= row;
-    }
-    out[3 * P + (tid - 64)] = n > 0.0 ? s2at(pa, pb) - tot[pa] * tot[pb] / n : 0.0;
-  }
+  __syncthreads();                                  // lsh
+  cov_records_emit<TPB>(S1, S2, cnt, lsh, P, c.partials + (((size_t)0 * c.G + g) * c.maxb + blockIdx.x) * WM * 3);
 }
 
 // G > 1: one workgroup per batch merges the records of BN layer `layer` and publishes scale / shift (+ the batch

@@ -27,6 +27,13 @@ struct RamboK {
   long r_ld;
   int col_major;
   int ncol;
+  // ---- batched plane sets + moment rider (nis_rambo_moments: the integrand side of a fused flow -> RAMBO weight -> moments step).
+  //      blockIdx.y = batch g: inputs at r + g r_gs, weights (optional) at weight + g w_gs; mom_part != null: the weight times the
+  //      flow's Jacobian jac[g r_gs + i] is reduced to one (count, mean, M2, max) record per workgroup, mom_part[(g maxb + block) 4]
+  long r_gs, w_gs;
+  const double* jac;
+  double* mom_part;
+  int mom_maxb;
 };
 
 #define RB_EPS 1.4901161193847656e-08     /* np.finfo(float).eps ** 0.5   (utils.py:151) */
@@ -217,8 +224,14 @@ __global__ __launch_bounds__(RB_TPB, (MODE == 0 && NF <= 4) ? RB_WAVES : 1)
 void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict__ momenta,
                                                   double* __restrict__ weight, int* __restrict__ status) {
   extern __shared__ double rb_lds[];
+  __shared__ double rb_fmom[RB_TPB / 64][4];
   constexpr int LM = 4 * (NF + 2);                   // doubles of one sample's momenta
   const int tid = threadIdx.x;
+  r += (size_t)blockIdx.y * k.r_gs;
+  if (weight) weight += (size_t)blockIdx.y * k.w_gs;
+  const double* const jac = k.mom_part ? k.jac + (size_t)blockIdx.y * k.r_gs : nullptr;
+  double mS1 = 0.0, mS2 = 0.0, mcnt = 0.0, mmax = -__builtin_huge_val(), mshift = 0.0;
+  bool mfirst = true;
   constexpr bool HAS_PDF = MODE >= 1, HAS_CUTS = MODE >= 2, GEN = MODE >= 3;
   const bool pdf_active = HAS_PDF ? (k.d.flags & NIS_RAMBO_PDF_ACTIVE) != 0 : false;
   const bool use_tau = HAS_PDF ? (k.d.flags & NIS_RAMBO_TAU) != 0 : false;
@@ -528,7 +541,20 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     }
     wtot *= factor;
     const double shat = x1 * x2 * (k.d.E_cm * k.d.E_cm);
-    if (live) weight[i] = wtot * nis_rcp(2 * shat);
+    const double wv = wtot * nis_rcp(2 * shat);
+    if (live && weight) weight[i] = wv;
+    if (jac) {                                       // moment rider: f(X) J with f = the phase-space weight (manager.py:397-400)
+      const double v = live ? wv * jac[i] : 0.0;
+      if (mfirst) {
+        mshift = wave_first(v);
+        mfirst = false;
+      }
+      const double t = live ? v - mshift : 0.0;
+      mS1 += t;
+      mS2 = fma(t, t, mS2);
+      mcnt += live ? 1.0 : 0.0;
+      mmax = live ? fmax(mmax, v) : mmax;
+    }
   };
   const std::integral_constant<bool, true> yes;
   const std::integral_constant<bool, false> no;
@@ -545,6 +571,7 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     if ((long)blockIdx.x < ntiles) fetch(blockIdx.x, rvn);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) process(tile, no, no);
 #endif
+    if (jac) block_record<RB_TPB / 64>(mshift, mS1, mS2, mcnt, mmax, rb_fmom, k.mom_part + ((size_t)blockIdx.y * k.mom_maxb + blockIdx.x) * 4);
   }
 }
 
@@ -567,10 +594,13 @@ extern "C" int nis_rambo_forward(const nis_rambo_desc* dh, const double* r, int6
   return nis_rambo_forward_pdf(dh, nullptr, r, r_ld, r_col_major, r_cols_host, N, momenta, weight, status, stream);
 }
 
-extern "C" int nis_rambo_forward_pdf(const nis_rambo_desc* dh, const nis_pdf1d* pdfh, const double* r, int64_t r_ld, int32_t r_col_major,
-                                     const int32_t* r_cols_host, int64_t N, double* momenta, double* weight, int32_t* status,
-                                     void* stream) {
-  if (!dh || !r || !weight || !status || N < 1) return NIS_E_ARG;
+// common host side: descriptor -> kernel constants, grid, MODE / n dispatch.  G plane sets (gs doubles apart) as blockIdx.y;
+// mom_part != null adds the moment rider (weights-only, column-major input)
+static int rambo_launch(const nis_rambo_desc* dh, const nis_pdf1d* pdfh, const double* r, int64_t r_ld, int32_t r_col_major,
+                        const int32_t* r_cols_host, int64_t N, double* momenta, double* weight, int32_t* status, hipStream_t s, int G,
+                        long r_gs, long w_gs, const double* jac, double* mom_part, int* grid_out) {
+  if (!dh || !r || !status || N < 1 || G < 1) return NIS_E_ARG;
+  if (!weight && !mom_part) return NIS_E_ARG;
   if (pdfh)
     for (int b = 0; b < 2; ++b)
       if (pdfh[b].nx != 0 && (pdfh[b].nx < 2 || !pdfh[b].logx || !pdfh[b].xf)) return NIS_E_ARG;
@@ -588,6 +618,11 @@ extern "C" int nis_rambo_forward_pdf(const nis_rambo_desc* dh, const nis_pdf1d* 
   k.ncol = 3 * n - 4 + (pdf_active ? 2 : 0);
   k.r_ld = r_ld;
   k.col_major = r_col_major;
+  k.r_gs = r_gs;
+  k.w_gs = w_gs;
+  k.jac = jac;
+  k.mom_part = mom_part;
+  k.mom_maxb = NIS_MAXB;
   if (!r_col_major && r_ld < k.ncol) return NIS_E_ARG;
   if (r_col_major && r_ld < N) return NIS_E_ARG;
   for (int c = 0; c < k.ncol; ++c) k.cols[c] = (r_col_major && r_cols_host) ? r_cols_host[c] : c;
@@ -605,23 +640,24 @@ extern "C" int nis_rambo_forward_pdf(const nis_rambo_desc* dh, const nis_pdf1d* 
   k.mtot = tot;
   const double base = (tot > 1.0 ? tot : 1.0) / dh->E_cm;   // absolute_Ecm_min = 1 (:68,:164-165)
   k.tau_min = base * base;
-  hipStream_t s = (hipStream_t)stream;
   const int LMh = 4 * (n + 2);
   const size_t lds_bytes = (size_t)RB_TPB * (LMh + 1) * sizeof(double);      // output staging only
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
   static const int mult = getenv("NIS_RAMBO_GRID_MULT") ? atoi(getenv("NIS_RAMBO_GRID_MULT")) : 2;
-  // workgroups: `mult` x what the chip holds at once.  NIS_RAMBO_BALANCE=1: evenly loaded instead -- ceil(tiles / rounds)
-  // workgroups of `rounds` tiles each (no partial last round)
-  const int64_t ntiles_h = (N + RB_TPB - 1) / RB_TPB, cap = (int64_t)per_cu * 256 * mult;
+  // workgroups: `mult` x what the chip holds at once (shared by the G plane sets).  NIS_RAMBO_BALANCE=1: evenly loaded instead --
+  // ceil(tiles / rounds) workgroups of `rounds` tiles each (no partial last round)
+  int64_t ntiles_h = (N + RB_TPB - 1) / RB_TPB, cap = std::max<int64_t>(1, (int64_t)per_cu * 256 * mult / G);
+  if (mom_part) cap = std::min<int64_t>(cap, NIS_MAXB);                // one moment record per workgroup
   const int64_t rounds = std::max<int64_t>(1, (ntiles_h + cap - 1) / cap);
   static const int balance = getenv("NIS_RAMBO_BALANCE") ? 1 : 0;      // measured 7 % SLOWER (55.1 vs 51.7 us per 1e6): oversubscribed workgroups balance better
   const int grid = (int)std::max<int64_t>(1, balance ? (ntiles_h + rounds - 1) / rounds : std::min<int64_t>(cap, ntiles_h));
+  if (grid_out) *grid_out = grid;
   const bool has_pdf = (dh->flags & (NIS_RAMBO_PDF_ACTIVE | NIS_RAMBO_LAB_BOOST)) != 0;          // TAU only matters with PDFs
   const bool has_cuts = dh->pT_mincut > 0. || dh->delR_mincut > 0. || dh->rap_maxcut > 0.;
   const bool need_gen = dh->bisect_levels > 0;
   const int mode = need_gen ? 3 : has_cuts ? 2 : has_pdf ? 1 : 0;
 #define RB_LAUNCH(NFV, M) \
-  hipLaunchKernelGGL((k_rambo<NFV, M>), dim3(grid), dim3(RB_TPB), lds_bytes, s, k, r, (long)N, momenta, weight, (int*)status)
+  hipLaunchKernelGGL((k_rambo<NFV, M>), dim3(grid, G), dim3(RB_TPB), lds_bytes, s, k, r, (long)N, momenta, weight, (int*)status)
 #define RB_CASE(NFV)                   \
   case NFV:                            \
     if (mode == 0)                     \
@@ -641,4 +677,32 @@ extern "C" int nis_rambo_forward_pdf(const nis_rambo_desc* dh, const nis_pdf1d* 
 #undef RB_CASE
 #undef RB_LAUNCH
   return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
+}
+
+extern "C" int nis_rambo_forward_pdf(const nis_rambo_desc* dh, const nis_pdf1d* pdfh, const double* r, int64_t r_ld, int32_t r_col_major,
+                                     const int32_t* r_cols_host, int64_t N, double* momenta, double* weight, int32_t* status,
+                                     void* stream) {
+  if (!weight) return NIS_E_ARG;
+  return rambo_launch(dh, pdfh, r, r_ld, r_col_major, r_cols_host, N, momenta, weight, status, (hipStream_t)stream, 1, 0, 0, nullptr, nullptr,
+                      nullptr);
+}
+
+// merge of the per-workgroup records, one workgroup per plane set (api_moments.hip)
+hipError_t nis_launch_moments_final(const double* partials, int nparts, double* out4, int maxb, int G, hipStream_t s);
+
+extern "C" size_t nis_rambo_moments_workspace_bytes(int32_t n_batches) {
+  return (size_t)std::max(1, n_batches) * NIS_MAXB * 4 * sizeof(double);
+}
+
+extern "C" int nis_rambo_moments(const nis_rambo_desc* dh, const nis_pdf1d* pdfh, const double* planes, int64_t ld, int64_t plane_gs,
+                                 const int32_t* cols_host, int32_t jplane, int64_t N, int32_t n_batches, double* weight_out, double* out4,
+                                 int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!planes || !cols_host || !out4 || jplane < 0 || n_batches < 1 || n_batches > 65535 || ld < N) return NIS_E_ARG;
+  if (!workspace || workspace_bytes < nis_rambo_moments_workspace_bytes(n_batches)) return NIS_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = 0;
+  const int rc = rambo_launch(dh, pdfh, planes, ld, 1, cols_host, N, nullptr, weight_out, status, s, n_batches, (long)plane_gs, (long)N,
+                              planes + (size_t)jplane * ld, (double*)workspace, &grid);
+  if (rc != NIS_OK) return rc;
+  return nis_launch_moments_final((const double*)workspace, grid, out4, NIS_MAXB, n_batches, s) == hipSuccess ? NIS_OK : NIS_E_HIP;
 }

@@ -339,16 +339,16 @@ class FlowEngine:
         self._raise_on_status(ws[:4].view(torch.int32))
         return fres
 
+    def rng_mode(self, G, N, train=True, f_kind=_lib.NIS_F_CAMEL, keep_planes=False):
+        """How `integrate_steps_rng` draws for this call -- asked of the library itself (`nis_integrate_rng_mode`, the very
+        predicate its launch planner uses): 2 = the d = 2 direct-row chain keeps float32 rows in a spare state plane, 1 = the
+        ingest launch generates the float64 planes (every other model), 0 = invalid arguments."""
+        return int(self.L.nis_integrate_rng_mode(self.handle, int(G), int(N), _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL,
+                                                 int(f_kind), 1 if keep_planes else 0))
+
     def rng_supported(self, train=True, f_kind=_lib.NIS_F_CAMEL):
-        """True for the model class whose first launch can draw the batch itself (d = 2 PWQuad chain of SPEC kernels, fused
-        camel, train-mode BN): include/nis_hip.h, nis_integrate_steps_rng."""
-        if self.d != 2 or not train or f_kind != _lib.NIS_F_CAMEL:
-            return False
-        for c in self.cells:
-            if c.KIND != _lib.NIS_PWQUAD or c.pass_through_size != 1 or int(c.n_bins) not in (4, 8, 16) or \
-                    len(c.hidden_widths) != 3 or max(c.hidden_widths) > 3:
-                return False
-        return True
+        """True when the first launch of a step can draw the batch itself: every model with a fusable built-in integrand."""
+        return self.fusable() and self.rng_mode(1, 2, train, f_kind) > 0
 
     def integrate_step_bins(self, w, f_kind, f_params):
         """Test hook: one fused train-mode iteration on the production direct-row kernels, returning ((4,) moment record,
@@ -369,39 +369,42 @@ class FlowEngine:
         self._stats_bump(1)
         return out4[0], bins
 
-    def integrate_steps_rng(self, G, N, dev, f_kind, f_params, out4, seed, stream0, token=None, w_out=None, rng_state=None):
+    def integrate_steps_rng(self, G, N, dev, f_kind, f_params, out4, seed, stream0, token=None, w_out=None, rng_state=None,
+                            train=True, planes=None, keep_planes=False, ws=None):
         """The same G iterations with the draw inside the step (manager.py:395): batch g is drawn on the device from Philox
-        stream `stream0 + g` of key `seed` (mapping: include/nis_hip.h) by the launch that gathers BN_0's records; no input
-        buffer exists.  Models outside that kernel class get the same draws from `philox_rows` and run `integrate_steps`.
-        w_out: optional (G, N, 2) float32 receiving the draws.  rng_state: optional int64[2] device tensor {seed, next stream}
-        that overrides seed / stream0 and is advanced by G on the device (IntegratePlan: graph replays)."""
+        stream `stream0 + g` of key `seed` (mapping: include/nis_hip.h) by the first launch of the set; no input buffer exists.
+        w_out: optional (G, N, d) float32 receiving the draws.  rng_state: optional int64[2] device tensor {seed, next stream}
+        that overrides seed / stream0 and is advanced by G on the device (IntegratePlan: graph replays).
+        planes: (G, d+1, N) float64 state to use (with keep_planes: X and J are left there); ws: workspace to use (a captured
+        launch set owns both, so no other call can move or re-layout what its graph points at)."""
         _lib.require_gpu()
         dev = torch.device(dev)
-        if N < 2:
+        if train and N < 2:
             raise ValueError("Expected more than 1 value per channel when training")
-        if not self.rng_supported(True, f_kind):
-            if rng_state is not None:
-                raise _lib.NisError("device-resident generator state needs the in-kernel draw (rng_supported())")
-            w = philox_rows(seed, stream0, G, N, self.d, dev)
-            if w_out is not None:
-                w_out.copy_(w)
-            return self.integrate_steps(w, True, f_kind, f_params, out4, token=token)
         pp, rp, tp = self._pointers(dev)
-        ws, wsb = self._workspace(dev, G)
+        if ws is None:
+            ws, wsb = self._workspace(dev, G)
+        else:
+            wsb = self.L.nis_flow_workspace_bytes(self.handle, G)
+            if ws.numel() < wsb:
+                raise _lib.NisError("integrate_steps_rng: the workspace passed in is too small for this set size")
         if token is None:
             token = self.pack_token()
-        planes = None
-        if not self.resident(G, N, True, f_kind):
+        if planes is None and not self.resident(G, N, train, f_kind):
             planes = self._planes_scratch(G, N, dev)
         fp = (C.c_double * 4)(*(list(f_params) + [0.0] * 4)[:4])
         with _lib.on_device(dev):
-            rc = self.L.nis_integrate_steps_rng(self.handle, G, N, pp, rp, tp, _lib.NIS_BN_TRAIN, token, f_kind, fp, seed, stream0,
+            rc = self.L.nis_integrate_steps_rng(self.handle, G, N, pp, rp, tp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL, token,
+                                                f_kind, fp, seed, stream0,
                                                 rng_state.data_ptr() if rng_state is not None else None,
                                                 w_out.data_ptr() if w_out is not None else None,
-                                                planes.data_ptr() if planes is not None else None, N, out4.data_ptr(),
-                                                ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+                                                planes.data_ptr() if planes is not None else None, N, 1 if keep_planes else 0,
+                                                out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
         _lib.check(rc, "nis_integrate_steps_rng")
-        self._stats_bump(1)
+        if train:
+            self._stats_bump(1)
+        if ws is self._ws:
+            self._raise_on_status(ws[:4].view(torch.int32))
         return None
 
     def _planes_scratch(self, G, N, dev):
@@ -413,8 +416,13 @@ class FlowEngine:
 
     def plan(self, G, N, dev, f_kind, f_params):
         """Cached IntegratePlan (one captured launch set) for this model state, set size and integrand."""
-        # parameters only: the BN running statistics change with every train-mode forward and do not enter a train-mode set
-        psig = tuple((p.data_ptr(), p._version) for c in self.cells for p in c.parameters())
+        for c in self.cells:
+            ensure_flat(c, dev)
+        # parameter VALUES (version counters) and the ADDRESSES the captured launches point at: parameter blob, BN running
+        # statistics and counters (ensure_flat re-creates them after .to() / deepcopy).  The running statistics' values change
+        # with every train-mode forward and do not enter a train-mode set.
+        psig = tuple((p.data_ptr(), p._version) for c in self.cells for p in c.parameters()) + \
+            tuple((c._flat.data_ptr(), c._running.data_ptr(), c._tracked.data_ptr()) for c in self.cells)
         key = (int(G), int(N), str(torch.device(dev)), int(f_kind), tuple(float(x) for x in f_params), psig)
         cache = getattr(self, "_plans", None)
         if cache is None or cache[0] != key:
@@ -436,13 +444,19 @@ class IntegratePlan:
     before the host has issued the next one: the first set after a synchronize costs ~90-330 us more than a later one
     (tools/graph_probe.py).  A captured set is submitted whole.  The generator state {seed, next stream} lives on the
     device and is advanced by the set's last launch, so every replay draws fresh numbers; records land in `self.out`.
-    Valid while the model's parameters are unchanged (integrate() never changes them)."""
+    Valid while the model's parameters are unchanged (integrate() never changes them).
+
+    The plan OWNS everything its graph points at besides the model's own blobs: workspace (parameter image, BN records and
+    coefficients), state planes, generator state and output records.  No other engine call uses them, so nothing can be
+    re-allocated, re-packed with another set size's layout or overwritten between replays."""
 
     def __init__(self, eng, G, N, dev, f_kind, f_params):
         self.eng, self.G, self.N, self.dev = eng, int(G), int(N), torch.device(dev)
         self.token = eng.pack_token()
         self.state = torch.zeros(2, dtype=torch.int64, device=self.dev)
         self.out = torch.zeros((self.G, 4), dtype=torch.double, device=self.dev)
+        self.ws = torch.empty(eng.L.nis_flow_workspace_bytes(eng.handle, self.G), dtype=torch.uint8, device=self.dev)
+        self.planes = torch.empty((self.G, eng.d + 1, self.N), dtype=torch.double, device=self.dev)
         cells = eng.cells
         for c in cells:
             ensure_flat(c, self.dev)
@@ -451,7 +465,8 @@ class IntegratePlan:
         side.wait_stream(torch.cuda.current_stream(self.dev))
 
         def call(n):
-            eng.integrate_steps_rng(self.G, n, self.dev, f_kind, f_params, self.out, 0, 0, token=self.token, rng_state=self.state)
+            eng.integrate_steps_rng(self.G, n, self.dev, f_kind, f_params, self.out, 0, 0, token=self.token, rng_state=self.state,
+                                    planes=self.planes, ws=self.ws)
 
         self._call = call
 
@@ -462,7 +477,6 @@ class IntegratePlan:
                 c._running.copy_(r)
                 c._tracked.copy_(t)
             eng._stats_bump(-1)
-            eng._planes_scratch(self.G, self.N, self.dev)
             # thread_local: other threads of the process (the RCCL watchdog of a multi-rank job polls its events) must not
             # invalidate the capture.  If the capture fails anyway the plan launches eagerly -- same launches, same results.
             self.graph = torch.cuda.CUDAGraph()
@@ -474,6 +488,7 @@ class IntegratePlan:
                 import sys
                 print(f"nf_amd: launch-set capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
                 self.graph = None
+        self.captured = self.graph is not None
         torch.cuda.current_stream(self.dev).wait_stream(side)
 
     def reset(self, seed, stream0=0):
@@ -496,15 +511,13 @@ class IntegratePlan:
 
 
 def philox_rows(seed, stream0, G, N, d, dev):
-    """(G, N, d) float32 uniform draws of the library's counter-based generator (d == 2: exactly the draws the persistent
-    kernel makes for the same seed / streams; include/nis_hip.h gives the mapping)."""
+    """(G, N, d) float32 uniform draws of the library's counter-based generator: exactly the numbers `integrate_steps_rng`
+    draws inside its first launch for the same seed / streams (include/nis_hip.h gives the mapping for d == 2 and d != 2)."""
     _lib.require_gpu()
-    if d != 2:
-        raise _lib.NisError("philox_rows: the in-kernel generator is defined for d = 2 rows")
     dev = torch.device(dev)
-    out = torch.empty((G, N, 2), dtype=torch.float32, device=dev)
+    out = torch.empty((G, N, d), dtype=torch.float32, device=dev)
     with _lib.on_device(dev):
-        _lib.check(_lib.lib().nis_philox_rows(seed, stream0, G, N, out.data_ptr(), _lib.stream_ptr(dev)), "nis_philox_rows")
+        _lib.check(_lib.lib().nis_philox_rows(seed, stream0, G, N, d, out.data_ptr(), _lib.stream_ptr(dev)), "nis_philox_rows")
     return out
 
 

@@ -86,3 +86,10 @@ class RamboWeight:
     def from_planes(self, planes, out_col, N):
         wgt, status = self.gen.weights_from_planes(self.E_cm, planes, out_col, N, *self.cuts, pdgs=self.pdgs)
         return wgt
+
+    def moments_from_planes(self, planes, out_col, jplane, N, out4, status):
+        """(G, d+1, N) kept planes -> (G, 4) moment records of weight * J, one launch set, no host sync."""
+        self.gen.moments_from_planes(self.E_cm, planes, out_col, jplane, N, out4, status, *self.cuts, pdgs=self.pdgs)
+
+    def check_status(self, status):
+        return self.gen.check_status(status)

@@ -68,6 +68,10 @@ def run_flow(engine, modules, x, has_jac, train):
     elif not engine.backward_supported():
         why = ("the adjoint kernels do not cover this model (PWQuad n_bins > 32, or a PWLin head whose LDS image "
                "does not fit): forward-only on this build")
+    if why is not None and train:
+        # a TRAINING forward outside the adjoint class: refuse before anything runs -- the forward would advance the BatchNorm
+        # running statistics and the failure would surface mid-step, inside loss.backward()
+        raise _lib.NisError(why)
     if why is not None:
         return _ForwardOnlyFn.apply(engine, train, has_jac, why, x, *params)
     from ..flow import ensure_flat

@@ -256,6 +256,8 @@ class BasicManager(ModelAPI):
                 self.best_loss = loss
                 self.best_var = float(var)
                 self.best_loss_rel = loss / self.int_loss
+                if self.data_parallel is not None:          # every rank takes this branch together (loss is the synced one)
+                    self.data_parallel.sync_buffers(self.model)
                 self.best_model = copy.deepcopy(self.model)
                 self.best_epoch = i
                 self.best_time = (datetime.datetime.utcnow() - run.start_time).total_seconds() if run is not None else 0
@@ -396,18 +398,20 @@ class BasicManager(ModelAPI):
         model = self.best_model
         model.to(dev)
         out = torch.empty((nitn, 4), dtype=torch.double, device=dev)
-        fused = hasattr(f, "nis_kind") and isinstance(model, FlowSequential) and model.engine().fusable()
-        if fused:                           # G iterations per library call, X / J never stored
+        flow = isinstance(model, FlowSequential)
+        fusable = flow and model.engine().fusable()
+        # the draw happens inside the step (manager.py:395) when nobody replays given draws: the first launch of a set generates the
+        # float32 batch itself (Philox, keyed from torch's generator so torch.manual_seed governs it); no torch.rand launch, no input
+        in_kernel = self.sample_hook is None and (neval >= 2 or not model.training)
+        if fusable and hasattr(f, "nis_kind"):      # G iterations per library call, X / J never stored
             eng = model.engine()
             G = max(1, min(int(self.batch_iterations), nitn, max(1, (1 << 28) // max(1, neval * (self.n_flow + 1)))))
-            # the draw happens inside the step (manager.py:395) when nobody replays given draws: the first launch of a set
-            # generates the float32 batch itself (Philox, keyed from torch's generator so torch.manual_seed governs it),
-            # and whole sets are replayed from a hipGraph (flow.IntegratePlan)
-            in_kernel = self.sample_hook is None and model.training and eng.rng_supported(True, f.nis_kind) and neval >= 2
             plan = None
             if in_kernel:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-                if nitn >= G and os.environ.get("NIS_NO_GRAPH", "0") in ("", "0"):
+                # whole sets of the short-kernel d = 2 chain are replayed from a hipGraph (flow.IntegratePlan)
+                if nitn >= G and model.training and os.environ.get("NIS_NO_GRAPH", "0") in ("", "0") and \
+                        eng.rng_mode(G, neval, True, f.nis_kind) == 2:
                     plan = eng.plan(G, neval, dev, f.nis_kind, f.nis_params)
                     plan.reset(seed, 0)
             i = 0
@@ -416,36 +420,43 @@ class BasicManager(ModelAPI):
                 if plan is not None and g == G:
                     plan.run(out[i:i + g])
                 elif in_kernel:
-                    eng.integrate_steps_rng(g, neval, dev, f.nis_kind, f.nis_params, out[i:i + g], seed, i)
+                    eng.integrate_steps_rng(g, neval, dev, f.nis_kind, f.nis_params, out[i:i + g], seed, i, train=model.training)
                 else:
-                    if self.sample_hook is None:        # g batches in one generator launch instead of g launches + a stack copy
-                        w = torch.rand(g, neval, self.n_flow, dtype=torch.float32, device=dev)
-                    else:
-                        w = torch.stack([self._uniform(neval, dev, torch.float32, "integrate") for _ in range(g)])
+                    w = torch.stack([self._uniform(neval, dev, torch.float32, "integrate") for _ in range(g)])
                     eng.integrate_steps(w, model.training, f.nis_kind, f.nis_params, out[i:i + g])
                 i += g
             return out
-        planar = hasattr(f, "from_planes") and isinstance(model, FlowSequential)
-        if planar and model.engine().fusable():
-            # e.g. RAMBO weight: reads the flow's column planes, X is never assembled.  The flow part of G iterations runs as ONE
-            # launch set that keeps its planes (the rider integrates f == 1, i.e. <J>, and is ignored); the weight kernel and the
-            # moment reduction then take one batch of planes each.
+        planar = hasattr(f, "from_planes") and flow
+        if planar and fusable and hasattr(f, "moments_from_planes"):
+            # e.g. RAMBO weight: reads the flow's column planes, X is never assembled, no weights are written.  Per launch set of G
+            # iterations: the flow keeps its planes (the rider integrates f == 1, i.e. <J>, and is ignored), then ONE launch turns
+            # the G plane sets into weight * J moment records.  The status word accumulates on the device and is read once.
             eng = model.engine()
             G = max(1, min(int(self.batch_iterations), nitn, max(1, (1 << 27) // max(1, neval * (self.n_flow + 1)))))
-            scratch = torch.empty((G, 4), dtype=torch.double, device=dev)
-            planes = torch.empty((G, eng.d + 1, neval), dtype=torch.double, device=dev)
+            key = (G, eng.d, neval, str(dev))
+            if getattr(self, "_planar_key", None) != key:
+                self._planar_key = key
+                self._planar_buf = (torch.empty((G, 4), dtype=torch.double, device=dev),
+                                    torch.empty((G, eng.d + 1, neval), dtype=torch.double, device=dev),
+                                    torch.zeros(1, dtype=torch.int32, device=dev))
+            scratch, planes, status = self._planar_buf
+            status.zero_()
+            if in_kernel:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             i = 0
             while i < nitn:
                 g = min(G, nitn - i)
-                if self.sample_hook is None:
-                    w = torch.rand(g, neval, self.n_flow, dtype=torch.float32, device=dev)
+                if in_kernel:
+                    eng.integrate_steps_rng(g, neval, dev, _lib.NIS_F_ONE, [], scratch[:g], seed, i, train=model.training,
+                                            planes=planes[:g], keep_planes=True)
                 else:
                     w = torch.stack([self._uniform(neval, dev, torch.float32, "integrate") for _ in range(g)])
-                eng.integrate_steps(w, model.training, _lib.NIS_F_ONE, [], scratch[:g], planes=planes[:g])
-                for k in range(g):
-                    out[i + k] = hip_moments(f.from_planes(planes[k], eng.out_col, neval), planes[k][eng.d])
+                    eng.integrate_steps(w, model.training, _lib.NIS_F_ONE, [], scratch[:g], planes=planes[:g])
+                f.moments_from_planes(planes[:g], eng.out_col, eng.d, neval, out[i:i + g], status)
                 i += g
-            return out
+            if not f.check_status(status):                 # the ONE host read of the call
+                return out
+            # some sample had x1 == x2: the reference skips the lab boost for that WHOLE batch -- redo batch by batch below
         for i in range(nitn):
             w = self._uniform(neval, dev, torch.float32, "integrate")
             if planar:                      # e.g. RAMBO weight: reads the flow's column planes, X is never assembled
@@ -454,7 +465,7 @@ class BasicManager(ModelAPI):
                 out[i] = hip_moments(f.from_planes(res["planes"], eng.out_col, neval), res["planes"][eng.d])
                 continue
             with torch.no_grad():
-                if self._stock_input() and isinstance(model, FlowSequential):
+                if self._stock_input() and flow:
                     XJ = model.flow_forward(w, want_xj=True)["xj"]
                 else:
                     XJ = model(self.format_input(w, dev)).detach()

@@ -104,25 +104,43 @@ def merge_gathered(buf):
     return out
 
 
+_GATHER_FORM = {}        # backend name -> "tensor" | "list": which all-gather form this backend accepts for CUDA tensors
+
+
+def gather_records(loc, group=None):
+    """(world,) + loc.shape gathered copies of a CUDA tensor, one collective: `all_gather_into_tensor` (RCCL: one ncclAllGather)
+    where the backend implements it, else the list form into views of the same buffer (gloo on CUDA tensors: the rehearsal of
+    several ranks on one GPU then runs the very code path -- gather + `nis_merge_moments` -- the RCCL job runs)."""
+    ws = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    buf = torch.empty((ws,) + tuple(loc.shape), dtype=loc.dtype, device=loc.device)
+    form = _GATHER_FORM.get(backend)
+    if form in (None, "tensor") and hasattr(dist, "all_gather_into_tensor"):
+        try:
+            dist.all_gather_into_tensor(buf, loc, group=group)
+            _GATHER_FORM[backend] = "tensor"
+            return buf
+        except (RuntimeError, NotImplementedError):
+            if form == "tensor":
+                raise
+    dist.all_gather(list(buf.unbind(0)), loc, group=group)
+    _GATHER_FORM[backend] = "list"
+    return buf
+
+
 def allreduce_moments(local, group=None):
     """local: (nitn, 4) float64 records of this rank (any device).  Returns the merged (nitn, 4) records,
     identical on every rank.  One collective.
 
-    On a GPU: ONE all-gather of the records (world x nitn x 32 bytes) and ONE merge launch (`nis_merge_moments`) -- the
-    collective and the merge are inside the job's timed region, so they are two launches, not a dozen tensor operations.
-    On the CPU (gloo rehearsals, tests): all-reduce (SUM) of a zero-padded (world, nitn, 4) buffer = an exact gather, merged in
-    torch ops."""
+    On a GPU (any backend): ONE all-gather of the records (world x nitn x 32 bytes) and ONE merge launch (`nis_merge_moments`) --
+    the collective and the merge are inside the job's timed region, so they are two launches, not a dozen tensor operations.
+    On CPU tensors (gloo tests without a GPU): all-reduce (SUM) of a zero-padded (world, nitn, 4) buffer = an exact gather,
+    merged in torch ops."""
     rank, ws = world()
     if ws == 1:
         return local
-    if local.is_cuda and dist.get_backend(group) == "nccl":
-        from . import _lib
-        loc = local.contiguous()
-        buf = torch.empty((ws,) + tuple(loc.shape), dtype=torch.double, device=loc.device)
-        gather = getattr(dist, "all_gather_into_tensor", None)
-        if gather is not None:
-            gather(buf, loc, group=group)
-            return merge_gathered(buf)
+    if local.is_cuda:
+        return merge_gathered(gather_records(local.contiguous(), group))
     buf = torch.zeros((ws,) + tuple(local.shape), dtype=torch.double, device=local.device)
     buf[rank] = local
     # max slot: an empty rank holds -inf there, which must not poison the SUM -> sanitise per slot
@@ -186,11 +204,11 @@ class DataParallel:
 
     Every rank runs `_train_variance_forward_seq` on its OWN minibatches (`batch_size` / `mini_batch_size` are per
     rank; seed the ranks differently), as independent train-mode BatchNorm batches.  Per optimizer step ONE all-reduce
-    carries the flattened parameter gradients (<= 448 KB at C5), the BatchNorm running statistics (every rank's train-mode
-    forwards advance them from its OWN minibatches; averaging them each step keeps the buffers -- hence `best_model`'s
-    state_dict, checkpoints and the eval-mode `integrate=True` tail -- identical on every rank) and the bookkeeping scalars
-    (loss, variance, estimator terms); all of them are averaged over the ranks, so the optimizer states, the early-stopping
-    decisions and the saved best model stay identical everywhere.  `max f` of the survey is combined with one
+    carries the flattened parameter gradients (<= 448 KB at C5) and the bookkeeping scalars (loss, variance, estimator
+    terms), averaged over the ranks, so the optimizer states and the early-stopping decisions stay identical everywhere.
+    The BatchNorm running statistics (every rank's train-mode forwards advance them from its OWN minibatches) are merged
+    whenever a copy of the model is kept (`sync_buffers`: pooled mean / variance), so `best_model`'s state_dict, checkpoints
+    and the eval-mode `integrate=True` tail are identical on every rank.  `max f` of the survey is combined with one
     all-reduce(MAX), and the survey's loss / variance are normalised with that GLOBAL maximum.
 
         rank, ws, _ = parallel.init_from_env()
@@ -226,31 +244,40 @@ class DataParallel:
         return t / self.world
 
     def sync_buffers(self, model):
-        """Average the BatchNorm running statistics of `model` over the ranks (one all-reduce): called before a copy of the
-        model is kept (`best_model`), so that what is saved / evaluated later is the same on every rank."""
+        """Merge the BatchNorm running statistics of `model` over the ranks (one all-reduce): called before a copy of the model
+        is kept (`best_model`), so that what is saved / evaluated later is the same on every rank.  running_mean is averaged;
+        running_var is merged like the variance of pooled groups -- mean of the ranks' variances PLUS the variance of their
+        means -- so the buffers match what a single process over the union of the minibatches would hold, not a value that
+        systematically lacks the between-rank spread of the means."""
         if self.world == 1:
             return
-        stats = [b for _, b in model.named_buffers() if b.is_floating_point()]
-        if not stats:
+        bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d) and m.running_mean is not None]
+        if not bns:
             return
-        flat = torch.cat([b.detach().reshape(-1).double() for b in stats])
+        mean = torch.cat([m.running_mean.detach().reshape(-1).double() for m in bns])
+        var = torch.cat([m.running_var.detach().reshape(-1).double() for m in bns])
+        flat = torch.cat([mean, var + mean * mean])                 # E[x], E[x^2] of the pooled running estimate
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat /= self.world
+        n = mean.numel()
+        gmean, gvar = flat[:n], (flat[n:] - flat[:n] * flat[:n]).clamp_min(0.0)
         off = 0
         with torch.no_grad():
-            for b in stats:
-                n = b.numel()
-                b.copy_(flat[off:off + n].view_as(b))
-                off += n
+            for m in bns:
+                k = m.running_mean.numel()
+                m.running_mean.copy_(gmean[off:off + k].view_as(m.running_mean))
+                m.running_var.copy_(gvar[off:off + k].view_as(m.running_var))
+                off += k
 
     def sync_step(self, model, scalars):
-        """Average the gradients of `model` (in place) and the 1-d tensor `scalars` over the ranks: one all-reduce."""
+        """Average the gradients of `model` (in place) and the 1-d tensor `scalars` over the ranks: one all-reduce.  The BatchNorm
+        running statistics are NOT part of it: they do not enter a train-mode step, and touching them every step would bump their
+        version counters (re-packing the kernels' parameter image each minibatch); `sync_buffers` merges them whenever a copy of
+        the model is kept."""
         if self.world == 1:
             return scalars
         grads = [p.grad for p in model.parameters() if p.grad is not None]
-        stats = [b for name, b in model.named_buffers() if b.is_floating_point()]      # running_mean / running_var
-        flat = torch.cat([g.reshape(-1) for g in grads] + [b.detach().reshape(-1).to(grads[0].dtype) for b in stats] +
-                         [scalars.detach().reshape(-1).to(grads[0].dtype)])
+        flat = torch.cat([g.reshape(-1) for g in grads] + [scalars.detach().reshape(-1).to(grads[0].dtype)])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat /= self.world
         off = 0
@@ -258,9 +285,5 @@ class DataParallel:
             for g in grads:
                 n = g.numel()
                 g.copy_(flat[off:off + n].view_as(g))
-                off += n
-            for b in stats:
-                n = b.numel()
-                b.copy_(flat[off:off + n].view_as(b))
                 off += n
         return flat[off:].to(scalars.dtype)

@@ -1358,11 +1358,9 @@ def test_in_kernel_draws_match_documented_mapping_and_oracle(N):
     np.testing.assert_allclose(rec[:, 2] / (rec[:, 0] - 1), variances, rtol=1e-9)
 
 
-@pytest.mark.parametrize("variant", ["graph", "chains2", "chains3", "resident"])
-def test_launch_set_variants_agree_with_the_plain_path(variant, monkeypatch):
-    """hipGraph replay of a launch set, several chains on side streams and the opt-in persistent LDS-resident kernel give the
-    records of the plain launch-per-phase path (bit for bit for the graph; 1e-12 where the record partition differs) and
-    the same BatchNorm running statistics."""
+def test_graph_replay_of_a_launch_set_equals_eager_launches():
+    """hipGraph replay of a launch set gives the records of the plain launch-per-phase path bit for bit, the same BatchNorm
+    running statistics, and the same records as feeding the materialised draws."""
     import copy
     from nf_amd import integrands
     from nf_amd.flow import philox_rows
@@ -1375,16 +1373,13 @@ def test_launch_set_variants_agree_with_the_plain_path(variant, monkeypatch):
     f = integrands.Camel()
     G, N = 7, 300_017
 
-    def run(env, how):
-        for k in ("NIS_STREAMS", "NIS_MEGA"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    def run(how):
         model = copy.deepcopy(base)
         eng = model.engine()
         out = torch.zeros((G, 4), dtype=torch.double, device=dev())
         if how == "graph":
             plan = eng.plan(G, N, dev(), f.nis_kind, f.nis_params)
+            assert plan.captured, "the launch set must be captured, not fall back to eager launches"
             plan.reset(77, 3)
             plan.run(out, replay=True)
         elif how == "fed":
@@ -1392,20 +1387,218 @@ def test_launch_set_variants_agree_with_the_plain_path(variant, monkeypatch):
         else:
             eng.integrate_steps_rng(G, N, dev(), f.nis_kind, f.nis_params, out, 77, 3)
         torch.cuda.synchronize()
-        eng.resident_status(dev())
         return t2n(out), {k: t2n(v) for k, v in model.state_dict().items()}
 
-    ref, sd_ref = run({}, "rng")
-    got, sd = run({"chains2": {"NIS_STREAMS": "2"}, "chains3": {"NIS_STREAMS": "3"}, "resident": {"NIS_MEGA": "1"}}.get(variant, {}),
-                  "graph" if variant == "graph" else "rng")
-    if variant == "graph":
-        np.testing.assert_array_equal(got, ref)
-    else:
-        np.testing.assert_allclose(got, ref, rtol=1e-12)
+    ref, sd_ref = run("rng")
+    got, sd = run("graph")
+    np.testing.assert_array_equal(got, ref)
     for k in sd_ref:
         np.testing.assert_allclose(sd[k], sd_ref[k], rtol=1e-9, atol=1e-15, err_msg=k)
-    fed, _ = run({}, "fed")
+    fed, _ = run("fed")
     np.testing.assert_allclose(fed, ref, rtol=1e-12)
+
+
+@pytest.mark.parametrize("variant", ["chains2", "chains3", "resident"])
+def test_diagnostics_build_variants_agree_with_the_plain_path(variant):
+    """Several chains on side streams and the persistent LDS-resident kernel are measured dead ends that live in the
+    DIAGNOSTICS library only (libnis_hip_diag.so, `python -m nf_amd.build --diag`): there they must still give the records of the
+    plain path (1e-12: the record partition differs) and the same BatchNorm running statistics."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "nf_amd", "lib", "libnis_hip_diag.so")
+    if not os.path.exists(diag):
+        pytest.skip("diagnostics library not built (python -m nf_amd.build --diag)")
+    env = dict(os.environ, NIS_LIB=diag)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "diag_variants_check.py"), variant], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0 and "OK " + variant in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_product_library_has_no_dead_end_kernels():
+    """The product library carries neither the persistent kernel nor the multi-chain mode: the switches are inert there."""
+    from nf_amd import _lib
+    L = _lib.lib()
+    if "diag" in os.path.basename(_lib.LIB_PATH):
+        pytest.skip("running against the diagnostics library")
+    assert L.nis_diag_build() == 0
+    from nf_amd.normalizing_flows.manager import PWQuadManager
+    NF = PWQuadManager(n_flow=2)
+    NF.create_model(2, 4, [3] * 3)
+    assert not NF.best_model.engine().resident(20, 1_000_000, True, _lib.NIS_F_CAMEL)
+
+
+@pytest.mark.parametrize("n_cells,N", [(3, 20002), (4, 50_000), (3, 20001)])
+def test_in_kernel_draws_longer_d2_chains_match_the_fed_path(n_cells, N):
+    """Chains of 3 and 4 cells with in-kernel draws: an INNER cell overwrites the state plane that also holds the float32 draws, so
+    the draws must stay in the row layout there (a thread overwrites exactly the row it has read; the two-plane layout is for the
+    2-cell chain only).  Records must equal those of feeding the materialised draws, even and odd N."""
+    from nf_amd import integrands
+    from nf_amd.flow import philox_rows
+    from nf_amd.normalizing_flows.manager import PWQuadManager
+    torch.manual_seed(21)
+    NF = PWQuadManager(n_flow=2)
+    NF.create_model(n_cells, 4, [3] * 3)
+    model = NF.best_model
+    model.train()
+    eng = model.engine()
+    f = integrands.Camel()
+    G, seed, s0 = 3, 99, 11
+    assert eng.rng_mode(G, N, True, f.nis_kind) == 2
+    out = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    wout = torch.zeros((G, N, 2), dtype=torch.float32, device=dev())
+    eng.integrate_steps_rng(G, N, dev(), f.nis_kind, f.nis_params, out, seed, s0, w_out=wout)
+    rows = philox_rows(seed, s0, G, N, 2, dev())
+    assert torch.equal(wout, rows)
+    fed = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    eng.integrate_steps(rows, True, f.nis_kind, f.nis_params, fed)
+    np.testing.assert_allclose(t2n(out), t2n(fed), rtol=1e-12)
+    params = {k: t2n(v) for k, v in model.state_dict().items()}
+    _, _, means, variances, _ = oflow.integrate(oflow.camel, params, oflow.plan_pwquad(2, n_cells, 4), list(t2n(rows)[:1]))
+    # (the oracle ran on the parameters AFTER the calls above: running statistics do not enter train-mode values)
+    np.testing.assert_allclose(t2n(out)[0, 1], means[0], rtol=1e-10)
+
+
+def _np_philox(ctr, key):
+    c = [np.asarray(x, dtype=np.uint64) for x in ctr]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & mask, p1 & mask, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & mask, p0 & mask]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return c
+
+
+@pytest.mark.parametrize("kind,c", [("pwlin", dict(d=8, P=4, n_cells=4, K=64, NN=[32, 32, 32], roll=4)),
+                                    ("pwquad", dict(d=10, n_cells=5, K=16, NN=[32, 32, 32])),
+                                    ("pwquad", dict(d=5, n_cells=5, K=6, NN=[7, 7])),
+                                    ("pwquad", dict(d=3, n_cells=3, K=4, NN=[3, 3, 3]))])
+@pytest.mark.parametrize("train", [True, False])
+def test_in_kernel_draws_any_model_match_mapping_and_fed_path(kind, c, train):
+    """nis_integrate_steps_rng for models outside the d = 2 direct-row class: the ingest launch GENERATES the float64 planes.  The
+    draws are Philox4x32-10 in the documented d != 2 mapping (NumPy restatement), and the records equal those of feeding the same
+    draws through nis_integrate_steps -- including the matrix-core first cell whose BN_0 records now carry the co-moments (BN_1
+    derived, no covariance pass, no layer-1 statistics launch)."""
+    from nf_amd import integrands
+    from nf_amd.flow import philox_rows
+    torch.manual_seed(31)
+    m = dict(c, kind=kind)
+    NF = build_manager(m)
+    model = NF.best_model
+    model.train(train)
+    eng = model.engine()
+    d = m["d"]
+    f = integrands.Normal(0.5, 0.2, d)
+    G, N, seed, s0 = 2, 6001, 0xABCDEF0123, 7
+    assert eng.rng_mode(G, N, train, f.nis_kind) == 1
+    rows = philox_rows(seed, s0, G, N, d, dev())
+    Q = (d + 3) // 4
+    for g in range(G):
+        ctr = (np.arange(N, dtype=np.uint64)[:, None] * np.uint64(Q) + np.arange(Q, dtype=np.uint64)[None, :]).reshape(-1)
+        sid = np.uint64(s0 + g)
+        r = _np_philox([ctr & np.uint64(0xFFFFFFFF), ctr >> np.uint64(32), np.full_like(ctr, sid & np.uint64(0xFFFFFFFF)),
+                        np.full_like(ctr, sid >> np.uint64(32))], [seed & 0xFFFFFFFF, seed >> 32])
+        want = ((np.stack(r, 1) >> np.uint64(8)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(N, 4 * Q)[:, :d]
+        np.testing.assert_array_equal(t2n(rows[g]), want)
+    out = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    wout = torch.zeros((G, N, d), dtype=torch.float32, device=dev())
+    eng.integrate_steps_rng(G, N, dev(), f.nis_kind, f.nis_params, out, seed, s0, w_out=wout, train=train)
+    assert torch.equal(wout, rows)
+    fed = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    eng.integrate_steps(rows, train, f.nis_kind, f.nis_params, fed)
+    np.testing.assert_allclose(t2n(out), t2n(fed), rtol=1e-9)
+    # kept planes: X, J of the rng path equal the fed path's
+    pl_a = torch.zeros((G, d + 1, N), dtype=torch.double, device=dev())
+    pl_b = torch.zeros_like(pl_a)
+    eng.integrate_steps_rng(G, N, dev(), f.nis_kind, f.nis_params, out, seed, s0, train=train, planes=pl_a, keep_planes=True)
+    eng.integrate_steps(rows, train, f.nis_kind, f.nis_params, fed, planes=pl_b)
+    np.testing.assert_allclose(t2n(pl_a), t2n(pl_b), rtol=1e-9, atol=1e-13)
+
+
+def test_a_captured_launch_set_survives_other_engine_calls():
+    """The IntegratePlan owns its workspace and state planes: engine calls with a LARGER set size, another batch size or another
+    BatchNorm mode (which re-allocate / re-pack the engine's own buffers with a different layout) must not disturb a later replay."""
+    from nf_amd import integrands
+    from nf_amd.normalizing_flows.manager import PWQuadManager
+    torch.manual_seed(5)
+    NF = PWQuadManager(n_flow=2)
+    NF.create_model(2, 4, [3] * 3)
+    model = NF.best_model
+    model.train()
+    eng = model.engine()
+    f = integrands.Camel()
+    G, N = 4, 100_003
+    plan = eng.plan(G, N, dev(), f.nis_kind, f.nis_params)
+    assert plan.captured
+    first = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    plan.reset(5, 0)
+    plan.run(first, replay=True)
+    # calls that used to move / re-layout what the graph pointed at
+    big = torch.zeros((3 * G + 1, 4), dtype=torch.double, device=dev())
+    eng.integrate_steps_rng(3 * G + 1, 2 * N + 7, dev(), f.nis_kind, f.nis_params, big, 1, 0)
+    eng.integrate_steps(torch.rand(2, 777, 2, device=dev()), False, f.nis_kind, f.nis_params, big[:2])
+    junk = [torch.full((1 << 22,), 7.0, device=dev()) for _ in range(8)]      # recycle whatever the allocator freed
+    assert eng.plan(G, N, dev(), f.nis_kind, f.nis_params) is plan
+    again = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    plan.reset(5, 0)
+    plan.run(again, replay=True)
+    np.testing.assert_array_equal(t2n(again), t2n(first))
+    eager = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    eng.integrate_steps_rng(G, N, dev(), f.nis_kind, f.nis_params, eager, 5, 0)
+    np.testing.assert_array_equal(t2n(eager), t2n(first))
+    del junk
+
+
+@pytest.mark.parametrize("cfg", ["massive8", "tau10", "cuts16"])
+def test_fused_rambo_tail_equals_weight_times_jacobian_moments(cfg):
+    """planes -> RAMBO weight * J -> moment records in ONE launch per set (nis_rambo_moments) against the separate weight kernel +
+    nis_moments per batch, on the kept planes of a real flow; and BasicManager.integrate() through that path against the
+    per-iteration path on identical draws."""
+    from nf_amd import integrands
+    from nf_amd.flow import moments as hip_moments, philox_rows
+    from nf_amd.normalizing_flows.manager import PWQuadManager
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    torch.manual_seed(17)
+    if cfg == "massive8":
+        d, gen, args = 8, FlatInvertiblePhasespace([100.] * 2, [100.] * 4, pdf=None, pdf_active=False), (1000., -1, -1, -1, [0, 0])
+    elif cfg == "tau10":
+        d, gen, args = 10, FlatInvertiblePhasespace([0., 0.], [100.] * 4, pdf=None, pdf_active=True), (13000., 0, 0, -1, [2, -1])
+    else:
+        d, gen, args = 16, FlatInvertiblePhasespace([0., 0.], [0.] * 6, pdf=None, pdf_active=True), (13000., 20, 0.4, 2.5, [21, 21])
+    NF = PWQuadManager(n_flow=d)
+    NF.create_model(2 * int(np.ceil(np.log2(d))), 8, [16, 16])
+    model = NF.best_model
+    model.train()
+    eng = model.engine()
+    f = integrands.RamboWeight(gen, args[0], args[1], args[2], args[3], args[4])
+    G, N = 3, 5003
+    scratch = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    planes = torch.zeros((G, d + 1, N), dtype=torch.double, device=dev())
+    eng.integrate_steps_rng(G, N, dev(), 2, [], scratch, 3, 0, planes=planes, keep_planes=True)
+    out = torch.zeros((G, 4), dtype=torch.double, device=dev())
+    status = torch.zeros(1, dtype=torch.int32, device=dev())
+    f.moments_from_planes(planes, eng.out_col, d, N, out, status)
+    assert not f.check_status(status)
+    for g in range(G):
+        want = hip_moments(f.from_planes(planes[g], eng.out_col, N), planes[g][d])
+        np.testing.assert_allclose(t2n(out[g]), t2n(want), rtol=1e-12)
+    # integrate(): in-kernel draws + fused tail vs the per-iteration path fed with the same draws
+    nitn = 4
+    torch.manual_seed(123)
+    sig, err = NF.integrate(f, nitn, N)
+    torch.manual_seed(123)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    rows = philox_rows(seed, 0, nitn, N, d, dev())
+    it = iter(range(nitn))
+    NF.sample_hook = lambda n, dd, dtype, stage: rows[next(it)].to(dtype)
+    NF.batch_iterations = 1
+    try:
+        sig2, err2 = NF.integrate(f, nitn, N)
+    finally:
+        NF.sample_hook = None
+    np.testing.assert_allclose(float(sig), float(sig2), rtol=2e-6)
+    np.testing.assert_allclose(float(err), float(err2), rtol=2e-6)
 
 
 # ------------------------------------------------------------------------------ device-side PDF interpolation (SURVEY 8(f) rank 4; parity unpinned)
