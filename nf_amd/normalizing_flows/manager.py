@@ -280,6 +280,8 @@ class BasicManager(ModelAPI):
                 preburner = False
 
         endpoint = i + 1
+        if self.data_parallel is not None:                  # leave the live model identical on every rank too
+            self.data_parallel.sync_buffers(self.model)
         with torch.no_grad():                                                       # :333-346
             if integrate and endpoint < epochs - 1:
                 model = self.best_model.eval()

@@ -28,7 +28,7 @@ dist.all_gather(gathered, flat)
 params_equal = all(torch.equal(g[:sum(p.numel() for p in NF._model.parameters())],
                                gathered[0][:sum(p.numel() for p in NF._model.parameters())]) for g in gathered)
 hist_equal = all(torch.equal(g[-len(NF.history) - 2:], gathered[0][-len(NF.history) - 2:]) for g in gathered)
-# everything, BatchNorm buffers included (running statistics averaged in the per-step all-reduce): model AND best_model
+# everything, BatchNorm buffers included (running statistics merged whenever a model copy is kept and at the end): model AND best_model
 all_equal = all(torch.equal(g, gathered[0]) for g in gathered)
 best = torch.cat([t.detach().double().reshape(-1) for t in NF.best_model.state_dict().values()])
 gb = [torch.zeros_like(best) for _ in range(ws)]
