@@ -264,6 +264,58 @@ def bench_config(name, rank, ws, dev, steps=3):
                          "note": "achieved = SURVEY 8(d) algorithmic flop/sample x per-GPU samples/s of the WHOLE step"}}
 
 
+TRAIN_CASES = {
+    # "integrate(...) and one train step with mbs = 1e6"; C5 topology at the minibatch the adjoint's workspace is sized for
+    "C2": ("C2", 1_000_000, 360.0),        # forward flop per sample (2 cells x 180)
+    "C5": ("C5", 200_000, 1.9e5),
+}
+
+
+def bench_train_step(name, rank, ws, dev, steps=5):
+    """One training minibatch (reference manager.py:219-280 with n_minibatches = 1): draw w, train-mode forward with history, integrand,
+    loss bookkeeping (nis_loss_terms), hand-written adjoint seeded by the loss, optimizer step.  `steps` timed after 2 warm-up steps."""
+    from nf_amd.normalizing_flows._autograd import flow_loss
+    cfg, mbs, fwd_flop = TRAIN_CASES[name]
+    torch.manual_seed(20 + rank)
+    if cfg == "C2":
+        NF = PWQuadManager(n_flow=2)
+        NF.create_model(2, 4, [3] * 3, dev=dev.index)
+        f, d = integrands.Camel(), 2
+    else:
+        kind, d, kw, _, _, _ = CONFIGS[cfg]
+        NF = PWQuadManager(n_flow=d)
+        NF.create_model(dev=dev.index, **kw)
+        f = integrands.Normal(0.5, 0.25, d)
+    model = NF._model
+    model.train()
+    optim = torch.optim.Adamax(model.parameters(), lr=2e-3, weight_decay=1e-4)       # README.md:42
+    maxf = torch.ones((), dtype=torch.double, device=dev)
+
+    def step():
+        optim.zero_grad()
+        w = torch.rand(mbs, d, dtype=torch.double, device=dev)
+        loss, t = flow_loss(model, w, f, maxf, False, False)
+        loss.backward()
+        optim.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    barrier_sync(ws)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    barrier_sync(ws)
+    dt = max_over_ranks(time.perf_counter() - t0, ws, dev)
+    rate = mbs * steps * ws / dt
+    tf = 3.0 * fwd_flop * rate / ws / 1e12          # forward + adjoint ~ 3x the forward's algorithmic flop (dX and dW products per layer)
+    return {"workload": f"{cfg} training minibatch: draw, forward with history, f(X)*J, loss + bookkeeping, adjoint, Adamax step", "mbs": mbs,
+            "value": rate, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "loss": float(loss),
+            "roofline": {"bound": "valu_f64" if cfg == "C2" else "mfma_f64", "achieved": round(tf, 3), "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(tf / MFMA_F64_PEAK_TF, 4), "flop_per_sample": 3.0 * fwd_flop,
+                         "note": "3 x SURVEY 8(d) forward flop/sample x samples/s of the whole step"}}
+
+
 def cpu_baseline():
     """The reference-equivalent CPU path on the GPU box's host cores: oracle/flow_torch.py -- the PyTorch-CPU fp64
     restatement of the C2 integrate loop, pinned to the reference's golden vectors -- on ALL cores (1 warm-up + median of 5
@@ -351,6 +403,7 @@ def main():
         flow = bench_flow(args, rank, ws, dev)
         rambo = bench_rambo(args, rank, ws, dev)
         configs = None if args.no_configs else {name: bench_config(name, rank, ws, dev) for name in CONFIGS}
+        train = None if args.no_configs else {name: bench_train_step(name, rank, ws, dev) for name in TRAIN_CASES}
     line = {
         "metric": "MC samples/sec at batch 1e6 (camel-2D; 2->4 RAMBO)",
         "value": flow["samples"] / flow["dt"],
@@ -378,6 +431,7 @@ def main():
         "roofline_issue": flow["roofline_issue"],
         "rambo": rambo,
         "configs": configs,
+        "train_step": train,
     }
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
         with contextlib.redirect_stdout(sys.stderr):

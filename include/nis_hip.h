@@ -220,6 +220,24 @@ int nis_integrand_moments(const double* planes, int64_t ld, int64_t N, int32_t d
 int nis_integrand_eval(int32_t f_kind, const double* f_params_host, const double* x, int64_t row_stride, int64_t N,
                        int32_t d, double* out, void* stream);
 
+/* The training loop's glue of one minibatch (manager.py:223-268) in two launches.  With fv_i the integrand on sample i -- given
+ * (fv_in, any callable evaluated by the caller) or evaluated here by a built-in f_kind on the rows xrows (X of the model output; w
+ * during the preburn, :237-239; the values are kept in fv_out) -- and J_i = jac[i * jstride]:
+ *   a_i = fv_i J_i (preburn: fv_i),  u_i = fv_i J_i / maxf,  u_i^2
+ * are reduced in one pass: rec12 = three {count, mean, M2, max} records (a | u | u^2) and
+ *   out8 = {mean(a), var(a) unbiased, loss, var(u^2) unbiased, n, mean(u), -, -},  loss = var(u) unbiased ("var", :254-255) or
+ *   mean((u maxf)^2) (est != 0, :257-258).  maxf_dev: device scalar.  workspace >= nis_loss_workspace_bytes().
+ * nis_flow_backward_loss: the adjoint seeded by that loss -- dL/dJ_i = gloss * d loss / d J_i from the records (no (N, d+1)
+ * cotangent tensor, no scatter pass), dL/dX = 0 (f sees the detached X, :244); gloss_dev: device scalar (1 / n_minibatches). */
+size_t nis_loss_workspace_bytes(void);
+int nis_loss_terms(const double* fv_in, const double* xrows, int64_t xstride, int32_t d, int32_t f_kind, const double* f_params_host,
+                   double* fv_out, const double* jac, int64_t jstride, int64_t N, const double* maxf_dev, int32_t preburn, int32_t est,
+                   double* rec12, double* out8, void* workspace, size_t workspace_bytes, void* stream);
+int nis_flow_backward_loss(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
+                           const double* const* params, const double* bnsave, const double* fvals, const double* maxf_dev,
+                           const double* rec12, const double* gloss_dev, int32_t est, double* const* gparams,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* Streaming moments of a vector (optionally of the product a[i]*b[i], b may be NULL). */
 size_t nis_moments_workspace_bytes(void);
 int nis_moments(const double* a, const double* b, int64_t N, double* out4,

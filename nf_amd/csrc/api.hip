@@ -933,10 +933,21 @@ extern "C" size_t nis_flow_backward_workspace_bytes(const nis_flow* f, int64_t N
   return ((size_t)(f->d + 1) * N + cellws + pk + 64) * sizeof(double);
 }
 
-extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
-                                 const double* const* params, const double* bnsave, const double* gxj, double* const* gparams,
-                                 double* gx_out, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!f || !planes_hist || !params || !bnsave || !gxj || !gparams || N < 1 || ld != N) return NIS_E_ARG;   // gradient planes share ld
+// where the output cotangent comes from: a (N, d+1) row-major dL/dXJ, or the minibatch loss of nis_loss_terms (dL/dJ only)
+struct BwdSeed {
+  const double* gxj = nullptr;
+  const double* fv = nullptr;          // loss seed: integrand values, device scalars maxf / gloss, nis_loss_terms' records
+  const double* maxf = nullptr;
+  const double* rec12 = nullptr;
+  const double* gloss = nullptr;
+  int est = 0;
+};
+
+static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
+                              const double* const* params, const double* bnsave, const BwdSeed& seed, double* const* gparams,
+                              double* gx_out, void* workspace, size_t workspace_bytes, void* stream) {
+  const double* gxj = seed.gxj;
+  if (!f || !planes_hist || !params || !bnsave || (!gxj && !seed.fv) || !gparams || N < 1 || ld != N) return NIS_E_ARG;   // gradient planes share ld
   if (!nis_flow_backward_supported(f)) return NIS_E_UNSUPPORTED;
   if (!workspace || workspace_bytes < nis_flow_backward_workspace_bytes(f, N)) return NIS_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
@@ -951,7 +962,10 @@ extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t
   double* pk = cellws + cw;
   const int tgrid = nis_grid_for(8, 1, N, NIS_TPB);
   // dL/dXJ (N, d+1) row-major in the model's OUTPUT column order -> gradient planes (output column c lives in plane out_col[c])
-  {
+  if (!gxj) {                         // seeded by the minibatch loss: dL/dJ from the records, zeros for the coordinates
+    HIP_OK(nis_launch_loss_cotangent(seed.fv, planes_hist + (size_t)f->n_cells * set + (size_t)d * ld, 1, (long)N, seed.maxf, seed.rec12,
+                                     seed.gloss, seed.est, d, g, (long)N, s));
+  } else {
     ColMap m;
     for (int j = 0; j < d; ++j) m.col[j] = f->out_col[j];
     m.col[d] = d;
@@ -1016,3 +1030,26 @@ extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t
   return NIS_OK;
 }
 
+
+extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
+                                 const double* const* params, const double* bnsave, const double* gxj, double* const* gparams,
+                                 double* gx_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!gxj) return NIS_E_ARG;
+  BwdSeed seed;
+  seed.gxj = gxj;
+  return flow_backward_impl(f, planes_hist, ld, N, w_has_jac, params, bnsave, seed, gparams, gx_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nis_flow_backward_loss(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
+                                      const double* const* params, const double* bnsave, const double* fvals, const double* maxf_dev,
+                                      const double* rec12, const double* gloss_dev, int32_t est, double* const* gparams, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  if (!fvals || !maxf_dev || !rec12 || !gloss_dev) return NIS_E_ARG;
+  BwdSeed seed;
+  seed.fv = fvals;
+  seed.maxf = maxf_dev;
+  seed.rec12 = rec12;
+  seed.gloss = gloss_dev;
+  seed.est = est;
+  return flow_backward_impl(f, planes_hist, ld, N, w_has_jac, params, bnsave, seed, gparams, nullptr, workspace, workspace_bytes, stream);
+}

@@ -123,3 +123,6 @@ struct EpiJob {
 hipError_t nis_launch_group_epilogue(const EpiJob& job, int blocks, hipStream_t s);
 // per-batch merge of the workgroup records (count, mean, M2, max): partials (G, maxb, 4) -> out4 (G, 4)
 hipError_t nis_launch_moments_final(const double* partials, int nparts, double* out4, int maxb, int G, hipStream_t s);
+// first launch of nis_flow_backward_loss: dL/dJ of the minibatch loss -> gradient planes (rec12 = nis_loss_terms' records)
+hipError_t nis_launch_loss_cotangent(const double* fv, const double* jac, long jstride, long N, const double* maxf, const double* rec12,
+                                     const double* gloss, int est, int d, double* g, long ld, hipStream_t s);

@@ -286,3 +286,201 @@ hipError_t nis_launch_moments_final(const double* partials, int nparts, double* 
   hipLaunchKernelGGL(k_moments_final, dim3(G), dim3(NIS_TPB), 0, s, partials, nparts, out4, maxb);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Training-loop glue of one minibatch (manager.py:223-268) as TWO launches instead of ~15 elementwise torch kernels and three
+// separate moment reductions: with fv_i = f(X_i) (or f(w_i) during the preburn, :237-239) and J_i the flow's Jacobian,
+//   a_i = fv_i J_i  (preburn: fv_i)        -> integ / err bookkeeping   (:241-249: mean and unbiased variance)
+//   u_i = fv_i J_i / maxf                  -> loss: var(u) ("var", :254-255) or mean((u maxf)^2) ("est", :257-258)
+//   u_i^2                                  -> variance of the mean (:268)
+// k_loss_terms reduces the three series in ONE pass (per-workgroup records, fixed-order merge in k_loss_final) and evaluates a
+// built-in integrand on the rows of X itself (fv_out keeps the values for the cotangent); k_loss_cotangent (api.hip: first launch
+// of nis_flow_backward_loss) turns the final records into dL/dJ_i, written straight to the adjoint's gradient planes.
+struct LossSrc {
+  const double* fv_in;      // given integrand values (arbitrary callable), or null:
+  const double* xrows;      //   rows the built-in integrand `ia` is evaluated on (X of the model output, or w during the preburn)
+  long xstride;
+  double* fv_out;           // receives the evaluated values (needed again by the cotangent)
+  const double* jac;        // J_i at jac[i * jstride]
+  long jstride;
+  const double* maxf;       // device scalar
+  int preburn;
+};
+__global__ __launch_bounds__(NIS_TPB) void k_loss_terms(LossSrc src, IntegrandArgs ia, long N, double* __restrict__ partials) {
+  __shared__ double wm[3][NIS_TPB / NIS_WAVE][4];
+  double S1[3] = {0, 0, 0}, S2[3] = {0, 0, 0}, sh[3] = {0, 0, 0}, mx[3] = {-__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
+  double cnt = 0.0;
+  bool first = true;
+  const double imax = 1.0 / src.maxf[0];
+  const long stride = (long)gridDim.x * NIS_TPB;
+  const long nit = (N + stride - 1) / stride;
+  for (long it = 0; it < nit; ++it) {
+    const long i = it * stride + (long)blockIdx.x * NIS_TPB + threadIdx.x;
+    const bool valid = i < N;
+    double v[3] = {0.0, 0.0, 0.0};
+    if (valid) {
+      double fv;
+      if (src.fv_in) {
+        fv = src.fv_in[i];
+      } else {
+        fv = eval_integrand_at(ia, src.xrows, 1, src.xstride, i);
+        src.fv_out[i] = fv;
+      }
+      const double fj = fv * src.jac[i * src.jstride];
+      v[0] = src.preburn ? fv : fj;
+      v[1] = fj * imax;
+      v[2] = v[1] * v[1];
+    }
+    if (first) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) sh[q] = wave_first(v[q]);
+      first = false;
+    }
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const double t = v[q] - sh[q];
+        S1[q] += t;
+        S2[q] = fma(t, t, S2[q]);
+        mx[q] = fmax(mx[q], v[q]);
+      }
+      cnt += 1.0;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double nw = wave_sum(cnt);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const double s1 = wave_sum(S1[q]), s2 = wave_sum(S2[q]), m = wave_max(mx[q]);
+    if (lane == 0) {
+      wm[q][wave][0] = nw;
+      wm[q][wave][1] = nw > 0.0 ? sh[q] + s1 / nw : 0.0;
+      wm[q][wave][2] = nw > 0.0 ? fmax(s2 - s1 * s1 / nw, 0.0) : 0.0;
+      wm[q][wave][3] = m;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int q = threadIdx.x;
+    Mom t = {0.0, 0.0, 0.0};
+    double m = -__builtin_huge_val();
+    for (int w = 0; w < NIS_TPB / NIS_WAVE; ++w) {
+      Mom r = {wm[q][w][0], wm[q][w][1], wm[q][w][2]};
+      t = mom_merge(t, r);
+      m = fmax(m, wm[q][w][3]);
+    }
+    double* part = partials + ((size_t)blockIdx.x * 3 + q) * 4;
+    part[0] = t.n;
+    part[1] = t.mean;
+    part[2] = t.m2;
+    part[3] = m;
+  }
+}
+
+// one workgroup: three fixed-order merges -> rec (3 x 4: a | u | u^2), then the scalars the host loop adds up:
+//   out[0] = mean(a), out[1] = var(a) (unbiased), out[2] = loss, out[3] = var(u^2) (unbiased), out[4] = n, out[5] = mean(u)
+__global__ __launch_bounds__(NIS_TPB) void k_loss_final(const double* __restrict__ partials, int nparts, const double* __restrict__ maxf, int est,
+                                                        double* __restrict__ rec, double* __restrict__ out) {
+  __shared__ double sm[NIS_TPB][4];
+  for (int q = 0; q < 3; ++q) {
+    Mom t = {0.0, 0.0, 0.0};
+    double m = -__builtin_huge_val();
+    for (int b = threadIdx.x; b < nparts; b += NIS_TPB) {
+      const double* p = partials + ((size_t)b * 3 + q) * 4;
+      Mom r = {p[0], p[1], p[2]};
+      t = mom_merge(t, r);
+      m = fmax(m, p[3]);
+    }
+    sm[threadIdx.x][0] = t.n;
+    sm[threadIdx.x][1] = t.mean;
+    sm[threadIdx.x][2] = t.m2;
+    sm[threadIdx.x][3] = m;
+    __syncthreads();
+    for (int s = NIS_TPB / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        Mom a = {sm[threadIdx.x][0], sm[threadIdx.x][1], sm[threadIdx.x][2]};
+        Mom b = {sm[threadIdx.x + s][0], sm[threadIdx.x + s][1], sm[threadIdx.x + s][2]};
+        a = mom_merge(a, b);
+        sm[threadIdx.x][0] = a.n;
+        sm[threadIdx.x][1] = a.mean;
+        sm[threadIdx.x][2] = a.m2;
+        sm[threadIdx.x][3] = fmax(sm[threadIdx.x][3], sm[threadIdx.x + s][3]);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rec[q * 4 + c] = sm[0][c];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double n = rec[0];
+    out[0] = rec[1];
+    out[1] = rec[2] / (n - 1.0);
+    out[2] = est ? (maxf[0] * maxf[0]) * rec[9] : rec[6] / (n - 1.0);      // mean((u maxf)^2)  |  unbiased var(u)
+    out[3] = rec[10] / (n - 1.0);
+    out[4] = n;
+    out[5] = rec[5];
+  }
+}
+
+extern "C" size_t nis_loss_workspace_bytes(void) { return (size_t)NIS_MAXB * 12 * sizeof(double); }
+
+extern "C" int nis_loss_terms(const double* fv_in, const double* xrows, int64_t xstride, int32_t d, int32_t f_kind, const double* f_params_host,
+                              double* fv_out, const double* jac, int64_t jstride, int64_t N, const double* maxf_dev, int32_t preburn,
+                              int32_t est, double* rec12, double* out8, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!jac || !maxf_dev || !rec12 || !out8 || N < 1 || jstride < 1) return NIS_E_ARG;
+  if (!fv_in && (!xrows || !fv_out || d < 1 || d > NIS_MAX_DIM || xstride < d)) return NIS_E_ARG;
+  if (!fv_in && f_kind != NIS_F_CAMEL && f_kind != NIS_F_NORMAL && f_kind != NIS_F_ONE) return NIS_E_ARG;
+  if (!fv_in && f_kind == NIS_F_CAMEL && d < 2) return NIS_E_ARG;
+  if (!workspace || workspace_bytes < nis_loss_workspace_bytes()) return NIS_E_WORKSPACE;
+  LossSrc src;
+  memset(&src, 0, sizeof(src));
+  src.fv_in = fv_in;
+  src.xrows = xrows;
+  src.xstride = (long)xstride;
+  src.fv_out = fv_out;
+  src.jac = jac;
+  src.jstride = (long)jstride;
+  src.maxf = maxf_dev;
+  src.preburn = preburn;
+  IntegrandArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int c = 0; c < d && c < NIS_MAX_DIM; ++c) a.out_col[c] = c;
+  a.d = d;
+  a.kind = f_kind;
+  for (int k = 0; k < 4; ++k) a.p[k] = f_params_host ? f_params_host[k] : 0.0;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = nis_stream_grid(N);
+  {
+    NisProfScope ps(NIS_K_MOMENTS, s);
+    hipLaunchKernelGGL(k_loss_terms, dim3(grid), dim3(NIS_TPB), 0, s, src, a, (long)N, (double*)workspace);
+  }
+  HIP_OK(hipGetLastError());
+  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(NIS_TPB), 0, s, (const double*)workspace, grid, maxf_dev, est, rec12, out8);
+  HIP_OK(hipGetLastError());
+  return NIS_OK;
+}
+
+// dL/dJ_i of the variance ("var") or second-moment ("est") loss of a minibatch, times the upstream cotangent gloss (device
+// scalar), into gradient plane d; the d coordinate planes get zeros (f is evaluated on the detached X, manager.py:244).
+__global__ __launch_bounds__(NIS_TPB) void k_loss_cotangent(const double* __restrict__ fv, const double* __restrict__ jac, long jstride, long N,
+                                                            const double* __restrict__ maxf, const double* __restrict__ rec,
+                                                            const double* __restrict__ gloss, int est, int d, double* __restrict__ g, long ld) {
+  const double imax = 1.0 / maxf[0], n = rec[4], mean_u = rec[5], gl = gloss[0];
+  const double cvar = 2.0 / (n - 1.0) * gl, cest = 2.0 / n * gl;
+  const long stride = (long)gridDim.x * NIS_TPB;
+  for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < N; i += stride) {
+    const double f = fv[i], J = jac[i * jstride];
+    const double gj = est ? cest * (f * J) * f : cvar * (f * J * imax - mean_u) * (f * imax);
+    for (int p = 0; p < d; ++p) g[(size_t)p * ld + i] = 0.0;
+    g[(size_t)d * ld + i] = gj;
+  }
+}
+
+hipError_t nis_launch_loss_cotangent(const double* fv, const double* jac, long jstride, long N, const double* maxf, const double* rec12,
+                                     const double* gloss, int est, int d, double* g, long ld, hipStream_t s) {
+  hipLaunchKernelGGL(k_loss_cotangent, dim3(nis_grid_for(8, 1, N, NIS_TPB)), dim3(NIS_TPB), 0, s, fv, jac, jstride, N, maxf, rec12, gloss, est, d, g, ld);
+  return hipGetLastError();
+}

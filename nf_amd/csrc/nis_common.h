@@ -81,10 +81,9 @@ __device__ __forceinline__ void nis_exp_init(double* lds_tab) {
 __device__ __forceinline__ double nis_exp(double x, const double* lds_tab) {
   const double kd = fma(x, 0x1.71547652b82fep+8, 0x1.8p+52);      // k = rint(256 x / ln 2) in the low word (see below)
   const double k = kd - 0x1.8p+52;
-  double r = fma(k, -0x1.62e42fef00000p-9, x);
-  r = fma(k, -0x1.473de6af278edp-42, r);
-  const int ki = __double2loint(kd);
-  const double T = lds_tab[ki & 255];
+  const double r = fma(k, -0x1.62e42fefa39efp-9, x);                // ONE fused step with the correctly rounded ln 2 / 256: the product is exact
+  const int ki = __double2loint(kd);                                 // inside the fma, so r is off by |x| 2^-53 at most (~1e-15 relative in exp for
+  const double T = lds_tab[ki & 255];                                // |x| < 10); the two-constant Cody-Waite form is for machines without fma
   double p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
   p = fma(r, p, 0.5);
   p = fma(r, p, 1.0);
@@ -99,8 +98,7 @@ __device__ __forceinline__ void nis_exp_init(double* lds_tab) {
 __device__ __forceinline__ double nis_exp(double x, const double* lds_tab) {
   const double kd = fma(x, 0x1.71547652b82fep+10, 0x1.8p+52);     // k = rint(1024 x / ln 2) in the low word (see below)
   const double k = kd - 0x1.8p+52;
-  double r = fma(k, -0x1.62e42fef00000p-11, x);
-  r = fma(k, -0x1.473de6af278edp-44, r);
+  const double r = fma(k, -0x1.62e42fefa39efp-11, x);               // one fused step (see the 256-entry form)
   const int ki = __double2loint(kd);
   const double T = lds_tab[ki & 1023];
   double p = fma(r, 1.0 / 6.0, NIS_EXP10_C2);
@@ -118,8 +116,7 @@ __device__ __forceinline__ double nis_exp(double x, const double* lds_tab) {
   // (|x| < 2.3e7); no clamp: |x| > 709 gives |k >> 6| > 1023 and v_ldexp_f64 returns 0 / inf like exp() would.
   const double kd = fma(x, 0x1.71547652b82fep+6, 0x1.8p+52);
   const double k = kd - 0x1.8p+52;
-  double r = fma(k, -0x1.62e42fef00000p-7, x);
-  r = fma(k, -0x1.473de6af278edp-40, r);
+  const double r = fma(k, -0x1.62e42fefa39efp-7, x);                // one fused step (see the 256-entry form)
   const int ki = __double2loint(kd);
   const double T = lds_tab[ki & 63];
   double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);

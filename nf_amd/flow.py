@@ -283,6 +283,55 @@ class FlowEngine:
         self._raise_on_status(ws[:4].view(torch.int32))
         return xj, (hist, bnsave, has_jac)
 
+    def _bwd_workspace(self, N, dev):
+        """Grow-only scratch of the adjoint (gradient planes, per-cell buffers), kept between calls: one minibatch's backward
+        has finished with it before the next one starts on the same stream."""
+        wsb = self.L.nis_flow_backward_workspace_bytes(self.handle, N)
+        ws = getattr(self, "_bws", None)
+        if ws is None or ws.device != dev or ws.numel() < wsb:
+            self._bws = ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        return ws, wsb
+
+    def loss_terms(self, xj, maxf, preburn, est, f=None, fvals=None, w=None):
+        """The minibatch's loss bookkeeping in two launches (`nis_loss_terms`, manager.py:223-268).  xj: (N, d+1) model output;
+        maxf: 0-d float64 device tensor; f: built-in integrand evaluated in the kernel on X (or on the latent rows `w` during the
+        preburn), or fvals: (N,) values of an arbitrary callable.  Returns (fvals, rec12, out8) device tensors."""
+        N, dev = xj.shape[0], xj.device
+        d = xj.shape[1] - 1
+        rec = torch.empty(12, dtype=torch.double, device=dev)
+        out = torch.empty(8, dtype=torch.double, device=dev)
+        ws = _moments_ws(dev, self.L.nis_loss_workspace_bytes())
+        if fvals is None:
+            rows = w if preburn else xj
+            fv = torch.empty(N, dtype=torch.double, device=dev)
+            fp = (C.c_double * 4)(*(list(f.nis_params) + [0.0] * 4)[:4])
+            args = (None, rows.data_ptr(), rows.stride(0), d, f.nis_kind, fp, fv.data_ptr())
+        else:
+            fv = fvals.detach().to(torch.double).contiguous()
+            args = (fv.data_ptr(), None, 0, d, -1, None, None)
+        with _lib.on_device(dev):
+            rc = self.L.nis_loss_terms(*args, xj.data_ptr() + 8 * d, d + 1, N, maxf.data_ptr(), 1 if preburn else 0, 1 if est else 0,
+                                       rec.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, "nis_loss_terms")
+        return fv, rec, out
+
+    def backward_loss(self, saved, fvals, maxf, rec, gloss, est):
+        """Adjoint seeded by the minibatch loss (`nis_flow_backward_loss`): [flat parameter-gradient blob per cell]."""
+        hist, bnsave, has_jac = saved
+        N, dev = hist.shape[2], hist.device
+        pp, _, _ = self._pointers(dev)
+        n = len(self.cells)
+        gflat = [torch.empty_like(c._flat) for c in self.cells]
+        gp = (C.c_void_p * n)(*[g.data_ptr() for g in gflat])
+        ws, wsb = self._bwd_workspace(N, dev)
+        gloss = gloss.detach().to(device=dev, dtype=torch.double).reshape(1)
+        with _lib.on_device(dev):
+            rc = self.L.nis_flow_backward_loss(self.handle, hist.data_ptr(), N, N, 1 if has_jac else 0, pp, bnsave.data_ptr(),
+                                               fvals.data_ptr(), maxf.data_ptr(), rec.data_ptr(), gloss.data_ptr(), 1 if est else 0, gp,
+                                               ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+        _lib.check(rc, "nis_flow_backward_loss")
+        return gflat
+
     def backward(self, saved, gxj, want_gx):
         """dL/dXJ (N, d+1) -> ([flat parameter-gradient blob per cell], dL/dx or None)."""
         hist, bnsave, has_jac = saved
@@ -291,8 +340,7 @@ class FlowEngine:
         n = len(self.cells)
         gflat = [torch.empty_like(c._flat) for c in self.cells]
         gp = (C.c_void_p * n)(*[g.data_ptr() for g in gflat])
-        wsb = self.L.nis_flow_backward_workspace_bytes(self.handle, N)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        ws, wsb = self._bwd_workspace(N, dev)
         gx = torch.empty((N, self.d + 1), dtype=torch.double, device=dev) if want_gx else None
         gxj = gxj.to(device=dev, dtype=torch.double).contiguous()
         with _lib.on_device(dev):
@@ -528,7 +576,7 @@ def moments_of(planes, d, out_col, f_kind, f_params, want_fres=False):
     dev = planes.device
     out4 = torch.empty(4, dtype=torch.double, device=dev)
     wsb = L.nis_moments_workspace_bytes()
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ws = _moments_ws(dev, wsb)
     fres = torch.empty(N, dtype=torch.double, device=dev) if want_fres else None
     oc = (C.c_int32 * d)(*out_col)
     fp = (C.c_double * 4)(*(list(f_params) + [0.0] * 4)[:4])
@@ -537,6 +585,19 @@ def moments_of(planes, d, out_col, f_kind, f_params, want_fres=False):
                                      out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
     _lib.check(rc, "nis_integrand_moments")
     return out4, fres
+
+
+_MOM_WS = {}
+
+
+def _moments_ws(dev, nbytes):
+    """Per-device scratch of the reduction kernels (per-workgroup records), kept between calls: the merge launch that reads it
+    is queued right behind the launch that writes it, on the same stream."""
+    key = (dev.type, dev.index or 0)
+    ws = _MOM_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _MOM_WS[key] = ws = torch.empty(max(nbytes, 1 << 18), dtype=torch.uint8, device=dev)
+    return ws
 
 
 def moments(a, b=None):
@@ -549,7 +610,7 @@ def moments(a, b=None):
         b = b.detach().to(torch.double).contiguous()
     out4 = torch.empty(4, dtype=torch.double, device=a.device)
     wsb = L.nis_moments_workspace_bytes()
-    ws = torch.empty(wsb, dtype=torch.uint8, device=a.device)
+    ws = _moments_ws(a.device, wsb)
     with _lib.on_device(a.device):
         rc = L.nis_moments(a.data_ptr(), b.data_ptr() if b is not None else None, a.numel(), out4.data_ptr(),
                            ws.data_ptr(), wsb, _lib.stream_ptr(a.device))

@@ -40,6 +40,52 @@ class _HipFlowFn(torch.autograd.Function):
         return (None, None, None, gx) + tuple(grads)
 
 
+class _HipLossFn(torch.autograd.Function):
+    """One training minibatch from the raw samples to the scalar loss, forward AND backward in libnis_hip.so
+    (/root/reference/nisrep/normalizing_flows/manager.py:220-268): nis_flow_forward_train -> integrand -> nis_loss_terms (one
+    reduction pass for the integ / err bookkeeping, the loss and the variance of the mean), and on backward
+    nis_flow_backward_loss, whose first launch forms dL/dJ from the records -- no (N, d+1) cotangent, no elementwise torch glue."""
+
+    @staticmethod
+    def forward(ctx, engine, w, f, maxf, preburn, est, *params):
+        xj, saved = engine.forward_train(w.detach(), False)
+        if hasattr(f, "nis_kind"):
+            fv, rec, out = engine.loss_terms(xj, maxf, preburn, est, f=f, w=w.detach())
+        else:
+            with torch.no_grad():
+                vals = f(w.detach()) if preburn else f(xj[:, :-1])
+            fv, rec, out = engine.loss_terms(xj, maxf, preburn, est, fvals=vals)
+        ctx.engine, ctx.saved, ctx.fv, ctx.rec, ctx.maxf, ctx.est = engine, saved, fv, rec, maxf, est
+        ctx.sizes = [[p.numel() for p in c.parameters()] for c in engine.cells]
+        ctx.shapes = [[p.shape for p in c.parameters()] for c in engine.cells]
+        ctx.mark_non_differentiable(out)
+        return out[2].clone(), out
+
+    @staticmethod
+    def backward(ctx, gloss, _gout):
+        gflat = ctx.engine.backward_loss(ctx.saved, ctx.fv, ctx.maxf, ctx.rec, gloss, ctx.est)
+        grads = []
+        for gf, sizes, shapes in zip(gflat, ctx.sizes, ctx.shapes):
+            off = 0
+            for n, sh in zip(sizes, shapes):
+                grads.append(gf[off:off + n].view(sh))
+                off += n
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+def flow_loss(model, w, f, maxf, preburn, est):
+    """(loss 0-d tensor with grad, out8 device tensor {mean(a), var(a), loss, var(u^2), n, mean(u)}) of one minibatch, or None
+    when the model is outside the class the fused path covers (then the caller runs the piecewise path)."""
+    engine = model.engine()
+    if not (model.training and engine.backward_supported() and w.is_cuda and w.dtype == torch.double and torch.is_grad_enabled()):
+        return None
+    from ..flow import ensure_flat
+    for c in engine.cells:
+        ensure_flat(c, w.device)
+    params = [p for c in engine.cells for p in c.parameters()]
+    return _HipLossFn.apply(engine, w, f, maxf, preburn, est, *params)
+
+
 class _ForwardOnlyFn(torch.autograd.Function):
     """HIP forward whose backward refuses: the reference lets a model be CALLED in eval mode (or with any cell shape) while
     autograd records; only asking for the gradient of a case the adjoint kernels do not cover is an error here."""

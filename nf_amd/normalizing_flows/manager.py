@@ -27,6 +27,7 @@ from ..flow import moments as hip_moments, moments_of
 from .layers.coupling_cells import AffineCoupling, PWLin, PWQuad
 from .layers.layers import AddJacobian, DeMaskLayer, MaskLayer, RollLayer
 from .sequential import FlowSequential
+from ._autograd import flow_loss
 
 
 def get_bin(x, n=0):
@@ -218,6 +219,17 @@ class BasicManager(ModelAPI):
             optimizer_object.zero_grad()
             for _ in range(n_minibatches):                                          # :219-270
                 w = self._uniform(mini_batch_size, dev, torch.double, "train")
+                fused = None
+                if self.fused_minibatch and loss_mode in ("var", "est") and torch.is_tensor(maxf) and self._stock_input() and \
+                        isinstance(self.model, FlowSequential):
+                    fused = flow_loss(self.model, w.to(dev), f, maxf, preburner, loss_mode == "est")
+                if fused is not None:               # forward, integrand, loss bookkeeping and (later) the adjoint: all in libnis_hip
+                    loss_mb, t = fused              # t = {mean(a), var(a), loss, var(u^2), n, mean(u)}
+                    integ[i + 1] += t[0] / n_minibatches
+                    err[i + 1] += t[1] / n_minibatches
+                    loss = loss + loss_mb
+                    var = var + t[3] / mini_batch_size                              # variance of the mean (:268)
+                    continue
                 XJ = self._forward(w, dev)
                 J = XJ[:, -1]
                 if preburner:                                                       # f on the latent point (:237-242)
@@ -394,6 +406,8 @@ class BasicManager(ModelAPI):
         return p.device if p.is_cuda else torch.device("cuda:0")
 
     batch_iterations = 20      # integrate(): iterations fused into one launch set (independent BN batches)
+    fused_minibatch = True     # training: forward -> integrand -> loss bookkeeping -> adjoint as library calls only (False: the piecewise
+                               # path through torch's autograd graph, kept for A/B tests and for models outside the adjoint kernels' class)
 
     def moments_batches(self, f, nitn, neval, dev):
         """(count, mean, M2, max) of f(X)*J for nitn fresh batches; stays on the device."""
