@@ -72,6 +72,7 @@ def build(force=False, verbose=False, diag=False):
                 if err.strip():
                     print(err, file=sys.stderr)
         _link(LIB, [o for o, _ in results])
+    diag = diag or os.path.exists(LIB_DIAG)          # once built, the diagnostics library is kept in step with the product library
     if diag and (force or _stale(LIB_DIAG, deps + [LIB])):
         with ThreadPoolExecutor(max_workers=3) as ex:
             dres = list(ex.map(_compile, DIAG_UNITS))

@@ -240,6 +240,8 @@ static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid, int
   // workgroup's prologue merges the previous layer's records, one per workgroup
   static const int bpc_s = nis_env_int("NIS_MFMA_STATS_BPC", 0);
   *grid_stats = *ok ? (bpc_s > 0 ? std::max(*grid, nis_grid_for(bpc_s, G, N, per_wg)) : *grid) : 1;
+  // register-resident apply kernel (three workgroups per CU): the statistics kernels keep THEIR residency (two per CU)
+  if (*ok && c.regmode && bpc_s <= 0) *grid_stats = nis_grid_for(2, G, N, per_wg);
 }
 
 // Descriptor-level mirror of launch_apply's SPEC conditions (flow_wm.hip): every cell of a d = 2 PWQuad chain with 3-wide
@@ -349,7 +351,8 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
                              body + L.off_bias, body + L.off_gb, body + L.off_hb, cell_hidden_bias(cd) ? 1 : 0, pgrid, s));
       if (L.WM >= 16 && use_mfma()) {
         HIP_OK(nis_launch_pack_mfma(L.WM, c.L, c.R, L.RT, body + L.off_wp, body + L.off_wlast, body + L.off_bias, body + L.off_wm,
-                                    body + L.off_wmlast, body + L.off_biaspad, cd.kind == NIS_AFFINE ? d - cd.P : 0, pgrid, s));
+                                    body + L.off_wmlast, body + L.off_biaspad, cd.kind == NIS_AFFINE ? d - cd.P : 0,
+                                    nis_mf_regmode(cd.kind, cd.K, d - cd.P, L.WM), d - cd.P, cd.K, pgrid, s));
       }
     }
   }
@@ -508,6 +511,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
         default: cell_grids<64>(cd.kind, L.KM, 0, false, Gg, N, &grid_stats, &grid_apply); break;
       }
       CellK c = cell_shape(ci);
+      c.regmode = nis_mf_regmode(cd.kind, cd.K, d - cd.P, L.WM);
       c.first = (ci == 0 && !o.w_has_jac) ? 1 : 0;
       c.G = G;
       c.Gy = Gy;
@@ -819,7 +823,10 @@ extern "C" int nis_flow_fusable(const nis_flow* f) {
   memset(&c, 0, sizeof(c));
   c.kind = cd.kind;
   c.K = cd.K;
+  c.T = f->d - cd.P;
+  c.R = cell_R(cd);
   c.out = cell_out(cd);
+  c.regmode = nis_mf_regmode(cd.kind, cd.K, c.T, L.WM);
   bool ok = false;
   switch (L.WM) {
     case 16: ok = mfma_supported<16>(c); break;
@@ -1013,7 +1020,7 @@ static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld
       double* wm_last = wm_all + nl * WM * WM;
       double* bias_pad = wm_last + RT * 16 * WM;
       HIP_OK(nis_launch_pack_mfma((int)WM, c.L, c.R, (int)RT, wp, wlast, bias, wm_all, wm_last, bias_pad, cd.kind == NIS_AFFINE ? d - cd.P : 0,
-                                  32, s));
+                                  0, 0, 0, 32, s));
       mw.wm_all = wm_all;
       mw.wm_last = wm_last;
       mw.bias_pad = bias_pad;

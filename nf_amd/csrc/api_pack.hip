@@ -1,5 +1,6 @@
 // Model handle, workspace layout and parameter packing of libnis_hip.so (see api_internal.h for the split).
 #include "api_internal.h"
+#include "flow_mfma_reg.h"
 #ifdef NIS_DIAG
 #include "flow_mega.h"
 #endif
@@ -182,10 +183,12 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double*
 // W[16 jt + (l & 15)][4 q + (l >> 4)]  (the A operand of v_mfma_f64_16x16x4_f64).
 // affT > 0 (NIS_AFFINE with T transformed columns): the last layer's rows [scale | shift][T] are interleaved to
 // [t][scale, shift], so that a column's outputs are contiguous like those of the piecewise cells.
+// regmode != 0 (flow_mfma_reg.h): the last layer's rows are permuted so that a lane's four accumulator registers hold four
+// consecutive bins of one column (mf_reg_row); T, K: transformed columns and bins of the cell.
 __global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int RT, const double* __restrict__ wp,
                                                        const double* __restrict__ wlast, const double* __restrict__ bias,
                                                        double* __restrict__ wm_all, double* __restrict__ wm_last,
-                                                       double* __restrict__ bias_pad, int affT) {
+                                                       double* __restrict__ bias_pad, int affT, int regmode, int T, int K) {
   const size_t tid = (size_t)blockIdx.x * NIS_TPB + threadIdx.x, nth = (size_t)gridDim.x * NIS_TPB;
   const int JT = WM / 16, KQ = WM / 4;
   const size_t nh = (size_t)L * WM * WM;
@@ -202,12 +205,21 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int
     const size_t frag = e >> 6;
     const int q = (int)(frag % KQ), jt = (int)(frag / KQ);
     const int j = 16 * jt + (lane & 15), k = 4 * q + (lane >> 4);
-    const int jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;          // packed row j <- blob row jo
-    wm_last[e] = j < R ? wlast[(size_t)jo * WM + k] : 0.0;
+    int jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;                // packed row j <- blob row jo
+    if (regmode) jo = mf_reg_row(regmode, T, K, jt, lane & 15);
+    double v = (regmode ? jo >= 0 && jo < R : j < R) ? wlast[(size_t)jo * WM + k] : 0.0;
+    const int js = regmode ? mf_reg_row_sub(regmode, T, K, jt, lane & 15) : -1;
+    if (js >= 0) v -= wlast[(size_t)js * WM + k];
+    wm_last[e] = v;
   }
   for (size_t e = tid; e < (size_t)RT * 16; e += nth) {
-    const int j = (int)e, jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;
-    bias_pad[e] = e < (size_t)R ? bias[jo] : 0.0;
+    const int j = (int)e;
+    int jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;
+    if (regmode) jo = mf_reg_row(regmode, T, K, j >> 4, j & 15);
+    double v = (regmode ? jo >= 0 && jo < R : e < (size_t)R) ? bias[jo] : 0.0;
+    const int js = regmode ? mf_reg_row_sub(regmode, T, K, j >> 4, j & 15) : -1;
+    if (js >= 0) v -= bias[js];
+    bias_pad[e] = v;
   }
 }
 
@@ -218,7 +230,8 @@ hipError_t nis_launch_pack(const CellK& c, int WM, const double* prm, const doub
 }
 
 hipError_t nis_launch_pack_mfma(int WM, int L, int R, int RT, const double* wp, const double* wlast, const double* bias, double* wm_all,
-                                double* wm_last, double* bias_pad, int affT, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_pack_mfma, dim3(std::max(1, grid)), dim3(NIS_TPB), 0, s, WM, L, R, RT, wp, wlast, bias, wm_all, wm_last, bias_pad, affT);
+                                double* wm_last, double* bias_pad, int affT, int regmode, int T, int K, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_mfma, dim3(std::max(1, grid)), dim3(NIS_TPB), 0, s, WM, L, R, RT, wp, wlast, bias, wm_all, wm_last, bias_pad, affT,
+                     regmode, T, K);
   return hipGetLastError();
 }

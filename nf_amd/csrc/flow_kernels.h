@@ -11,6 +11,7 @@
 // Reference restated: normalizing_flows/layers/coupling_cells.py:107-142 (PWLin.forward),
 // :159-228 (PWQuad.forward), :236-254 (RectNN), torch.nn.BatchNorm1d semantics.
 #pragma once
+#include <cstdlib>
 #include "nis_common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -1261,6 +1262,16 @@ hipError_t launch_apply_mfma(const CellK& c, const MfmaW& w, double* planes, lon
                              int grid, hipStream_t s);
 // true when launch_apply_mfma has a fused-integrand instantiation for this cell (PWLin, AffineCoupling, PWQuad with K == KM)
 static inline bool nis_mfma_fusable(int kind, int km) { return kind != NIS_PWQUAD || km < 0; }
+// Row order of the last Linear's matrix-core image (flow_mfma_reg.h): 1 = PWQuad with 16 bins, 2 = PWLin with 16 m bins -- the
+// cells whose bijector runs on the accumulator registers of four cooperating lanes; 0 = reference order (per-wave LDS image).
+// One function decides for the packer (api.hip) and the launcher (flow_wm.hip).  NIS_NO_REGBIJ=1: always 0 (A/B).
+static inline int nis_mf_regmode(int kind, int K, int T, int wm) {
+  static const bool off = getenv("NIS_NO_REGBIJ") != nullptr && atoi(getenv("NIS_NO_REGBIJ")) != 0;
+  if (off || wm < 16) return 0;
+  if (kind == NIS_PWQUAD && K == 16 && T >= 1 && T <= 16) return 1;
+  if (kind == NIS_PWLIN && K >= 16 && K % 16 == 0) return 2;
+  return 0;
+}
 #define NIS_DECL_WM(W)                                                                                                      \
   template <>                                                                                                               \
   int stats_blocks_per_cu<W>(int wx, bool folded);                                                                                          \

@@ -46,19 +46,19 @@ __host__ __device__ inline int mf_cb_tiles(int T, int out, int R, int ncb_cols) 
 #ifndef NIS_MF_WAVES
 #define NIS_MF_WAVES 2                 // waves per SIMD the apply kernel is allocated for (K <= 16)
 #endif
-template <int WM>
+template <int WM, int STV = NIS_MF_ST>
 struct MfCfg {
-  static constexpr int ST = NIS_MF_ST;             // sample tiles (of 16) per wave: keeps VGPR+AGPR <= 256 -> 2 waves/SIMD,
+  static constexpr int ST = STV;                   // sample tiles (of 16) per wave: keeps VGPR+AGPR <= 256 -> 2 waves/SIMD,
                                                    // so one wave's MFMA phase overlaps the other's VALU (exp / bijector) phase
   static constexpr int JT = WM / 16;               // output row tiles of a hidden layer
   static constexpr int KQ = WM / 4;                // k-steps of a hidden layer
 };
 
 // Load the pass-through block as B operands and apply BN_0:  H[q][st] = sc0[k]*x[k][s] + sh0[k],  k = 4q + (lane>>4).
-template <int WM>
+template <int WM, int STV = NIS_MF_ST>
 __device__ __forceinline__ void mf_load_input(const CellK& c, const double* planes, long ld, long N, long base, const int* lds_plane,
-                                              const double* lds_coef, double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST]) {
-  constexpr int ST = MfCfg<WM>::ST, KQ = MfCfg<WM>::KQ;
+                                              const double* lds_coef, double (&H)[MfCfg<WM>::KQ][STV]) {
+  constexpr int ST = STV, KQ = MfCfg<WM>::KQ;
   const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
   const int nq = (c.P + 3) / 4;                      // k-steps that hold pass-through columns (wave-uniform: no exec-masked loads)
   const bool whole = base + 16 * ST <= N;            // wave-uniform: every sample of the wave's tiles exists
@@ -84,10 +84,10 @@ __device__ __forceinline__ void mf_load_input(const CellK& c, const double* plan
 
 // The same in two halves for a software-pipelined caller (P <= 4 PQ): `mf_issue_input` only requests the raw pass-through values of
 // the tiles at `base` (a ragged tile re-reads an existing sample), `mf_finish_input` turns them into B operands one iteration later.
-template <int WM, int PQ>
+template <int WM, int PQ, int STV = NIS_MF_ST>
 __device__ __forceinline__ void mf_issue_input(const CellK& c, const double* planes, long ld, long N, long base, const int* lds_plane,
-                                               double (&xr)[PQ][MfCfg<WM>::ST]) {
-  constexpr int ST = MfCfg<WM>::ST;
+                                               double (&xr)[PQ][STV]) {
+  constexpr int ST = STV;
   const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
   const bool whole = base + 16 * ST <= N;
 #pragma unroll
@@ -101,10 +101,10 @@ __device__ __forceinline__ void mf_issue_input(const CellK& c, const double* pla
     }
   }
 }
-template <int WM, int PQ>
-__device__ __forceinline__ void mf_finish_input(const CellK& c, long N, long base, const double* lds_coef, const double (&xr)[PQ][MfCfg<WM>::ST],
-                                                double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST]) {
-  constexpr int ST = MfCfg<WM>::ST, KQ = MfCfg<WM>::KQ;
+template <int WM, int PQ, int STV = NIS_MF_ST>
+__device__ __forceinline__ void mf_finish_input(const CellK& c, long N, long base, const double* lds_coef, const double (&xr)[PQ][STV],
+                                                double (&H)[MfCfg<WM>::KQ][STV]) {
+  constexpr int ST = STV, KQ = MfCfg<WM>::KQ;
   const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
   const bool whole = base + 16 * ST <= N;
 #pragma unroll
@@ -122,10 +122,10 @@ __device__ __forceinline__ void mf_finish_input(const CellK& c, long N, long bas
 }
 
 // One hidden Linear on the matrix cores: acc[jt][st] = sum_q Wm[jt][q] (x) H[q][st];  nq = k-steps actually populated.
-template <int WM>
-__device__ __forceinline__ void mf_dense(const double* __restrict__ wm, int nq, const double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST],
-                                         nis_d4 (&acc)[MfCfg<WM>::JT][MfCfg<WM>::ST]) {
-  constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ;
+template <int WM, int STV = NIS_MF_ST>
+__device__ __forceinline__ void mf_dense(const double* __restrict__ wm, int nq, const double (&H)[MfCfg<WM>::KQ][STV],
+                                         nis_d4 (&acc)[MfCfg<WM>::JT][STV]) {
+  constexpr int ST = STV, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ;
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int jt = 0; jt < JT; ++jt) {
@@ -143,10 +143,10 @@ __device__ __forceinline__ void mf_dense(const double* __restrict__ wm, int nq, 
 }
 
 // BN_l + ReLU on the accumulators -> B operands of the next layer (feature j = 16 jt + (lane>>4) + 4 r  ->  k-step 4 jt + r).
-template <int WM>
-__device__ __forceinline__ void mf_bn_relu(const double* lds_coef_l, const nis_d4 (&acc)[MfCfg<WM>::JT][MfCfg<WM>::ST],
-                                           double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST]) {
-  constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT;
+template <int WM, int STV = NIS_MF_ST>
+__device__ __forceinline__ void mf_bn_relu(const double* lds_coef_l, const nis_d4 (&acc)[MfCfg<WM>::JT][STV],
+                                           double (&H)[MfCfg<WM>::KQ][STV]) {
+  constexpr int ST = STV, JT = MfCfg<WM>::JT;
   const int g = (threadIdx.x & 63) >> 4;
 #pragma unroll
   for (int jt = 0; jt < JT; ++jt)
@@ -160,13 +160,13 @@ __device__ __forceinline__ void mf_bn_relu(const double* lds_coef_l, const nis_d
 }
 
 // Hidden stack up to (excluding) BN layer `upto` (1..L): leaves the pre-BN accumulators of that layer in acc.
-template <int WM>
+template <int WM, int STV = NIS_MF_ST>
 __device__ __forceinline__ void mf_hidden(const CellK& c, const double* wm_all, const double* lds_coef, int upto,
-                                          double (&H)[MfCfg<WM>::KQ][MfCfg<WM>::ST], nis_d4 (&acc)[MfCfg<WM>::JT][MfCfg<WM>::ST]) {
+                                          double (&H)[MfCfg<WM>::KQ][STV], nis_d4 (&acc)[MfCfg<WM>::JT][STV]) {
   for (int l = 0; l < upto; ++l) {
     const int nq = l == 0 ? (c.P + 3) / 4 : MfCfg<WM>::KQ;
-    mf_dense<WM>(wm_all + (size_t)l * WM * WM, nq, H, acc);
-    if (l + 1 < upto) mf_bn_relu<WM>(lds_coef + (size_t)(l + 1) * 2 * WM, acc, H);
+    mf_dense<WM, STV>(wm_all + (size_t)l * WM * WM, nq, H, acc);
+    if (l + 1 < upto) mf_bn_relu<WM, STV>(lds_coef + (size_t)(l + 1) * 2 * WM, acc, H);
   }
 }
 

@@ -183,6 +183,7 @@ struct FuseF {
 struct CellK {
   int kind, d, P, T, K, L, out, R;       // out = conditioner outputs per transformed column, R = T*out
   int mf_ncb;                            // matrix-core apply kernel: transformed columns per bijector batch (4, 2 or 1; set at launch)
+  int regmode;                           // != 0: the last Linear is packed for the register-resident bijector (flow_mfma_reg.h: MF_REG_*)
   int width[NIS_MAX_HIDDEN];
   int in_plane[NIS_MAX_DIM];             // local column j -> state plane
   int jplane;                            // plane of the running Jacobian

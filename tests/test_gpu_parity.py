@@ -710,6 +710,26 @@ def test_data_parallel_training_two_ranks_one_gpu():
     assert r.returncode == 0 and "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_sharded_integrate_ranks_on_one_gpu_run_the_rccl_code_path(ranks):
+    """The sample-sharded integrate() job with 2 and 3 ranks on this GPU (gloo serving the collective): every rank captures its launch
+    set into a hipGraph inside the multi-rank job (no eager fallback), `allreduce_moments` takes the CUDA branch an RCCL job takes
+    (ONE gather + ONE nis_merge_moments launch) and agrees with a NumPy Chan merge, and integrate_sharded is identical on all ranks."""
+    import socket
+    import subprocess
+    import sys
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NIS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "rank2_integrate_check.py")],
+                       env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0 and "R2_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 # ------------------------------------------------------------------------------ AffineCoupling / AffineManager (8(f) rank 3)
 @pytest.mark.parametrize("case", [c for c in golden("affine.npz").cases() if "model" not in c])
 def test_affine_cell_vs_reference_golden(case, g_affine):
