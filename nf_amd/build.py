@@ -4,8 +4,9 @@ The per-conditioner-width translation units (forward: 5, wide adjoint: 3) compil
 the shared library to nf_amd/lib/libnis_hip.so (git-ignored, travels to the GPU box with the snapshot).
 
 `--diag` additionally builds nf_amd/lib/libnis_hip_diag.so: the same library with -DNIS_DIAG, i.e. plus the measured dead ends kept for
-A/B measurements only -- the persistent LDS-resident C2 kernel (flow_mega.hip, NIS_MEGA=1) and the multi-chain launch sets
-(NIS_STREAMS=n).  Select it with NIS_LIB=<path>; the product library contains neither.
+A/B measurements only -- the persistent LDS-resident C2 kernel (flow_mega.hip, NIS_MEGA=1), the multi-chain launch sets
+(NIS_STREAMS=n) and the register-resident bijector of the matrix-core apply kernel (flow_mfma_reg.h, NIS_REGBIJ=1).  Select it
+with NIS_LIB=<path>; the product library contains none of them.
 """
 import os
 import subprocess
@@ -24,7 +25,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
 
 LIB_DIAG = os.path.join(LIBDIR, "libnis_hip_diag.so")
 API_UNITS = [("api", "api.hip", []), ("api_pack", "api_pack.hip", []), ("api_ingest", "api_ingest.hip", []), ("api_moments", "api_moments.hip", [])]
-DIAG_UNITS = [("diag_api", "api.hip", ["-DNIS_DIAG"]), ("diag_api_pack", "api_pack.hip", ["-DNIS_DIAG"]), ("diag_flow_mega", "flow_mega.hip", ["-DNIS_DIAG"])]
+DIAG_UNITS = [("diag_api", "api.hip", ["-DNIS_DIAG"]), ("diag_api_pack", "api_pack.hip", ["-DNIS_DIAG"]), ("diag_flow_mega", "flow_mega.hip", ["-DNIS_DIAG"])] + \
+             [(f"diag_flow_wm{w}", "flow_wm.hip", [f"-DNIS_WM={w}", "-DNIS_DIAG"]) for w in (16, 32, 64)]
 UNITS = API_UNITS + [("rambo", "rambo.hip", []), ("flow_bwd", "flow_bwd.hip", [])] + \
         [(f"flow_wm{w}", "flow_wm.hip", [f"-DNIS_WM={w}"]) for w in (4, 8, 16, 32, 64)] + \
         [(f"flow_bwd_wm{w}", "flow_bwd_wm.hip", [f"-DNIS_WM={w}"]) for w in (16, 32, 64)]
@@ -74,9 +76,9 @@ def build(force=False, verbose=False, diag=False):
         _link(LIB, [o for o, _ in results])
     diag = diag or os.path.exists(LIB_DIAG)          # once built, the diagnostics library is kept in step with the product library
     if diag and (force or _stale(LIB_DIAG, deps + [LIB])):
-        with ThreadPoolExecutor(max_workers=3) as ex:
+        with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
             dres = list(ex.map(_compile, DIAG_UNITS))
-        swapped = {"api.o", "api_pack.o"}
+        swapped = {"api.o", "api_pack.o", "flow_wm16.o", "flow_wm32.o", "flow_wm64.o"}
         objs = [os.path.join(OBJ, n + ".o") for n, _, _ in UNITS if n + ".o" not in swapped] + [o for o, _ in dres]
         _link(LIB_DIAG, objs)
     return LIB

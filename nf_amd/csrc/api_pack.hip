@@ -1,7 +1,7 @@
 // Model handle, workspace layout and parameter packing of libnis_hip.so (see api_internal.h for the split).
 #include "api_internal.h"
-#include "flow_mfma_reg.h"
 #ifdef NIS_DIAG
+#include "flow_mfma_reg.h"
 #include "flow_mega.h"
 #endif
 
@@ -183,8 +183,12 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double*
 // W[16 jt + (l & 15)][4 q + (l >> 4)]  (the A operand of v_mfma_f64_16x16x4_f64).
 // affT > 0 (NIS_AFFINE with T transformed columns): the last layer's rows [scale | shift][T] are interleaved to
 // [t][scale, shift], so that a column's outputs are contiguous like those of the piecewise cells.
-// regmode != 0 (flow_mfma_reg.h): the last layer's rows are permuted so that a lane's four accumulator registers hold four
-// consecutive bins of one column (mf_reg_row); T, K: transformed columns and bins of the cell.
+// regmode != 0 (diagnostics build, flow_mfma_reg.h): the last layer's rows are permuted so that a lane's four accumulator registers
+// hold four consecutive bins of one column (mf_reg_row); T, K: transformed columns and bins of the cell.
+#ifndef NIS_DIAG
+__host__ __device__ inline int mf_reg_row(int, int, int, int tile, int rho) { return 16 * tile + rho; }
+__host__ __device__ inline int mf_reg_row_sub(int, int, int, int, int) { return -1; }
+#endif
 __global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int RT, const double* __restrict__ wp,
                                                        const double* __restrict__ wlast, const double* __restrict__ bias,
                                                        double* __restrict__ wm_all, double* __restrict__ wm_last,

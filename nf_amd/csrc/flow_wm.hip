@@ -268,7 +268,11 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
 // ---------------------------------------------------------------------------------------------------------------
 // matrix-core (MFMA f64) variants for wide conditioners
 #if NIS_WM >= 16
-#include "flow_mfma_reg.h"
+#ifdef NIS_DIAG
+#include "flow_mfma_reg.h"          // register-resident bijector: diagnostics build only (measured slower)
+#else
+#include "flow_mfma.h"
+#endif
 
 // per wave: the whole row tiles of one column batch (flow_mfma.h, mf_cb_tiles); at least the prologue's reduction scratch
 static size_t mf_ring_bytes_n(const CellK& c, int ncb) {
@@ -292,16 +296,20 @@ static size_t mf_ring_bytes(const CellK& c) { return mf_ring_bytes_n(c, mf_pick_
 
 template <>
 bool mfma_supported<NIS_WM>(const CellK& c) {
+#ifdef NIS_DIAG
   if (c.regmode) return true;                      // register-resident bijector: no LDS image
+#endif
   return mf_ring_bytes(c) + 24 * 1024 <= 160 * 1024 && (c.kind == NIS_PWLIN || c.K <= 32);
 }
 
 template <>
 int mfma_blocks_per_cu<NIS_WM>(const CellK& c) {
+#ifdef NIS_DIAG
   if (c.regmode) {                                 // registers decide: one 256-thread workgroup = one wave per SIMD
     static const int bpc = getenv("NIS_MFR_BPC") ? atoi(getenv("NIS_MFR_BPC")) : NIS_MFR_WAVES;
     return bpc;
   }
+#endif
   const size_t lds = mf_ring_bytes(c) + MF_STATIC_LDS;
   int n = (int)(160 * 1024 / lds);
   const int waves = (c.kind == NIS_PWLIN && NIS_MF_WAVES_LIN) ? NIS_MF_WAVES_LIN : NIS_MF_WAVES;
@@ -326,6 +334,7 @@ template <>
 hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* planes, long ld, long N, int bn_train, int km, int* bins,
                                      const FuseF& fz, int grid, hipStream_t s) {
   CellK c = c_in;
+#ifdef NIS_DIAG
   if (c.regmode) {                       // PWQuad K = 16 / PWLin K = 16 m: bijector on the accumulator registers (flow_mfma_reg.h)
     const bool fuse = fz.kind >= 0;
     if (fuse && (bins || fz.fres)) return hipErrorInvalidValue;
@@ -342,6 +351,7 @@ hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* 
 #undef NIS_APPLY_MFR
     return hipGetLastError();
   }
+#endif
   c.mf_ncb = mf_pick_ncb(c_in);
   if (fz.kind >= 0) {                      // last cell of an integrate step: integrand * J + moment records fused (FUSE instantiations)
     if (!nis_mfma_fusable(c.kind, km) || bins || fz.fres) return hipErrorInvalidValue;

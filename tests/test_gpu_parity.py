@@ -1418,11 +1418,12 @@ def test_graph_replay_of_a_launch_set_equals_eager_launches():
     np.testing.assert_allclose(fed, ref, rtol=1e-12)
 
 
-@pytest.mark.parametrize("variant", ["chains2", "chains3", "resident"])
+@pytest.mark.parametrize("variant", ["chains2", "chains3", "resident", "regbij"])
 def test_diagnostics_build_variants_agree_with_the_plain_path(variant):
-    """Several chains on side streams and the persistent LDS-resident kernel are measured dead ends that live in the
-    DIAGNOSTICS library only (libnis_hip_diag.so, `python -m nf_amd.build --diag`): there they must still give the records of the
-    plain path (1e-12: the record partition differs) and the same BatchNorm running statistics."""
+    """Several chains on side streams, the persistent LDS-resident kernel and the register-resident bijector of the matrix-core
+    apply kernel are measured dead ends that live in the DIAGNOSTICS library only (libnis_hip_diag.so,
+    `python -m nf_amd.build --diag`): there they must still give the records of the plain path (1e-12: the record partition
+    differs; regbij: identical bins, values to rounding) and the same BatchNorm running statistics."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1577,8 +1578,8 @@ def test_fused_training_minibatch_equals_the_piecewise_path(loss_mode, builtin, 
     np.testing.assert_allclose(ra, rb, rtol=1e-6)
     for x, y in zip(ga, gb):
         np.testing.assert_allclose(x, y, rtol=1e-7, atol=1e-12)
-    for x, y in zip(pa, pb):
-        np.testing.assert_allclose(x, y, rtol=1e-8, atol=1e-12)
+    for x, y in zip(pa, pb):               # atol: parameters whose gradient is pure rounding noise (BN_0's shift cancels in BN_1) take
+        np.testing.assert_allclose(x, y, rtol=1e-8, atol=1e-8)      # lr-sized Adamax steps of arbitrary sign, as in the golden training tests
 
 
 def test_a_captured_launch_set_survives_other_engine_calls():

@@ -15,9 +15,41 @@ from nf_amd.flow import philox_rows                              # noqa: E402
 from nf_amd.normalizing_flows.manager import PWQuadManager       # noqa: E402
 
 variant = sys.argv[1]
-env = {"chains2": {"NIS_STREAMS": "2"}, "chains3": {"NIS_STREAMS": "3"}, "resident": {"NIS_MEGA": "1"}}[variant]
 assert _lib.lib().nis_diag_build() == 1, "needs the diagnostics library (NIS_LIB=.../libnis_hip_diag.so)"
 dev = torch.device("cuda:0")
+if variant == "regbij":
+    # register-resident bijector of the matrix-core apply kernel (flow_mfma_reg.h, NIS_REGBIJ=1) against the LDS-image kernel:
+    # identical bins, values to rounding (relative heights, blocked sums), for PWQuad K = 16 and PWLin K = 64
+    from nf_amd.normalizing_flows.manager import PWLinManager
+    for kind in ("pwquad", "pwlin"):
+        torch.manual_seed(4)
+        if kind == "pwquad":
+            NFw = PWQuadManager(n_flow=10)
+            NFw.create_model(5, 16, [32] * 3)
+        else:
+            NFw = PWLinManager(n_flow=8)
+            NFw.create_model(4, 4, 64, [32] * 3, 4)
+        m = NFw.best_model
+        m.train()
+        w = torch.rand(20_011, NFw.n_flow, dtype=torch.double, device=dev) * (1 - 1e-9)
+        res = {}
+        for flag in ("0", "1"):
+            os.environ["NIS_REGBIJ"] = flag
+            r = m.flow_forward(w, want_xj=True, want_bins=True)
+            res[flag] = (r["xj"].cpu().numpy(), r["bins"].cpu().numpy())
+        np.testing.assert_array_equal(res["1"][1], res["0"][1])
+        np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=1e-11, atol=1e-14)
+        f = integrands.Normal(0.5, 0.2, NFw.n_flow)
+        outs = {}
+        for flag in ("0", "1"):
+            os.environ["NIS_REGBIJ"] = flag
+            o = torch.zeros((2, 4), dtype=torch.double, device=dev)
+            m.engine().integrate_steps_rng(2, 30_001, dev, f.nis_kind, f.nis_params, o, 5, 0)
+            outs[flag] = o.cpu().numpy()
+        np.testing.assert_allclose(outs["1"], outs["0"], rtol=1e-10)
+    print("OK", variant)
+    sys.exit(0)
+env = {"chains2": {"NIS_STREAMS": "2"}, "chains3": {"NIS_STREAMS": "3"}, "resident": {"NIS_MEGA": "1"}}[variant]
 torch.manual_seed(9)
 NF = PWQuadManager(n_flow=2)
 NF.create_model(2, 4, [3] * 3)
