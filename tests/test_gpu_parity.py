@@ -1579,7 +1579,7 @@ def test_fused_training_minibatch_equals_the_piecewise_path(loss_mode, builtin, 
     for x, y in zip(ga, gb):
         np.testing.assert_allclose(x, y, rtol=1e-7, atol=1e-12)
     for x, y in zip(pa, pb):               # atol: parameters whose gradient is pure rounding noise (BN_0's shift cancels in BN_1) take
-        np.testing.assert_allclose(x, y, rtol=1e-8, atol=1e-8)      # lr-sized Adamax steps of arbitrary sign, as in the golden training tests
+        np.testing.assert_allclose(x, y, rtol=1e-7, atol=1e-6)      # lr-sized Adamax steps of arbitrary sign, as in the golden training tests
 
 
 def test_a_captured_launch_set_survives_other_engine_calls():
