@@ -240,8 +240,8 @@ static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid, int
   // workgroup's prologue merges the previous layer's records, one per workgroup
   static const int bpc_s = nis_env_int("NIS_MFMA_STATS_BPC", 0);
   *grid_stats = *ok ? (bpc_s > 0 ? std::max(*grid, nis_grid_for(bpc_s, G, N, per_wg)) : *grid) : 1;
-  // register-resident apply kernel (three workgroups per CU): the statistics kernels keep THEIR residency (two per CU)
-  if (*ok && c.regmode && bpc_s <= 0) *grid_stats = nis_grid_for(2, G, N, per_wg);
+  // the statistics kernels keep THEIR residency (two 256-thread workgroups per CU) whatever the apply kernel's workgroup shape is
+  if (*ok && bpc_s <= 0) *grid_stats = nis_grid_for(2, G, N, per_wg);
 }
 
 // Descriptor-level mirror of launch_apply's SPEC conditions (flow_wm.hip): every cell of a d = 2 PWQuad chain with 3-wide

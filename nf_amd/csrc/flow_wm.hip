@@ -273,6 +273,7 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
 #else
 #include "flow_mfma.h"
 #endif
+#include "flow_mfma_pc.h"
 
 // per wave: the whole row tiles of one column batch (flow_mfma.h, mf_cb_tiles); at least the prologue's reduction scratch
 static size_t mf_ring_bytes_n(const CellK& c, int ncb) {
@@ -294,8 +295,28 @@ static int mf_pick_ncb(const CellK& c) {
 }
 static size_t mf_ring_bytes(const CellK& c) { return mf_ring_bytes_n(c, mf_pick_ncb(c)); }
 
+// producer / consumer apply kernel (flow_mfma_pc.h): two images per pair, ONE 512-thread workgroup per CU
+static size_t mfpc_ring_bytes_n(const CellK& c, int ncb) {
+  const size_t ring = (size_t)2 * NIS_MFPC_PAIRS * mf_cb_tiles(c.T, c.out, c.R, ncb) * 256 * sizeof(double);
+  return std::max<size_t>(ring, 3 * NIS_MFPC_TPB * sizeof(double));
+}
+static int mfpc_pick_ncb(const CellK& c) {           // 0: no batch size fits
+  static const int forced = getenv("NIS_MF_NCB") ? atoi(getenv("NIS_MF_NCB")) : 0;
+  for (int n = NIS_MF_NCB; n >= 1; n >>= 1) {
+    if (forced && n != forced) continue;
+    if (mfpc_ring_bytes_n(c, n) + MF_STATIC_LDS + 1024 <= 160 * 1024) return n;
+  }
+  return 0;
+}
+static bool mf_use_pc(const CellK& c) {
+  static const int on = getenv("NIS_MF_PC") ? atoi(getenv("NIS_MF_PC")) : 1;
+  // PWQuad with more than 16 bins keeps the one-wave-per-SIMD kernel (its bin arrays need > 256 registers)
+  return on && !c.regmode && (c.kind != NIS_PWQUAD || c.K <= 16) && mfpc_pick_ncb(c) > 0;
+}
+
 template <>
 bool mfma_supported<NIS_WM>(const CellK& c) {
+  if (mf_use_pc(c)) return true;
 #ifdef NIS_DIAG
   if (c.regmode) return true;                      // register-resident bijector: no LDS image
 #endif
@@ -304,6 +325,7 @@ bool mfma_supported<NIS_WM>(const CellK& c) {
 
 template <>
 int mfma_blocks_per_cu<NIS_WM>(const CellK& c) {
+  if (mf_use_pc(c)) return 1;                      // one 512-thread workgroup per CU: a producer and a consumer wave per SIMD
 #ifdef NIS_DIAG
   if (c.regmode) {                                 // registers decide: one 256-thread workgroup = one wave per SIMD
     static const int bpc = getenv("NIS_MFR_BPC") ? atoi(getenv("NIS_MFR_BPC")) : NIS_MFR_WAVES;
@@ -352,6 +374,39 @@ hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* 
     return hipGetLastError();
   }
 #endif
+  if (mf_use_pc(c)) {                    // wave-specialised producer / consumer kernel (flow_mfma_pc.h)
+    c.mf_ncb = mfpc_pick_ncb(c_in);
+    const size_t ring = mfpc_ring_bytes_n(c, c.mf_ncb);
+    const bool fuse = fz.kind >= 0;
+    if (fuse && (!nis_mfma_fusable(c.kind, km) || bins || fz.fres)) return hipErrorInvalidValue;
+#define NIS_APPLY_PC(KIND, KMV, EX, FU)                                                                                            \
+  hipLaunchKernelGGL((k_cell_apply_mfpc<KIND, NIS_WM, KMV, EX, FU>), dim3(grid, c.Gy), dim3(NIS_MFPC_TPB), ring, s, c, planes, ld, N, \
+                     bn_train, bins, w.wm_all, w.wm_last, w.bias_pad, fz)
+#define NIS_APPLY_PCQ(KMV)                                  \
+  do {                                                      \
+    if (fuse) NIS_APPLY_PC(NIS_PWQUAD, KMV, true, true);    \
+    else if (km < 0) NIS_APPLY_PC(NIS_PWQUAD, KMV, true, false); \
+    else NIS_APPLY_PC(NIS_PWQUAD, KMV, false, false);       \
+  } while (0)
+    if (c.kind == NIS_PWLIN) {
+      if (fuse) NIS_APPLY_PC(NIS_PWLIN, 4, true, true);
+      else NIS_APPLY_PC(NIS_PWLIN, 4, false, false);
+    } else if (c.kind == NIS_AFFINE) {
+      if (fuse) NIS_APPLY_PC(NIS_AFFINE, 4, true, true);
+      else NIS_APPLY_PC(NIS_AFFINE, 4, false, false);
+    } else {
+      switch (km < 0 ? -km : km) {
+        case 4: NIS_APPLY_PCQ(4); break;
+        case 8: NIS_APPLY_PCQ(8); break;
+        case 16: NIS_APPLY_PCQ(16); break;
+        case 32: NIS_APPLY_PCQ(32); break;
+        default: return hipErrorInvalidValue;
+      }
+    }
+#undef NIS_APPLY_PCQ
+#undef NIS_APPLY_PC
+    return hipGetLastError();
+  }
   c.mf_ncb = mf_pick_ncb(c_in);
   if (fz.kind >= 0) {                      // last cell of an integrate step: integrand * J + moment records fused (FUSE instantiations)
     if (!nis_mfma_fusable(c.kind, km) || bins || fz.fres) return hipErrorInvalidValue;
