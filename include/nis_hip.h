@@ -202,6 +202,17 @@ int nis_flow_forward_train(nis_flow* f, const void* w, int32_t w_dtype, int32_t 
                            const double* const* params, double* const* running, long long* const* tracked,
                            int64_t pack_token, double* planes_hist, int64_t ld, double* bnsave, double* xj_out,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* The same pair for a forward that ran EVAL-mode BatchNorm (running statistics; the reference's autograd differentiates a model in
+ * any mode): nis_flow_forward_hist takes bn_mode (NIS_BN_TRAIN: nis_flow_forward_train); with NIS_BN_EVAL bnsave receives the
+ * running-statistics affine form, and nis_flow_backward_eval runs the adjoint without the batch-mean terms of the train-mode
+ * BatchNorm backward (dx = scale dy; d gamma = sum dy xhat, d beta = sum dy as before). */
+int nis_flow_forward_hist(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N,
+                          const double* const* params, double* const* running, long long* const* tracked, int32_t bn_mode,
+                          int64_t pack_token, double* planes_hist, int64_t ld, double* bnsave, double* xj_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int nis_flow_backward_eval(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
+                           const double* const* params, const double* bnsave, const double* gxj, double* const* gparams,
+                           double* gx_out, void* workspace, size_t workspace_bytes, void* stream);
 size_t nis_flow_backward_workspace_bytes(const nis_flow* f, int64_t N);
 int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
                       const double* const* params, const double* bnsave, const double* gxj,

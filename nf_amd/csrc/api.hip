@@ -150,7 +150,7 @@ struct RunOpts {
 bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm);
 size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N);
 int nis_bwd_cell_run(const CellK& c, int wm, const double* x, const double* xo, double* g, const double* bnsave, long ld, long N,
-                     double* ws, double* gparams, const MfmaW& mw, hipStream_t s);
+                     double* ws, double* gparams, const MfmaW& mw, bool eval_bn, hipStream_t s);
 
 static bool use_mfma() {
   static const int off = nis_env_int("NIS_NO_MFMA", 0);
@@ -291,6 +291,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   bool repack = o.pack_token == 0 || o.pack_token != f->packed_token || o.bn_mode != f->packed_mode || workspace != f->packed_ws ||
                 G != f->packed_G;
   for (int ci = 0; ci < f->n_cells && !repack; ++ci) repack = params[ci] != f->packed_params[ci] || running[ci] != f->packed_running[ci];
+  if (o.hist && !train && o.bnsave) repack = true;        // eval-mode forward with history: the pack launch also fills the adjoint's BN record
 
   // ---- ingest (+ BN_0 records of the first cell)
   const nis_cell_desc& c0 = f->cells[0];
@@ -341,14 +342,17 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   for (int ci = 0; ci < f->n_cells; ++ci)
     if (!params[ci] || !running[ci]) return NIS_E_ARG;
   if (repack) {
+    size_t bn_pack_off = 0;
     for (int ci = 0; ci < f->n_cells; ++ci) {
       const nis_cell_desc& cd = f->cells[ci];
       const CellLayout& L = lay[ci];
       const CellK c = cell_shape(ci);
+      double* bns = (o.hist && !train && o.bnsave) ? o.bnsave + bn_pack_off : nullptr;
+      bn_pack_off += (size_t)(cd.n_hidden + 1) * 4 * L.WM;
       const int pgrid = (int)std::min<size_t>(64, ((size_t)c.R * L.WM + NIS_TPB - 1) / NIS_TPB);
       NisProfScope ps(NIS_K_PACK, s);
       HIP_OK(nis_launch_pack(c, L.WM, params[ci], (const double*)running[ci], train ? 0 : 1, body + L.off_wp, body + L.off_wlast,
-                             body + L.off_bias, body + L.off_gb, body + L.off_hb, cell_hidden_bias(cd) ? 1 : 0, pgrid, s));
+                             body + L.off_bias, body + L.off_gb, body + L.off_hb, cell_hidden_bias(cd) ? 1 : 0, bns, pgrid, s));
       if (L.WM >= 16 && use_mfma()) {
         HIP_OK(nis_launch_pack_mfma(L.WM, c.L, c.R, L.RT, body + L.off_wp, body + L.off_wlast, body + L.off_bias, body + L.off_wm,
                                     body + L.off_wmlast, body + L.off_biaspad, cd.kind == NIS_AFFINE ? d - cd.P : 0,
@@ -905,20 +909,28 @@ extern "C" size_t nis_flow_bnsave_count(const nis_flow* f) {
   return n;
 }
 
-extern "C" int nis_flow_forward_train(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N,
-                                      const double* const* params, double* const* running, long long* const* tracked,
-                                      int64_t pack_token, double* planes_hist, int64_t ld, double* bnsave, double* xj_out,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int nis_flow_forward_hist(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N,
+                                     const double* const* params, double* const* running, long long* const* tracked, int32_t bn_mode,
+                                     int64_t pack_token, double* planes_hist, int64_t ld, double* bnsave, double* xj_out,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
   if (!planes_hist || !bnsave) return NIS_E_ARG;
   RunOpts o;
   o.w_has_jac = w_has_jac;
-  o.bn_mode = NIS_BN_TRAIN;
+  o.bn_mode = bn_mode;
   o.pack_token = pack_token;
   o.tracked = tracked;
   o.xj_out = xj_out;
   o.hist = 1;
   o.bnsave = bnsave;
   return flow_run(f, w, w_dtype, N, params, running, planes_hist, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
+}
+
+extern "C" int nis_flow_forward_train(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_jac, int64_t N,
+                                      const double* const* params, double* const* running, long long* const* tracked,
+                                      int64_t pack_token, double* planes_hist, int64_t ld, double* bnsave, double* xj_out,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return nis_flow_forward_hist(f, w, w_dtype, w_has_jac, N, params, running, tracked, NIS_BN_TRAIN, pack_token, planes_hist, ld, bnsave,
+                               xj_out, workspace, workspace_bytes, stream);
 }
 
 // doubles of the packed parameter image a cell's adjoint works from (row-major images + MFMA fragments when wide)
@@ -948,6 +960,7 @@ struct BwdSeed {
   const double* rec12 = nullptr;
   const double* gloss = nullptr;
   int est = 0;
+  bool eval_bn = false;                // the forward ran eval-mode BatchNorm (running statistics): no batch-mean terms in its backward
 };
 
 static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
@@ -1011,7 +1024,8 @@ static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld
     c.bias = bias;
     c.gb = gb;
     c.coef = coef;
-    HIP_OK(nis_launch_pack(c, (int)WM, params[ci], nullptr, 0, wp, wlast, bias, gb, nullptr, cell_hidden_bias(cd) ? 1 : 0, WM >= 16 ? 32 : 1, s));
+    HIP_OK(nis_launch_pack(c, (int)WM, params[ci], nullptr, 0, wp, wlast, bias, gb, nullptr, cell_hidden_bias(cd) ? 1 : 0, nullptr,
+                           WM >= 16 ? 32 : 1, s));
     MfmaW mw;
     mw.wm_all = mw.wm_last = mw.bias_pad = nullptr;
     if (WM >= 16) {
@@ -1026,7 +1040,7 @@ static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld
       mw.bias_pad = bias_pad;
     }
     int rc = nis_bwd_cell_run(c, L.WM, planes_hist + (size_t)ci * set, planes_hist + (size_t)(ci + 1) * set, g, bnsave + bn_off,
-                              (long)ld, (long)N, cellws, gparams[ci], mw, s);
+                              (long)ld, (long)N, cellws, gparams[ci], mw, seed.eval_bn, s);
     if (rc != NIS_OK) return rc;
   }
   if (gx_out) {
@@ -1037,6 +1051,16 @@ static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld
   return NIS_OK;
 }
 
+
+extern "C" int nis_flow_backward_eval(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
+                                      const double* const* params, const double* bnsave, const double* gxj, double* const* gparams,
+                                      double* gx_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!gxj) return NIS_E_ARG;
+  BwdSeed seed;
+  seed.gxj = gxj;
+  seed.eval_bn = true;
+  return flow_backward_impl(f, planes_hist, ld, N, w_has_jac, params, bnsave, seed, gparams, gx_out, workspace, workspace_bytes, stream);
+}
 
 extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
                                  const double* const* params, const double* bnsave, const double* gxj, double* const* gparams,

@@ -61,7 +61,7 @@ static inline int nis_stream_grid(int64_t N) { return (int)std::max<int64_t>(1, 
 
 // ---- api_pack.hip
 hipError_t nis_launch_pack(const CellK& c, int WM, const double* prm, const double* run, int eval_mode, double* wp, double* wlast,
-                           double* bias, double* gb, double* hb, int hidden_bias, int grid, hipStream_t s);
+                           double* bias, double* gb, double* hb, int hidden_bias, double* bnsave, int grid, hipStream_t s);
 hipError_t nis_launch_pack_mfma(int WM, int L, int R, int RT, const double* wp, const double* wlast, const double* bias, double* wm_all,
                                 double* wm_last, double* bias_pad, int affT, int regmode, int T, int K, int grid, hipStream_t s);
 

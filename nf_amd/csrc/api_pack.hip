@@ -130,7 +130,7 @@ extern "C" size_t nis_flow_workspace_bytes(const nis_flow* f, int64_t n_batches)
 // k_pack: reference-order parameter blob -> zero-padded WM-strided weights (+ eval-mode BN affine).
 __global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double* __restrict__ prm, const double* __restrict__ run,
                                                   int eval_mode, double* wp, double* wlast, double* bias, double* gb, double* hb,
-                                                  int hidden_bias) {
+                                                  int hidden_bias, double* bnsave) {
   const int tid = blockIdx.x * NIS_TPB + threadIdx.x, nth = gridDim.x * NIS_TPB;
   size_t off = 0;
   int roff = 0;
@@ -157,6 +157,12 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double*
         }
         c.coef[(l * 2 + 0) * WM + j] = sc;
         c.coef[(l * 2 + 1) * WM + j] = sh;
+        if (bnsave) {                        // eval-mode forward with history: what the adjoint reads (scale | shift | mean | rstd)
+          bnsave[(l * 4 + 0) * WM + j] = sc;
+          bnsave[(l * 4 + 1) * WM + j] = sh;
+          bnsave[(l * 4 + 2) * WM + j] = j < F ? run[roff + j] - hbv : 0.0;
+          bnsave[(l * 4 + 3) * WM + j] = j < F ? 1.0 / sqrt(run[roff + F + j] + NIS_BN_EPS) : 0.0;
+        }
       }
     }
     if (l < c.L) {
@@ -228,8 +234,9 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int
 }
 
 hipError_t nis_launch_pack(const CellK& c, int WM, const double* prm, const double* run, int eval_mode, double* wp, double* wlast,
-                           double* bias, double* gb, double* hb, int hidden_bias, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_pack, dim3(std::max(1, grid)), dim3(NIS_TPB), 0, s, c, WM, prm, run, eval_mode, wp, wlast, bias, gb, hb, hidden_bias);
+                           double* bias, double* gb, double* hb, int hidden_bias, double* bnsave, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack, dim3(std::max(1, grid)), dim3(NIS_TPB), 0, s, c, WM, prm, run, eval_mode, wp, wlast, bias, gb, hb, hidden_bias,
+                     bnsave);
   return hipGetLastError();
 }
 

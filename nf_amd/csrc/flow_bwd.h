@@ -21,6 +21,8 @@ struct BwdK {
   const double* sums;         // reduced record of the previous launch (BNACC)
   long ld, N;
   long ldw;                   // leading dimension of the workspace planes dyp / alp / dzp (wide adjoint: multiple of 16)
+  double invN;                // 1 / N with train-mode BatchNorm; 0 in eval mode: dx = scale dy, the batch-mean terms of the
+                              //   train-mode backward (mean(dy), xhat mean(dy xhat)) vanish, d gamma / d beta keep their sums
 };
 
 // ---- wide conditioners (register width 16 / 32 / 64), one translation unit per width

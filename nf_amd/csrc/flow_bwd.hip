@@ -318,7 +318,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_layer(BwdK k, int l, int s
   nis_cptr wp = as_const(c.wp);
   nis_cptr bn = as_const(k.bn);
   nis_cptr sm = as_const(k.sums);
-  const double invN = 1.0 / (double)k.N;
+  const double invN = k.invN;
   double acc[WM * WM + 2 * WM];
 #pragma unroll
   for (int a = 0; a < WM * WM + 2 * WM; ++a) acc[a] = 0.0;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_input(BwdK k, int sums_off
   const CellK& c = k.c;
   nis_cptr bn = as_const(k.bn);
   nis_cptr sm = as_const(k.sums);
-  const double invN = 1.0 / (double)k.N;
+  const double invN = k.invN;
   const long stride = (long)gridDim.x * NIS_TPB;
   for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < k.N; i += stride) {
 #pragma unroll
@@ -485,7 +485,7 @@ static int bwd_run(const CellK& c, BwdK k, double* ws, double* gparams, hipStrea
 }
 
 int nis_bwd_cell_run(const CellK& c, int wm, const double* x, const double* xo, double* g, const double* bnsave, long ld, long N,
-                     double* ws, double* gparams, const MfmaW& mw, hipStream_t s) {
+                     double* ws, double* gparams, const MfmaW& mw, bool eval_bn, hipStream_t s) {
   BwdK k;
   memset(&k, 0, sizeof(k));
   k.c = c;
@@ -496,6 +496,7 @@ int nis_bwd_cell_run(const CellK& c, int wm, const double* x, const double* xo, 
   k.ld = ld;
   k.ldw = ld;
   k.N = N;
+  k.invN = eval_bn ? 0.0 : 1.0 / (double)N;
   if (wm == 4) return bwd_run<4>(c, k, ws, gparams, s);
   if (wm == 8) return bwd_run<8>(c, k, ws, gparams, s);
   if (wm == 16) return bwd_wide_run<16>(c, k, mw, ws, gparams, s);

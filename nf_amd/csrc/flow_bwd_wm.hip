@@ -472,7 +472,7 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
   bww_stage(k, lds_bn, lds_plane);
   const long ld = k.ld, N = k.N;
-  if (tid < SREC) lds_m[tid] = k.sums[tid] * (1.0 / (double)N);
+  if (tid < SREC) lds_m[tid] = k.sums[tid] * k.invN;
   __syncthreads();
   const double* bnl = lds_bn + (size_t)l * 4 * WM;
   const double* wt = c.wp + (size_t)(l - 1) * WM * WM + (size_t)gq * WM + s;       // W_{l-1}[4 ks + gq][16 qt + s]
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
 // BN_0 backward: gradient of the pass-through columns
 __global__ __launch_bounds__(TPB) void k_bwd_input_w(BwdK k) {
   const CellK& c = k.c;
-  const double invN = 1.0 / (double)k.N;
+  const double invN = k.invN;
   const long stride = (long)gridDim.x * TPB;
   for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < k.N; i += stride)
     for (int p = 0; p < c.P; ++p) {

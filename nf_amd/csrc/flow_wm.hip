@@ -273,7 +273,9 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
 #else
 #include "flow_mfma.h"
 #endif
-#include "flow_mfma_pc.h"
+#ifdef NIS_DIAG
+#include "flow_mfma_pc.h"           // producer / consumer wave roles: diagnostics build only (measured slower)
+#endif
 
 // per wave: the whole row tiles of one column batch (flow_mfma.h, mf_cb_tiles); at least the prologue's reduction scratch
 static size_t mf_ring_bytes_n(const CellK& c, int ncb) {
@@ -295,7 +297,8 @@ static int mf_pick_ncb(const CellK& c) {
 }
 static size_t mf_ring_bytes(const CellK& c) { return mf_ring_bytes_n(c, mf_pick_ncb(c)); }
 
-// producer / consumer apply kernel (flow_mfma_pc.h): two images per pair, ONE 512-thread workgroup per CU
+#ifdef NIS_DIAG
+// producer / consumer apply kernel (flow_mfma_pc.h, opt-in with NIS_MF_PC=1): two images per pair, ONE 512-thread workgroup per CU
 static size_t mfpc_ring_bytes_n(const CellK& c, int ncb) {
   const size_t ring = (size_t)2 * NIS_MFPC_PAIRS * mf_cb_tiles(c.T, c.out, c.R, ncb) * 256 * sizeof(double);
   return std::max<size_t>(ring, 3 * NIS_MFPC_TPB * sizeof(double));
@@ -309,10 +312,13 @@ static int mfpc_pick_ncb(const CellK& c) {           // 0: no batch size fits
   return 0;
 }
 static bool mf_use_pc(const CellK& c) {
-  static const int on = getenv("NIS_MF_PC") ? atoi(getenv("NIS_MF_PC")) : 1;
+  const char* e = getenv("NIS_MF_PC");
   // PWQuad with more than 16 bins keeps the one-wave-per-SIMD kernel (its bin arrays need > 256 registers)
-  return on && !c.regmode && (c.kind != NIS_PWQUAD || c.K <= 16) && mfpc_pick_ncb(c) > 0;
+  return e && atoi(e) != 0 && !c.regmode && (c.kind != NIS_PWQUAD || c.K <= 16) && mfpc_pick_ncb(c) > 0;
 }
+#else
+static bool mf_use_pc(const CellK&) { return false; }
+#endif
 
 template <>
 bool mfma_supported<NIS_WM>(const CellK& c) {
@@ -374,6 +380,7 @@ hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* 
     return hipGetLastError();
   }
 #endif
+#ifdef NIS_DIAG
   if (mf_use_pc(c)) {                    // wave-specialised producer / consumer kernel (flow_mfma_pc.h)
     c.mf_ncb = mfpc_pick_ncb(c_in);
     const size_t ring = mfpc_ring_bytes_n(c, c.mf_ncb);
@@ -407,6 +414,7 @@ hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* 
 #undef NIS_APPLY_PC
     return hipGetLastError();
   }
+#endif
   c.mf_ncb = mf_pick_ncb(c_in);
   if (fz.kind >= 0) {                      // last cell of an integrate step: integrand * J + moment records fused (FUSE instantiations)
     if (!nis_mfma_fusable(c.kind, km) || bins || fz.fres) return hipErrorInvalidValue;

@@ -265,9 +265,9 @@ class FlowEngine:
         """True when every cell is in the class the adjoint kernels cover (include/nis_hip.h)."""
         return bool(self.L.nis_flow_backward_supported(self.handle))
 
-    def forward_train(self, w, has_jac):
-        """Train-mode forward that keeps what the adjoint needs.  Returns (xj, saved)."""
-        w = self._check_input(w, self.d + (1 if has_jac else 0), True)
+    def forward_train(self, w, has_jac, train=True):
+        """Forward that keeps what the adjoint needs (train-mode BatchNorm, or eval mode: running statistics).  Returns (xj, saved)."""
+        w = self._check_input(w, self.d + (1 if has_jac else 0), train)
         N, dev = w.shape[0], w.device
         pp, rp, tp = self._pointers(dev)
         ws, wsb = self._workspace(dev)
@@ -275,13 +275,15 @@ class FlowEngine:
         bnsave = torch.empty(self.L.nis_flow_bnsave_count(self.handle), dtype=torch.double, device=dev)
         xj = torch.empty((N, self.d + 1), dtype=torch.double, device=dev)
         with _lib.on_device(dev):
-            rc = self.L.nis_flow_forward_train(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
-                                               1 if has_jac else 0, N, pp, rp, tp, self.pack_token(), hist.data_ptr(), N,
-                                               bnsave.data_ptr(), xj.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
-        _lib.check(rc, "nis_flow_forward_train")
-        self._stats_bump(1)
+            rc = self.L.nis_flow_forward_hist(self.handle, w.data_ptr(), _lib.NIS_F32 if w.dtype == torch.float32 else _lib.NIS_F64,
+                                              1 if has_jac else 0, N, pp, rp, tp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL,
+                                              self.pack_token(), hist.data_ptr(), N, bnsave.data_ptr(), xj.data_ptr(), ws.data_ptr(), wsb,
+                                              _lib.stream_ptr(dev))
+        _lib.check(rc, "nis_flow_forward_hist")
+        if train:
+            self._stats_bump(1)
         self._raise_on_status(ws[:4].view(torch.int32))
-        return xj, (hist, bnsave, has_jac)
+        return xj, (hist, bnsave, has_jac, bool(train))
 
     def _bwd_workspace(self, N, dev):
         """Grow-only scratch of the adjoint (gradient planes, per-cell buffers), kept between calls: one minibatch's backward
@@ -317,7 +319,7 @@ class FlowEngine:
 
     def backward_loss(self, saved, fvals, maxf, rec, gloss, est):
         """Adjoint seeded by the minibatch loss (`nis_flow_backward_loss`): [flat parameter-gradient blob per cell]."""
-        hist, bnsave, has_jac = saved
+        hist, bnsave, has_jac, _train = saved
         N, dev = hist.shape[2], hist.device
         pp, _, _ = self._pointers(dev)
         n = len(self.cells)
@@ -334,7 +336,7 @@ class FlowEngine:
 
     def backward(self, saved, gxj, want_gx):
         """dL/dXJ (N, d+1) -> ([flat parameter-gradient blob per cell], dL/dx or None)."""
-        hist, bnsave, has_jac = saved
+        hist, bnsave, has_jac, train = saved
         N, dev = hist.shape[2], hist.device
         pp, _, _ = self._pointers(dev)
         n = len(self.cells)
@@ -344,8 +346,9 @@ class FlowEngine:
         gx = torch.empty((N, self.d + 1), dtype=torch.double, device=dev) if want_gx else None
         gxj = gxj.to(device=dev, dtype=torch.double).contiguous()
         with _lib.on_device(dev):
-            rc = self.L.nis_flow_backward(self.handle, hist.data_ptr(), N, N, 1 if has_jac else 0, pp, bnsave.data_ptr(), gxj.data_ptr(),
-                                          gp, gx.data_ptr() if want_gx else None, ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+            fn = self.L.nis_flow_backward if train else self.L.nis_flow_backward_eval
+            rc = fn(self.handle, hist.data_ptr(), N, N, 1 if has_jac else 0, pp, bnsave.data_ptr(), gxj.data_ptr(),
+                    gp, gx.data_ptr() if want_gx else None, ws.data_ptr(), wsb, _lib.stream_ptr(dev))
         _lib.check(rc, "nis_flow_backward")
         return gflat, gx
 

@@ -4,8 +4,10 @@ Forward values AND gradients come from the HIP kernels.  Gradients are needed on
 (/root/reference/nisrep/normalizing_flows/manager.py:275-280): `nis_flow_forward_train` keeps what the adjoint needs,
 `nis_flow_backward` runs the hand-written adjoint (nf_amd/csrc/flow_bwd.hip: conditioner widths and pass-through size <= 8 on
 the fp64 VALU; flow_bwd_wm.hip: widths 9..64 on the f64 matrix cores; PWQuad n_bins <= 32, PWLin any n_bins whose LDS image
-fits; AffineCoupling).  Shapes outside that class, and backward through eval-mode BatchNorm, RAISE: there is no stock-PyTorch
-fallback in the product (the torch re-evaluation the adjoint kernels are tested against lives in tests/torch_adjoint.py).
+fits; AffineCoupling), with train-mode BatchNorm or -- like the reference's autograd, which differentiates a model in any mode --
+eval-mode BatchNorm (running statistics: `nis_flow_forward_hist` / `nis_flow_backward_eval`).  Shapes outside that class RAISE:
+there is no stock-PyTorch fallback in the product (the torch re-evaluation the adjoint kernels are tested against lives in
+tests/torch_adjoint.py).
 """
 import torch
 
@@ -17,7 +19,7 @@ class _HipFlowFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine, train, has_jac, x, *params):
-        xj, saved = engine.forward_train(x.detach(), has_jac)
+        xj, saved = engine.forward_train(x.detach(), has_jac, train)
         ctx.engine, ctx.saved = engine, saved
         ctx.sizes = [[p.numel() for p in c.parameters()] for c in engine.cells]
         ctx.shapes = [[p.shape for p in c.parameters()] for c in engine.cells]
@@ -108,10 +110,7 @@ def run_flow(engine, modules, x, has_jac, train):
     if not need:
         return engine.forward(x, has_jac, train, want_xj=True)["xj"]
     why = None
-    if not train:
-        why = ("gradients through eval-mode BatchNorm are not built: the reference trains in train mode "
-               "(manager.py:219-280); call model.train()")
-    elif not engine.backward_supported():
+    if not engine.backward_supported():
         why = ("the adjoint kernels do not cover this model (PWQuad n_bins > 32, or a PWLin head whose LDS image "
                "does not fit): forward-only on this build")
     if why is not None and train:

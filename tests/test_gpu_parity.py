@@ -265,6 +265,55 @@ def test_hip_backward_matches_torch_adjoint(kind, K, NN, n_cells, monkeypatch):
         np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-7, atol=1e-9 * max(1.0, float(b.abs().max())), err_msg=name)
 
 
+@pytest.mark.parametrize("kind,d,P,K,NN,n_cells", [("pwquad", 2, 1, 4, [3, 3, 3], 2), ("pwlin", 3, 1, 7, [5, 4], 2), ("pwquad", 6, 3, 8, [16, 16], 2),
+                                                   ("pwlin", 8, 4, 16, [32, 32, 32], 2), ("affine", 5, 2, 0, [8, 8], 3)])
+def test_hip_backward_through_eval_mode_batchnorm(kind, d, P, K, NN, n_cells):
+    """The reference's autograd differentiates a model in ANY mode; here the adjoint of a forward that ran eval-mode BatchNorm
+    (running statistics: nis_flow_forward_hist / nis_flow_backward_eval -- no batch-mean terms) against autograd through the
+    stock-PyTorch re-evaluation in eval mode: narrow (fp64 VALU) and wide (matrix-core) adjoint kernels, every cell kind."""
+    from nf_amd.normalizing_flows.layers.coupling_cells import AffineCoupling, PWLin, PWQuad
+    from nf_amd.normalizing_flows.layers.layers import RollLayer
+    from nf_amd.normalizing_flows.sequential import FlowSequential
+    torch.manual_seed(3 * d + n_cells)
+    model = FlowSequential()
+    for i in range(n_cells):
+        cell = AffineCoupling(d, P, list(NN)) if kind == "affine" else (PWQuad if kind == "pwquad" else PWLin)(d, P, K, list(NN))
+        model.add_module(str(i), cell)
+        model.add_module("roll" + str(i), RollLayer(1))
+    model = model.double().to(dev())
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.2 * torch.randn_like(p))
+        model.train()
+        for _ in range(3):                          # give the running statistics non-trivial values
+            model(torch.cat((torch.rand(500, d, dtype=torch.double, device=dev()), torch.ones(500, 1, dtype=torch.double, device=dev())), 1))
+    model.eval()
+    assert model.engine().backward_supported()
+    N = 2003
+    x0 = torch.rand(N, d + 1, dtype=torch.double, device=dev())
+    x0[:, :d] *= (1 - 1e-9)
+    x0[:, d] += 0.5
+    R = torch.randn(N, d + 1, dtype=torch.double, device=dev())
+    stats = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "tracked" in k}
+
+    def grads(force_torch):
+        for p in model.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        out = model_torch(model, x) if force_torch else model(x)
+        (out * R).sum().backward()
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in model.parameters()]
+
+    o_h, gx_h, gp_h = grads(False)
+    for k, v in stats.items():                      # an eval-mode forward + backward leaves the buffers alone
+        assert torch.equal(model.state_dict()[k], v), k
+    o_t, gx_t, gp_t = grads(True)
+    np.testing.assert_allclose(t2n(o_h), t2n(o_t), rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(t2n(gx_h), t2n(gx_t), rtol=1e-7, atol=1e-9 * float(gx_t.abs().max()))
+    for (name, _), a, b in zip(model.named_parameters(), gp_h, gp_t):
+        np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-7, atol=1e-9 * max(1.0, float(b.abs().max())), err_msg=name)
+
+
 # ------------------------------------------------------------------------------ whole models
 @pytest.mark.parametrize("case", golden("models.npz").cases())
 def test_model_vs_reference_golden(case, g_models):
@@ -1418,7 +1467,7 @@ def test_graph_replay_of_a_launch_set_equals_eager_launches():
     np.testing.assert_allclose(fed, ref, rtol=1e-12)
 
 
-@pytest.mark.parametrize("variant", ["chains2", "chains3", "resident", "regbij"])
+@pytest.mark.parametrize("variant", ["chains2", "chains3", "resident", "regbij", "pcwaves"])
 def test_diagnostics_build_variants_agree_with_the_plain_path(variant):
     """Several chains on side streams, the persistent LDS-resident kernel and the register-resident bijector of the matrix-core
     apply kernel are measured dead ends that live in the DIAGNOSTICS library only (libnis_hip_diag.so,

@@ -17,9 +17,11 @@ from nf_amd.normalizing_flows.manager import PWQuadManager       # noqa: E402
 variant = sys.argv[1]
 assert _lib.lib().nis_diag_build() == 1, "needs the diagnostics library (NIS_LIB=.../libnis_hip_diag.so)"
 dev = torch.device("cuda:0")
-if variant == "regbij":
-    # register-resident bijector of the matrix-core apply kernel (flow_mfma_reg.h, NIS_REGBIJ=1) against the LDS-image kernel:
-    # identical bins, values to rounding (relative heights, blocked sums), for PWQuad K = 16 and PWLin K = 64
+if variant in ("regbij", "pcwaves"):
+    SWITCH = "NIS_REGBIJ" if variant == "regbij" else "NIS_MF_PC"
+    # register-resident bijector (flow_mfma_reg.h, NIS_REGBIJ=1) / producer-consumer wave roles (flow_mfma_pc.h, NIS_MF_PC=1) of the
+    # matrix-core apply kernel against the product's LDS-image kernel: identical bins, values to rounding (regbij: relative heights,
+    # blocked sums; pcwaves: the same arithmetic, bit-identical), for PWQuad K = 16 and PWLin K = 64
     from nf_amd.normalizing_flows.manager import PWLinManager
     for kind in ("pwquad", "pwlin"):
         torch.manual_seed(4)
@@ -34,7 +36,7 @@ if variant == "regbij":
         w = torch.rand(20_011, NFw.n_flow, dtype=torch.double, device=dev) * (1 - 1e-9)
         res = {}
         for flag in ("0", "1"):
-            os.environ["NIS_REGBIJ"] = flag
+            os.environ[SWITCH] = flag
             r = m.flow_forward(w, want_xj=True, want_bins=True)
             res[flag] = (r["xj"].cpu().numpy(), r["bins"].cpu().numpy())
         np.testing.assert_array_equal(res["1"][1], res["0"][1])
@@ -42,7 +44,7 @@ if variant == "regbij":
         f = integrands.Normal(0.5, 0.2, NFw.n_flow)
         outs = {}
         for flag in ("0", "1"):
-            os.environ["NIS_REGBIJ"] = flag
+            os.environ[SWITCH] = flag
             o = torch.zeros((2, 4), dtype=torch.double, device=dev)
             m.engine().integrate_steps_rng(2, 30_001, dev, f.nis_kind, f.nis_params, o, 5, 0)
             outs[flag] = o.cpu().numpy()
