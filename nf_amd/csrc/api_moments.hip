@@ -452,7 +452,8 @@ extern "C" int nis_loss_terms(const double* fv_in, const double* xrows, int64_t 
   a.kind = f_kind;
   for (int k = 0; k < 4; ++k) a.p[k] = f_params_host ? f_params_host[k] : 0.0;
   hipStream_t s = (hipStream_t)stream;
-  const int grid = nis_stream_grid(N);
+  // two workgroups per CU: the pass streams 16-24 B per sample, and every record costs the one-workgroup merge three Chan updates
+  const int grid = std::min(nis_stream_grid(N), 2 * nis_device_cus());
   {
     NisProfScope ps(NIS_K_MOMENTS, s);
     hipLaunchKernelGGL(k_loss_terms, dim3(grid), dim3(NIS_TPB), 0, s, src, a, (long)N, (double*)workspace);

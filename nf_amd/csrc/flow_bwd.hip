@@ -379,8 +379,9 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_input(BwdK k, int sums_off
 // Summed records -> gradient blob in the reference's parameter order (include/nis_hip.h).
 //   sums: [pass 0 = head (BN_L sums) | pass 1 = layer L | ... | pass L = layer 1], each BNACC doubles;
 //   wsum: one BNACC record per chunk of BRC last-layer rows, [r][WM weights | bias].
+// hidden_bias (NIS_AFFINE): 1 = train-mode BatchNorm, 2 = eval mode (`bn`: the saved scale | shift | mean | rstd records).
 __global__ void k_bwd_scatter(CellK c, int WM, const double* __restrict__ sums, const double* __restrict__ wsum,
-                              double* __restrict__ gparams, int hidden_bias) {
+                              double* __restrict__ gparams, int hidden_bias, const double* __restrict__ bn) {
   const int L = c.L;
   size_t off = 0;
   const int tid = threadIdx.x, nth = blockDim.x;
@@ -398,8 +399,11 @@ __global__ void k_bwd_scatter(CellK c, int WM, const double* __restrict__ sums, 
     if (l < L) {                       // dW_l from layer pass l+1 (pass index L-l)
       const double* w = sums + (size_t)(L - l) * BNACC;
       for (int e = tid; e < O * F; e += nth) gparams[off + e] = w[(e / F) * WM + (e % F)];
-      if (hidden_bias) {                 // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0
-        for (int e = tid; e < O; e += nth) gparams[off + (size_t)O * F + e] = 0.0;
+      if (hidden_bias) {                 // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0;
+        // in eval mode dh_{l+1} = scale_{l+1} dy_{l+1}, so the bias of Linear_l gets scale_{l+1} * sum dy_{l+1}
+        const double* s1 = (l + 1 == L) ? sums : sums + (size_t)(L - l - 1) * BNACC + WM * WM;
+        for (int e = tid; e < O; e += nth)
+          gparams[off + (size_t)O * F + e] = hidden_bias == 2 ? bn[((l + 1) * 4 + 0) * WM + e] * s1[e] : 0.0;
       }
     } else {
       for (int e = tid; e < O * F; e += nth) {
@@ -480,7 +484,7 @@ static int bwd_run(const CellK& c, BwdK k, double* ws, double* gparams, hipStrea
   k.sums = sums + (size_t)L * BNACC;
   hipLaunchKernelGGL((k_cell_bwd_input<WM>), dim3(grid), dim3(NIS_TPB), 0, s, k, WM * WM);
   hipLaunchKernelGGL(k_bwd_scatter, dim3(1), dim3(NIS_TPB), 0, s, c, WM, (const double*)sums, (const double*)wsum, gparams,
-                     c.kind == NIS_AFFINE ? 1 : 0);
+                     c.kind == NIS_AFFINE ? (k.invN == 0.0 ? 2 : 1) : 0, k.bn);
   return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
 }
 

@@ -671,8 +671,10 @@ __global__ __launch_bounds__(TPB) void k_bwd_reduce_w(const double* __restrict__
 // Reduced records -> gradient blob in the reference's parameter order (include/nis_hip.h).
 //   sums : pass p (0 = head, L - l + 1 = layer kernel l) holds the sums of BN_{L-p}: [sum dy | sum dy xhat]
 //   glast: GEMM result of the last Linear (row groups of GREC); ghid + m*ngh*GREC: of hidden Linear m
+// hidden_bias (NIS_AFFINE): 1 = train-mode BatchNorm, 2 = eval mode (`bn`: the saved scale | shift | mean | rstd records).
 __global__ void k_bwd_scatter_w(CellK c, const double* __restrict__ sums, const double* __restrict__ glast,
-                                const double* __restrict__ ghid, int ngh, double* __restrict__ gparams, int hidden_bias) {
+                                const double* __restrict__ ghid, int ngh, double* __restrict__ gparams, int hidden_bias,
+                                const double* __restrict__ bn) {
   const int L = c.L, tid = threadIdx.x, nth = blockDim.x;
   size_t off = 0;
   for (int l = 0; l <= L; ++l) {
@@ -690,8 +692,9 @@ __global__ void k_bwd_scatter_w(CellK c, const double* __restrict__ sums, const 
       gparams[off + e] = src[(size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + q];
     }
     off += (size_t)O * F;
-    if (hidden_bias && l < L) {          // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0
-      for (int e = tid; e < O; e += nth) gparams[off + e] = 0.0;
+    if (hidden_bias && l < L) {          // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0;
+      const double* s1 = sums + (size_t)(L - l - 1) * SREC;      // eval mode: scale_{l+1} * sum dy_{l+1}
+      for (int e = tid; e < O; e += nth) gparams[off + e] = hidden_bias == 2 ? bn[((l + 1) * 4 + 0) * WM + e] * s1[e] : 0.0;
       off += O;
     }
   }
@@ -817,6 +820,6 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
     hipLaunchKernelGGL(k_bwd_input_w, dim3(gi), dim3(TPB), 0, s, k);
   }
   hipLaunchKernelGGL(k_bwd_scatter_w, dim3(1), dim3(TPB), 0, s, c, (const double*)sums, (const double*)glast, (const double*)ghid, p.ngh,
-                     gparams, c.kind == NIS_AFFINE ? 1 : 0);
+                     gparams, c.kind == NIS_AFFINE ? (k.invN == 0.0 ? 2 : 1) : 0, k.bn);
   return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
 }
