@@ -24,6 +24,9 @@ typedef double nis_d4 __attribute__((ext_vector_type(4)));
 #ifndef NIS_MF_PREFETCH
 #define NIS_MF_PREFETCH 1              // 0: operands requested where they are used (A/B measurements)
 #endif
+#ifndef NIS_MF_TILE_INTERLEAVE
+#define NIS_MF_TILE_INTERLEAVE 1       // next tile's A fragments requested one by one behind the MFMAs that free their registers (0: all behind the chain; round 3: C3 / C4 / C5 iteration 12.20 / 2.64 / 6.65 -> 11.81 / 2.57 / 6.46 ms)
+#endif
 
 // Row tiles of the last layer one column batch touches (its rows [cb NCB out, (cb+1) NCB out) need not start on a tile): the
 // per-wave LDS image holds that many whole tiles, so every accumulator row is written without a guard at a fixed offset.
@@ -417,8 +420,17 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
   double xin[PQ][ST];
   const long base0 = ((long)blockIdx.x * NW + wave) * 16 * ST;
   if (pin && base0 < N) mf_issue_input<WM, PQ>(c, planes, ld, N, base0, lds_plane, xin);
+#ifdef NIS_MF_STAMPS
+  long long st_hidden = 0, st_tiles = 0, st_bij = 0, st_tail = 0, st_t0 = clock64(), st_a, st_b;
+#define MF_STAMP(acc_) do { st_b = clock64(); acc_ += st_b - st_a; st_a = st_b; } while (0)
+#else
+#define MF_STAMP(acc_) do { } while (0)
+#endif
   for (long base = base0; base < N; base += wstride) {
     double H[KQ][ST];
+#ifdef NIS_MF_STAMPS
+    st_a = clock64();
+#endif
     {
       nis_d4 acc[JT][ST];
       if (pin) {
@@ -430,6 +442,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
       mf_hidden<WM>(c, wm_all, lds_coef, c.L, H, acc);
       mf_bn_relu<WM>(lds_coef + (size_t)c.L * 2 * WM, acc, H);
     }
+    MF_STAMP(st_hidden);
     if (c.out_off != 0) {                              // history mode: the next plane set gets the pass-through block too
       for (int p = gq; p < c.P; p += 4)
 #pragma unroll
@@ -483,9 +496,26 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
         double* rw = ring + lane;                      // row (16 (jt - jt0) + gq + 4 r), sample s  ->  rw[256 (jt - jt0) + 64 r]
         for (int jt = jt0; jt * 16 < r1; ++jt) {
           nis_d4 z = bnx;
+#if NIS_MF_TILE_INTERLEAVE
+          // the next tile's operands are requested AS their registers fall free: the bias rows at once (z holds this tile's copy), each A
+          // fragment right behind the MFMA that read it -- the chain is dependent, so the requests go out 64 cycles apart and the first
+          // ones have the whole chain + the exp phase to land (all of them behind the chain left ~170 cycles for an L2 round trip, and
+          // the stamps of tools/wide_stamps.py showed this loop at 2.4x its datapath time)
+          const int jn = (jt + 1) * 16 < r1 ? jt + 1 : jt_first_next;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bnx[r] = bias_pad[16 * jn + gq + 4 * r];
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) {
+            z = __builtin_amdgcn_mfma_f64_16x16x4f64(an[q], Hs[q], z, 0, 0, 0);
+            an[q] = wm_last[((size_t)jn * KQ + q) * 64 + lane];
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA ...
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // ... then one VMEM read
+          }
+#else
 #pragma unroll
           for (int q = 0; q < KQ; ++q) z = __builtin_amdgcn_mfma_f64_16x16x4f64(an[q], Hs[q], z, 0, 0, 0);
           load_tile((jt + 1) * 16 < r1 ? jt + 1 : jt_first_next);
+#endif
           // every row of the tile goes to the image (rows of the neighbouring batch and the zero-padded rows past R land in
           // entries nobody reads): no guards, no address arithmetic -- immediate offsets off one pointer
 #pragma unroll
@@ -495,6 +525,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
         // (sample s, column t) per lane.  A wave executes in lock step and its LDS operations complete in order:
         // the image written above is complete; the wave barriers only pin the compiler's schedule.
         __builtin_amdgcn_wave_barrier();
+        MF_STAMP(st_tiles);
         if (gq < NCB && t < c.T && i < N) {
           double* col = planes + (size_t)lds_plane[c.P + t] * ld;
           const double xb = NIS_MF_PREFETCH ? xbq : col[i];
@@ -557,6 +588,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
           if (KIND != NIS_AFFINE && bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
         }
         __builtin_amdgcn_wave_barrier();
+        MF_STAMP(st_bij);
       }
       // product over this sample's columns: 4 lanes (row groups) share a sample
       jprod *= __shfl_xor(jprod, 16, 64);
@@ -596,7 +628,14 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
         fmx = mine ? fmax(fmx, v) : fmx;
         fcnt += mine ? 1.0 : 0.0;
       }
+      MF_STAMP(st_tail);
     }
   }
+#ifdef NIS_MF_STAMPS
+  if (blockIdx.x == 1 && blockIdx.y == 0 && lane == 0 && c.status) {      // diagnostics: bytes 64.. of the workspace header (nothing reads them)
+    long long* o = reinterpret_cast<long long*>(reinterpret_cast<char*>(c.status) + 64) + wave * 5;
+    o[0] = st_hidden; o[1] = st_tiles; o[2] = st_bij; o[3] = st_tail; o[4] = clock64() - st_t0;
+  }
+#endif
   if (FUSE) block_record<NW>(fshift, fS1, fS2, fcnt, fmx, fmom, fz.partials + ((size_t)g * fz.maxb + blockIdx.x) * 4);
 }
