@@ -235,7 +235,7 @@ def config_integrand(name):
     return integrands.RamboWeight(gen, 13000., 20, 0.4, 2.5, [21, 21]), "RAMBO 2->6 massless weight, cuts pT 20 / dR 0.4 / eta 2.5"
 
 
-def bench_config(name, rank, ws, dev, steps=3):
+def bench_config(name, rank, ws, dev, steps=6):
     """BASELINE config `name` at its per-GPU batch: `steps` iterations of integrate()'s loop body (draw, flow forward with
     train-mode BN on the f64 matrix cores, integrand * J, moments), records of all ranks combined by one all-reduce."""
     kind, d, kw, N, quoted_gpus, flops = CONFIGS[name]

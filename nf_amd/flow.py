@@ -156,8 +156,16 @@ class FlowEngine:
     def pack_token(self):
         """Changes whenever a parameter / BN buffer was modified (torch version counters) or a train-mode
         forward (of ANY engine over these cells) advanced the running statistics: libnis_hip then re-packs its parameter image."""
-        sig = tuple(getattr(c, "_stats_epoch", 0) for c in self.cells) + \
-            tuple(t._version for c in self.cells for t in c.state_dict(keep_vars=True).values())
+        # (the tensors behind a cell's state_dict are looked up once per blob generation: building eight state_dicts per call cost
+        #  more host time than the launches of a small integrate() set)
+        tens = []
+        for c in self.cells:
+            cache = getattr(c, "_sd_cache", None)
+            if cache is None or cache[0] is not c._flat or cache[1] is not c._running:
+                cache = (c._flat, c._running, list(c.state_dict(keep_vars=True).values()))
+                c._sd_cache = cache
+            tens.append(cache[2])
+        sig = tuple(getattr(c, "_stats_epoch", 0) for c in self.cells) + tuple(t._version for ts in tens for t in ts)
         if sig != self._sig:
             self._sig = sig
             self._token += 1

@@ -82,7 +82,7 @@ class _PiecewiseCell(torch.nn.Module):
         for k, v in self.__dict__.items():
             if k == "_engine":
                 new.__dict__[k] = None
-            elif k in ("_flat", "_running", "_tracked"):
+            elif k in ("_flat", "_running", "_tracked", "_sd_cache"):
                 new.__dict__[k] = None
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)
