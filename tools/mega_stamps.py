@@ -12,6 +12,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nf_amd import _lib, integrands                              # noqa: E402
+from nf_amd import _lib as _nis_lib                               # noqa: E402
+assert _nis_lib.lib().nis_diag_build() == 1, "this probe exercises a quarantined variant: run it with NIS_LIB=nf_amd/lib/libnis_hip_diag.so (python -m nf_amd.build --diag)"
 from nf_amd.normalizing_flows.manager import PWQuadManager       # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
