@@ -249,6 +249,34 @@ int nis_flow_backward_loss(nis_flow* f, const double* planes_hist, int64_t ld, i
                            const double* rec12, const double* gloss_dev, int32_t est, double* const* gparams,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* The G minibatches of ONE optimizer step per call (manager.py:219-270: the epoch's loss is the mean of the minibatch losses and
+ * loss.backward() runs once, so the minibatches are independent given the parameters): every launch carries them as its y dimension,
+ * each with its own train-mode BatchNorm statistics; the reference's default regime (mini_batch_size = 2000) is launch-bound otherwise.
+ *   nis_flow_forward_hist_batched: w (G, N, d); planes_hist (G, n_cells + 1, d + 1, ld); bnsave (G, nis_flow_bnsave_count) (NIS_BN_EVAL:
+ *     one record); xj_out (G, N, d + 1) optional; workspace >= nis_flow_workspace_bytes(f, G).  The running statistics advance in
+ *     minibatch order.
+ *   nis_loss_terms_batched: fv_in / fv_out (G, N), rec12 (G, 12), out8 (G, 8).  A built-in integrand (fv_in == NULL) reads element
+ *     (column c, sample i) of minibatch g at xbase[g x_batch_stride + x_cols[c] x_col_stride + i x_row_stride]: rows of a (G, N, d)
+ *     matrix (strides 1, d, N d) or the output planes of the history (strides ld, 1, (n_cells + 1)(d + 1) ld; x_cols = out_col).
+ *     J_i of minibatch g at jac[g jac_batch_stride + i jstride].  workspace >= nis_loss_workspace_bytes_batched(G, N).
+ *   nis_flow_backward_loss_batched: gparams[c] = sum over the minibatches of gloss * d loss_g / d(parameter blob of cell c).
+ *     workspace >= nis_flow_backward_workspace_bytes_batched(f, G, N). */
+int nis_flow_forward_hist_batched(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_batches, int64_t N,
+                                  const double* const* params, double* const* running, long long* const* tracked, int32_t bn_mode,
+                                  int64_t pack_token, double* planes_hist, int64_t ld, double* bnsave, double* xj_out,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+size_t nis_loss_workspace_bytes_batched(int32_t n_batches, int64_t N);
+int nis_loss_terms_batched(const double* fv_in, const double* xbase, int64_t x_col_stride, int64_t x_row_stride, int64_t x_batch_stride,
+                           const int32_t* x_cols_host, int32_t d, int32_t f_kind, const double* f_params_host, double* fv_out,
+                           const double* jac, int64_t jstride, int64_t jac_batch_stride, int32_t n_batches, int64_t N,
+                           const double* maxf_dev, int32_t preburn, int32_t est, double* rec12, double* out8,
+                           void* workspace, size_t workspace_bytes, void* stream);
+size_t nis_flow_backward_workspace_bytes_batched(const nis_flow* f, int32_t n_batches, int64_t N);
+int nis_flow_backward_loss_batched(nis_flow* f, const double* planes_hist, int64_t ld, int32_t n_batches, int64_t N,
+                                   const double* const* params, const double* bnsave, int32_t bn_mode, const double* fvals,
+                                   const double* maxf_dev, const double* rec12, const double* gloss_dev, int32_t est,
+                                   double* const* gparams, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Streaming moments of a vector (optionally of the product a[i]*b[i], b may be NULL). */
 size_t nis_moments_workspace_bytes(void);
 int nis_moments(const double* a, const double* b, int64_t N, double* out4,

@@ -27,7 +27,9 @@ LIB_PATH = os.environ.get("NIS_LIB") or os.path.join(os.path.dirname(os.path.abs
 EXPORTS = ["nis_cell_param_count", "nis_cell_running_count", "nis_flow_create", "nis_flow_destroy",
            "nis_flow_workspace_bytes", "nis_flow_forward", "nis_flow_forward_sync", "nis_integrate_steps", "nis_integrate_steps_rng",
            "nis_integrate_resident", "nis_integrate_rng_mode", "nis_diag_build", "nis_philox_rows", "nis_integrate_steps_bins", "nis_flow_fusable", "nis_flow_backward_supported",
-           "nis_flow_bnsave_count", "nis_flow_forward_train", "nis_flow_forward_hist", "nis_flow_backward_eval", "nis_flow_backward_workspace_bytes", "nis_flow_backward", "nis_flow_backward_loss", "nis_loss_terms", "nis_loss_workspace_bytes", "nis_integrand_moments", "nis_integrand_eval",
+           "nis_flow_bnsave_count", "nis_flow_forward_train", "nis_flow_forward_hist", "nis_flow_backward_eval", "nis_flow_backward_workspace_bytes", "nis_flow_backward", "nis_flow_backward_loss", "nis_loss_terms", "nis_loss_workspace_bytes",
+           "nis_flow_forward_hist_batched", "nis_loss_workspace_bytes_batched", "nis_loss_terms_batched",
+           "nis_flow_backward_workspace_bytes_batched", "nis_flow_backward_loss_batched", "nis_integrand_moments", "nis_integrand_eval",
            "nis_moments_workspace_bytes",
            "nis_moments", "nis_merge_moments", "nis_rambo_forward", "nis_rambo_forward_pdf", "nis_rambo_moments", "nis_rambo_moments_workspace_bytes", "nis_pdf_xfx", "nis_prof_enable", "nis_prof_read", "nis_prof_disable", "nis_last_error", "nis_version", "nis_device_count"]
 
@@ -119,6 +121,18 @@ def lib():
     L.nis_loss_workspace_bytes.argtypes = []
     L.nis_loss_terms.restype = i32
     L.nis_loss_terms.argtypes = [vp, vp, i64, i32, i32, C.POINTER(C.c_double), vp, vp, i64, i64, vp, i32, i32, vp, vp, vp, sz, vp]
+    L.nis_flow_forward_hist_batched.restype = i32
+    L.nis_flow_forward_hist_batched.argtypes = [vp, vp, i32, i32, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, vp, i64, vp, vp,
+                                                vp, sz, vp]
+    L.nis_loss_workspace_bytes_batched.restype = sz
+    L.nis_loss_workspace_bytes_batched.argtypes = [i32, i64]
+    L.nis_loss_terms_batched.restype = i32
+    L.nis_loss_terms_batched.argtypes = [vp, vp, i64, i64, i64, C.POINTER(i32), i32, i32, C.POINTER(C.c_double), vp, vp, i64, i64, i32, i64,
+                                         vp, i32, i32, vp, vp, vp, sz, vp]
+    L.nis_flow_backward_workspace_bytes_batched.restype = sz
+    L.nis_flow_backward_workspace_bytes_batched.argtypes = [vp, i32, i64]
+    L.nis_flow_backward_loss_batched.restype = i32
+    L.nis_flow_backward_loss_batched.argtypes = [vp, vp, i64, i32, i64, C.POINTER(vp), vp, i32, vp, vp, vp, vp, i32, C.POINTER(vp), vp, sz, vp]
     L.nis_flow_forward_sync.restype = i32
     L.nis_flow_forward_sync.argtypes = [vp, vp, i32, i32, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64, vp, i64, vp, vp, sz, vp,
                                         SYNC_FN, vp, vp, i32, i32]

@@ -148,9 +148,11 @@ struct RunOpts {
 
 // declared in flow_bwd.hip
 bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm);
-size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N);
-int nis_bwd_cell_run(const CellK& c, int wm, const double* x, const double* xo, double* g, const double* bnsave, long ld, long N,
-                     double* ws, double* gparams, const MfmaW& mw, bool eval_bn, hipStream_t s);
+size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N, int G);
+size_t nis_bwd_cell_params(const nis_cell_desc& cd);
+int nis_bwd_cell_run(const CellK& c, const nis_cell_desc& cd, int wm, const double* x, const double* xo, double* g, const double* bnsave,
+                     long ld, long N, int G, long x_gs, long g_gs, long bn_gs, double* ws, double* gparams, double* gtmp, const MfmaW& mw,
+                     bool eval_bn, hipStream_t s);
 
 static bool use_mfma() {
   static const int off = nis_env_int("NIS_NO_MFMA", 0);
@@ -275,7 +277,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   if (w_dtype != NIS_F64 && w_dtype != NIS_F32) return NIS_E_ARG;
   const int G = o.G;
   if (G < 1 || G > 65535) return NIS_E_ARG;
-  if (G > 1 && (o.xj_out || o.bins_out || o.w_has_jac || o.hist)) return NIS_E_UNSUPPORTED;
+  if (G > 1 && (o.bins_out || o.w_has_jac || (o.xj_out && !o.hist))) return NIS_E_UNSUPPORTED;
   if (!workspace || workspace_bytes < nis_flow_workspace_bytes(f, G)) return NIS_E_WORKSPACE;
   std::vector<CellLayout> lay;
   size_t off_fpart = 0, off_mega = 0;
@@ -285,7 +287,8 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   const int d = f->d;
   const bool train = o.bn_mode == NIS_BN_TRAIN;
   const int wcols = o.w_has_jac ? d + 1 : d;
-  const long plane_gs = (long)(d + 1) * ld;
+  const long set = (long)(d + 1) * ld;                                   // one plane set
+  const long plane_gs = o.hist ? (long)(f->n_cells + 1) * set : set;     // history: batch g owns n_cells + 1 consecutive sets
 
   // is the padded parameter image in this workspace still valid?
   bool repack = o.pack_token == 0 || o.pack_token != f->packed_token || o.bn_mode != f->packed_mode || workspace != f->packed_ws ||
@@ -503,7 +506,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     for (int ci = 0; ci < f->n_cells; ++ci) {
       const nis_cell_desc& cd = f->cells[ci];
       const CellLayout& L = lay[ci];
-      if (o.hist) pl = planes + (size_t)ci * plane_gs;
+      if (o.hist) pl = planes + (size_t)ci * set;
       int grid_stats = 1, grid_apply = 1;
       switch (L.WM) {
         // folded statistics launches (k_bn_stats_fold): train mode, one pass-through column, BN_1 derived
@@ -563,7 +566,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       c.wx = cell_wx(cd, L.WM);
       c.sync_part = o.sync_fn ? o.sync_buf : nullptr;
       c.sync_world = o.sync_world;
-      c.pmerge = (G == 1 || !nis_env_int("NIS_FINALIZE_KERNEL", 0)) ? 1 : 0;   // a launch costs >= 4.3 us, the prologue merge ~1 us
+      c.pmerge = (G == 1 || o.hist || !nis_env_int("NIS_FINALIZE_KERNEL", 0)) ? 1 : 0;   // a launch costs >= 4.3 us, the prologue merge ~1 us
       if (direct) {
         c.wrows = wrows;
         c.wrows_gs = wrows_gs;
@@ -575,8 +578,9 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       } else {
         c.x_wcol = c.xb_wcol = -1;
       }
-      c.out_off = o.hist ? plane_gs : 0;
+      c.out_off = o.hist ? set : 0;
       c.bnsave = (o.hist && o.bnsave && train) ? o.bnsave + bn_off : nullptr;
+      c.bnsave_gs = (long)nis_flow_bnsave_count(f);
       bn_off += (size_t)(cd.n_hidden + 1) * 4 * L.WM;
       // rider 1: BN_0 records of the next cell (every state column is in this thread's registers)
       bool next_rider = false;
@@ -701,10 +705,10 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     ColMap m;
     for (int j = 0; j < d; ++j) m.col[j] = f->out_col[j];
     m.col[d] = d;
-    const int tgrid = nis_grid_for(8, 1, N, NIS_TPB);
-    double* pl = o.hist ? planes + (size_t)f->n_cells * plane_gs : planes;      // hist: the final state lives in the last plane set
+    const int tgrid = nis_grid_for(8, G, N, NIS_TPB);
+    double* pl = o.hist ? planes + (size_t)f->n_cells * set : planes;      // hist: the final state lives in the last plane set
     NisProfScope ps(NIS_K_EMIT, s);
-    HIP_OK(nis_launch_emit(pl, (long)ld, (long)N, d, m, o.xj_out, tgrid, s));
+    HIP_OK(nis_launch_emit(pl, (long)ld, (long)N, d, m, o.xj_out, tgrid, s, G, plane_gs));
   }
   return NIS_OK;
 }
@@ -941,21 +945,34 @@ static size_t bwd_pack_doubles(const nis_cell_desc& cd, size_t WM) {
   return n;
 }
 
-extern "C" size_t nis_flow_backward_workspace_bytes(const nis_flow* f, int64_t N) {
-  size_t cellws = 0, pk = 0;
+// doubles of one call's adjoint scratch: gradient planes of the G minibatches, the largest cell workspace, the packed parameter
+// image, one cell's gradient blob (wide cells run one minibatch at a time and are added up)
+static void bwd_ws_layout(const nis_flow* f, int G, int64_t N, size_t* gplanes, size_t* cellws, size_t* pk, size_t* gtmp) {
   std::vector<CellLayout> lay;
   nis_flow_layout(f, 1, &lay, nullptr);
+  *cellws = *pk = *gtmp = 0;
   for (int ci = 0; ci < f->n_cells; ++ci) {
-    cellws = std::max(cellws, nis_bwd_cell_workspace_doubles(f->cells[ci], lay[ci].WM, N));
-    pk = std::max(pk, bwd_pack_doubles(f->cells[ci], lay[ci].WM));
+    *cellws = std::max(*cellws, nis_bwd_cell_workspace_doubles(f->cells[ci], lay[ci].WM, N, G));
+    *pk = std::max(*pk, bwd_pack_doubles(f->cells[ci], lay[ci].WM));
+    *gtmp = std::max(*gtmp, nis_bwd_cell_params(f->cells[ci]));
   }
-  return ((size_t)(f->d + 1) * N + cellws + pk + 64) * sizeof(double);
+  *gplanes = ((size_t)G * (f->d + 1) * N + 15) / 16 * 16;          // 128-byte aligned: the wide adjoint uses vector loads
+  *cellws = (*cellws + 15) / 16 * 16;
+  *pk = (*pk + 15) / 16 * 16;
 }
+
+extern "C" size_t nis_flow_backward_workspace_bytes_batched(const nis_flow* f, int32_t n_batches, int64_t N) {
+  if (!f || n_batches < 1 || N < 1) return 0;
+  size_t gp, cw, pk, gt;
+  bwd_ws_layout(f, n_batches, N, &gp, &cw, &pk, &gt);
+  return (gp + cw + pk + gt + 64) * sizeof(double);
+}
+extern "C" size_t nis_flow_backward_workspace_bytes(const nis_flow* f, int64_t N) { return nis_flow_backward_workspace_bytes_batched(f, 1, N); }
 
 // where the output cotangent comes from: a (N, d+1) row-major dL/dXJ, or the minibatch loss of nis_loss_terms (dL/dJ only)
 struct BwdSeed {
   const double* gxj = nullptr;
-  const double* fv = nullptr;          // loss seed: integrand values, device scalars maxf / gloss, nis_loss_terms' records
+  const double* fv = nullptr;          // loss seed: integrand values (G, N), device scalars maxf / gloss, nis_loss_terms' records (G, 12)
   const double* maxf = nullptr;
   const double* rec12 = nullptr;
   const double* gloss = nullptr;
@@ -963,35 +980,40 @@ struct BwdSeed {
   bool eval_bn = false;                // the forward ran eval-mode BatchNorm (running statistics): no batch-mean terms in its backward
 };
 
-static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
+// G minibatches: planes_hist (G, n_cells + 1, d + 1, ld), bnsave (G, nis_flow_bnsave_count) (eval mode: one record), gradient
+// planes (G, d + 1, ld); gparams[c] receives the SUM over the minibatches.
+static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld, int G, int64_t N, int32_t w_has_jac,
                               const double* const* params, const double* bnsave, const BwdSeed& seed, double* const* gparams,
                               double* gx_out, void* workspace, size_t workspace_bytes, void* stream) {
   const double* gxj = seed.gxj;
-  if (!f || !planes_hist || !params || !bnsave || (!gxj && !seed.fv) || !gparams || N < 1 || ld != N) return NIS_E_ARG;   // gradient planes share ld
+  if (!f || !planes_hist || !params || !bnsave || (!gxj && !seed.fv) || !gparams || N < 1 || ld != N || G < 1 || G > 65535) return NIS_E_ARG;   // gradient planes share ld
+  if (G > 1 && (gxj || gx_out || w_has_jac)) return NIS_E_UNSUPPORTED;
   if (!nis_flow_backward_supported(f)) return NIS_E_UNSUPPORTED;
-  if (!workspace || workspace_bytes < nis_flow_backward_workspace_bytes(f, N)) return NIS_E_WORKSPACE;
+  if (!workspace || workspace_bytes < nis_flow_backward_workspace_bytes_batched(f, G, N)) return NIS_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int d = f->d;
   const long set = (long)(d + 1) * ld;
-  double* g = (double*)workspace;                       // gradient planes (d+1, ld)
-  double* cellws = g + ((size_t)(d + 1) * N + 15) / 16 * 16;      // 128-byte aligned: the wide adjoint uses vector loads
-  size_t cw = 0;
+  const long hist_gs = (long)(f->n_cells + 1) * set;
+  size_t gpl, cw, pkd, gtd;
+  bwd_ws_layout(f, G, N, &gpl, &cw, &pkd, &gtd);
+  double* g = (double*)workspace;                       // gradient planes (G, d+1, ld)
+  double* cellws = g + gpl;
+  double* pk = cellws + cw;
+  double* gtmp = pk + pkd;
   std::vector<CellLayout> lay;
   nis_flow_layout(f, 1, &lay, nullptr);
-  for (int ci = 0; ci < f->n_cells; ++ci) cw = std::max(cw, nis_bwd_cell_workspace_doubles(f->cells[ci], lay[ci].WM, N));
-  double* pk = cellws + cw;
-  const int tgrid = nis_grid_for(8, 1, N, NIS_TPB);
+  const int tgrid = nis_grid_for(8, G, N, NIS_TPB);
   // dL/dXJ (N, d+1) row-major in the model's OUTPUT column order -> gradient planes (output column c lives in plane out_col[c])
   if (!gxj) {                         // seeded by the minibatch loss: dL/dJ from the records, zeros for the coordinates
     HIP_OK(nis_launch_loss_cotangent(seed.fv, planes_hist + (size_t)f->n_cells * set + (size_t)d * ld, 1, (long)N, seed.maxf, seed.rec12,
-                                     seed.gloss, seed.est, d, g, (long)N, s));
+                                     seed.gloss, seed.est, d, g, (long)N, s, G, hist_gs, set));
   } else {
     ColMap m;
     for (int j = 0; j < d; ++j) m.col[j] = f->out_col[j];
     m.col[d] = d;
     HIP_OK(nis_launch_scatter_rows(gxj, (long)N, d + 1, m, g, (long)N, tgrid, s));
   }
-  size_t bn_total = nis_flow_bnsave_count(f);
+  const size_t bn_total = nis_flow_bnsave_count(f);
   size_t bn_off = bn_total;
   for (int ci = f->n_cells - 1; ci >= 0; --ci) {
     const nis_cell_desc& cd = f->cells[ci];
@@ -1039,8 +1061,9 @@ static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld
       mw.wm_last = wm_last;
       mw.bias_pad = bias_pad;
     }
-    int rc = nis_bwd_cell_run(c, L.WM, planes_hist + (size_t)ci * set, planes_hist + (size_t)(ci + 1) * set, g, bnsave + bn_off,
-                              (long)ld, (long)N, cellws, gparams[ci], mw, seed.eval_bn, s);
+    int rc = nis_bwd_cell_run(c, cd, L.WM, planes_hist + (size_t)ci * set, planes_hist + (size_t)(ci + 1) * set, g, bnsave + bn_off,
+                              (long)ld, (long)N, G, hist_gs, set, seed.eval_bn ? 0L : (long)bn_total, cellws, gparams[ci], gtmp, mw,
+                              seed.eval_bn, s);
     if (rc != NIS_OK) return rc;
   }
   if (gx_out) {
@@ -1059,7 +1082,7 @@ extern "C" int nis_flow_backward_eval(nis_flow* f, const double* planes_hist, in
   BwdSeed seed;
   seed.gxj = gxj;
   seed.eval_bn = true;
-  return flow_backward_impl(f, planes_hist, ld, N, w_has_jac, params, bnsave, seed, gparams, gx_out, workspace, workspace_bytes, stream);
+  return flow_backward_impl(f, planes_hist, ld, 1, N, w_has_jac, params, bnsave, seed, gparams, gx_out, workspace, workspace_bytes, stream);
 }
 
 extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
@@ -1068,7 +1091,7 @@ extern "C" int nis_flow_backward(nis_flow* f, const double* planes_hist, int64_t
   if (!gxj) return NIS_E_ARG;
   BwdSeed seed;
   seed.gxj = gxj;
-  return flow_backward_impl(f, planes_hist, ld, N, w_has_jac, params, bnsave, seed, gparams, gx_out, workspace, workspace_bytes, stream);
+  return flow_backward_impl(f, planes_hist, ld, 1, N, w_has_jac, params, bnsave, seed, gparams, gx_out, workspace, workspace_bytes, stream);
 }
 
 extern "C" int nis_flow_backward_loss(nis_flow* f, const double* planes_hist, int64_t ld, int64_t N, int32_t w_has_jac,
@@ -1082,5 +1105,41 @@ extern "C" int nis_flow_backward_loss(nis_flow* f, const double* planes_hist, in
   seed.rec12 = rec12;
   seed.gloss = gloss_dev;
   seed.est = est;
-  return flow_backward_impl(f, planes_hist, ld, N, w_has_jac, params, bnsave, seed, gparams, nullptr, workspace, workspace_bytes, stream);
+  return flow_backward_impl(f, planes_hist, ld, 1, N, w_has_jac, params, bnsave, seed, gparams, nullptr, workspace, workspace_bytes, stream);
+}
+
+// ---- G minibatches of one optimizer step per call (manager.py:219-270: the loss is their mean and backward runs once): the
+//      minibatches are blockIdx.y of every launch, each with its own train-mode BatchNorm statistics.
+//      planes_hist (G, n_cells + 1, d + 1, ld), bnsave (G, nis_flow_bnsave_count) (eval mode: one record), xj_out (G, N, d + 1) optional.
+extern "C" int nis_flow_forward_hist_batched(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_batches, int64_t N,
+                                             const double* const* params, double* const* running, long long* const* tracked,
+                                             int32_t bn_mode, int64_t pack_token, double* planes_hist, int64_t ld, double* bnsave,
+                                             double* xj_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!planes_hist || !bnsave || n_batches < 1) return NIS_E_ARG;
+  RunOpts o;
+  o.G = n_batches;
+  o.bn_mode = bn_mode;
+  o.pack_token = pack_token;
+  o.tracked = tracked;
+  o.xj_out = xj_out;
+  o.hist = 1;
+  o.bnsave = bnsave;
+  return flow_run(f, w, w_dtype, N, params, running, planes_hist, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
+}
+
+// fvals (G, N), rec12 (G, 12) of nis_loss_terms_batched; gloss_dev: device scalar applied to every minibatch's loss (1 / n_minibatches);
+// gparams[c] = sum over the minibatches of gloss * d loss_g / d(parameter blob of cell c).
+extern "C" int nis_flow_backward_loss_batched(nis_flow* f, const double* planes_hist, int64_t ld, int32_t n_batches, int64_t N,
+                                              const double* const* params, const double* bnsave, int32_t bn_mode, const double* fvals,
+                                              const double* maxf_dev, const double* rec12, const double* gloss_dev, int32_t est,
+                                              double* const* gparams, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!fvals || !maxf_dev || !rec12 || !gloss_dev) return NIS_E_ARG;
+  BwdSeed seed;
+  seed.fv = fvals;
+  seed.maxf = maxf_dev;
+  seed.rec12 = rec12;
+  seed.gloss = gloss_dev;
+  seed.est = est;
+  seed.eval_bn = bn_mode == NIS_BN_EVAL;
+  return flow_backward_impl(f, planes_hist, ld, n_batches, N, 0, params, bnsave, seed, gparams, nullptr, workspace, workspace_bytes, stream);
 }

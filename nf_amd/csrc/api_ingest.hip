@@ -252,9 +252,11 @@ __global__ __launch_bounds__(NIS_TPB) void k_scatter_rows(const double* __restri
 }
 
 __global__ __launch_bounds__(NIS_TPB) void k_emit(const double* __restrict__ planes, long ld, long N, int d, ColMap m,
-                                                  double* __restrict__ xj) {
+                                                  double* __restrict__ xj, long plane_gs) {
   extern __shared__ double tile[];
   const int dd = d + 1;
+  planes += (size_t)blockIdx.y * plane_gs;          // batch g of a launch set: own plane set, own (N, d+1) block of rows
+  xj += (size_t)blockIdx.y * N * dd;
   const long nblk = (N + NIS_TPB - 1) / NIS_TPB;
   for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const long i0 = blk * NIS_TPB;
@@ -449,8 +451,9 @@ hipError_t nis_launch_scatter_rows(const double* src, long N, int cols, const Co
   return hipGetLastError();
 }
 
-hipError_t nis_launch_emit(const double* planes, long ld, long N, int d, const ColMap& m, double* xj, int grid, hipStream_t s) {
+hipError_t nis_launch_emit(const double* planes, long ld, long N, int d, const ColMap& m, double* xj, int grid, hipStream_t s, int G,
+                           long plane_gs) {
   const size_t tile_bytes = ((size_t)NIS_TPB * (d + 1) + 16) * sizeof(double);
-  hipLaunchKernelGGL(k_emit, dim3(grid), dim3(NIS_TPB), tile_bytes, s, planes, ld, N, d, m, xj);
+  hipLaunchKernelGGL(k_emit, dim3(grid, G), dim3(NIS_TPB), tile_bytes, s, planes, ld, N, d, m, xj, plane_gs);
   return hipGetLastError();
 }

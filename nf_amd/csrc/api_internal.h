@@ -96,7 +96,8 @@ hipError_t nis_launch_ingest_rng(unsigned long long seed, unsigned long long str
 hipError_t nis_launch_philox_rows(unsigned long long seed, unsigned long long stream0, int G, long N, int d, float* out, hipStream_t s);
 hipError_t nis_launch_sync_reduce(const double* part, int nparts, int WM, double* out, hipStream_t s);
 hipError_t nis_launch_scatter_rows(const double* src, long N, int cols, const ColMap& m, double* planes, long ld, int grid, hipStream_t s);
-hipError_t nis_launch_emit(const double* planes, long ld, long N, int d, const ColMap& m, double* xj, int grid, hipStream_t s);
+hipError_t nis_launch_emit(const double* planes, long ld, long N, int d, const ColMap& m, double* xj, int grid, hipStream_t s, int G = 1,
+                           long plane_gs = 0);
 
 // ---- api_moments.hip
 // Batched iterations (G > 1): ONE launch at the end of the launch set applies the G momentum-0.1 running-statistics
@@ -125,4 +126,5 @@ hipError_t nis_launch_group_epilogue(const EpiJob& job, int blocks, hipStream_t 
 hipError_t nis_launch_moments_final(const double* partials, int nparts, double* out4, int maxb, int G, hipStream_t s);
 // first launch of nis_flow_backward_loss: dL/dJ of the minibatch loss -> gradient planes (rec12 = nis_loss_terms' records)
 hipError_t nis_launch_loss_cotangent(const double* fv, const double* jac, long jstride, long N, const double* maxf, const double* rec12,
-                                     const double* gloss, int est, int d, double* g, long ld, hipStream_t s);
+                                     const double* gloss, int est, int d, double* g, long ld, hipStream_t s, int G = 1, long jac_gs = 0,
+                                     long g_gs = 0);

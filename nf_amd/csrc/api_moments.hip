@@ -297,21 +297,27 @@ hipError_t nis_launch_moments_final(const double* partials, int nparts, double* 
 // built-in integrand on the rows of X itself (fv_out keeps the values for the cotangent); k_loss_cotangent (api.hip: first launch
 // of nis_flow_backward_loss) turns the final records into dL/dJ_i, written straight to the adjoint's gradient planes.
 struct LossSrc {
-  const double* fv_in;      // given integrand values (arbitrary callable), or null:
-  const double* xrows;      //   rows the built-in integrand `ia` is evaluated on (X of the model output, or w during the preburn)
-  long xstride;
-  double* fv_out;           // receives the evaluated values (needed again by the cotangent)
-  const double* jac;        // J_i at jac[i * jstride]
-  long jstride;
+  const double* fv_in;      // given integrand values (G, N) (arbitrary callable), or null:
+  const double* xbase;      //   element (column c, sample i) of minibatch g at xbase[g * x_gs + out_col[c] * xcs + i * xss]: the rows of X
+  long xcs, xss, x_gs;      //   (or of w during the preburn) or the column planes of the model output, for the built-in integrand `ia`
+  double* fv_out;           // (G, N) receives the evaluated values (needed again by the cotangent)
+  const double* jac;        // J_i of minibatch g at jac[g * jac_gs + i * jstride]
+  long jstride, jac_gs;
   const double* maxf;       // device scalar
   int preburn;
 };
+// grid (records per minibatch, G).  Record of workgroup b, minibatch g: partials[((g * gridDim.x + b) * 3 + q) * 4 ...], q = a | u | u^2
 __global__ __launch_bounds__(NIS_TPB) void k_loss_terms(LossSrc src, IntegrandArgs ia, long N, double* __restrict__ partials) {
   __shared__ double wm[3][NIS_TPB / NIS_WAVE][4];
   double S1[3] = {0, 0, 0}, S2[3] = {0, 0, 0}, sh[3] = {0, 0, 0}, mx[3] = {-__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
   double cnt = 0.0;
   bool first = true;
+  const int g = blockIdx.y;
   const double imax = 1.0 / src.maxf[0];
+  const double* __restrict__ fvi = src.fv_in ? src.fv_in + (size_t)g * N : nullptr;
+  double* __restrict__ fvo = src.fv_out ? src.fv_out + (size_t)g * N : nullptr;
+  const double* __restrict__ xb = src.xbase ? src.xbase + (size_t)g * src.x_gs : nullptr;
+  const double* __restrict__ jac = src.jac + (size_t)g * src.jac_gs;
   const long stride = (long)gridDim.x * NIS_TPB;
   const long nit = (N + stride - 1) / stride;
   for (long it = 0; it < nit; ++it) {
@@ -320,13 +326,13 @@ __global__ __launch_bounds__(NIS_TPB) void k_loss_terms(LossSrc src, IntegrandAr
     double v[3] = {0.0, 0.0, 0.0};
     if (valid) {
       double fv;
-      if (src.fv_in) {
-        fv = src.fv_in[i];
+      if (fvi) {
+        fv = fvi[i];
       } else {
-        fv = eval_integrand_at(ia, src.xrows, 1, src.xstride, i);
-        src.fv_out[i] = fv;
+        fv = eval_integrand_at(ia, xb, src.xcs, src.xss, i);
+        fvo[i] = fv;
       }
-      const double fj = fv * src.jac[i * src.jstride];
+      const double fj = fv * jac[i * src.jstride];
       v[0] = src.preburn ? fv : fj;
       v[1] = fj * imax;
       v[2] = v[1] * v[1];
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_loss_terms(LossSrc src, IntegrandAr
       t = mom_merge(t, r);
       m = fmax(m, wm[q][w][3]);
     }
-    double* part = partials + ((size_t)blockIdx.x * 3 + q) * 4;
+    double* part = partials + (((size_t)g * gridDim.x + blockIdx.x) * 3 + q) * 4;
     part[0] = t.n;
     part[1] = t.mean;
     part[2] = t.m2;
@@ -377,43 +383,40 @@ __global__ __launch_bounds__(NIS_TPB) void k_loss_terms(LossSrc src, IntegrandAr
   }
 }
 
-// one workgroup: three fixed-order merges -> rec (3 x 4: a | u | u^2), then the scalars the host loop adds up:
-//   out[0] = mean(a), out[1] = var(a) (unbiased), out[2] = loss, out[3] = var(u^2) (unbiased), out[4] = n, out[5] = mean(u)
+// one workgroup per minibatch (blockIdx.x = g), wave q merges series q: every lane folds its share of the records as sums about
+// record 0's mean (no divisions; the records' means differ by ~sigma / sqrt(n)), then a wave reduction -- fixed order.
+//   rec (G, 12) = 3 x {n, mean, M2, max} (a | u | u^2), then the scalars the host loop adds up:
+//   out (G, 8): out[0] = mean(a), out[1] = var(a) (unbiased), out[2] = loss, out[3] = var(u^2) (unbiased), out[4] = n, out[5] = mean(u)
 __global__ __launch_bounds__(NIS_TPB) void k_loss_final(const double* __restrict__ partials, int nparts, const double* __restrict__ maxf, int est,
                                                         double* __restrict__ rec, double* __restrict__ out) {
-  __shared__ double sm[NIS_TPB][4];
-  for (int q = 0; q < 3; ++q) {
-    Mom t = {0.0, 0.0, 0.0};
-    double m = -__builtin_huge_val();
-    for (int b = threadIdx.x; b < nparts; b += NIS_TPB) {
+  const int g = blockIdx.x;
+  partials += (size_t)g * nparts * 12;
+  rec += (size_t)g * 12;
+  out += (size_t)g * 8;
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  if (q < 3) {
+    const double ref = partials[(size_t)q * 4 + 1];
+    double an = 0.0, a1 = 0.0, a2 = 0.0, m = -__builtin_huge_val();
+    for (int b = lane; b < nparts; b += 64) {
       const double* p = partials + ((size_t)b * 3 + q) * 4;
-      Mom r = {p[0], p[1], p[2]};
-      t = mom_merge(t, r);
+      const double n = p[0], dl = p[1] - ref;
+      an += n;
+      a1 = fma(n, dl, a1);
+      a2 += fma(n * dl, dl, p[2]);
       m = fmax(m, p[3]);
     }
-    sm[threadIdx.x][0] = t.n;
-    sm[threadIdx.x][1] = t.mean;
-    sm[threadIdx.x][2] = t.m2;
-    sm[threadIdx.x][3] = m;
-    __syncthreads();
-    for (int s = NIS_TPB / 2; s > 0; s >>= 1) {
-      if (threadIdx.x < s) {
-        Mom a = {sm[threadIdx.x][0], sm[threadIdx.x][1], sm[threadIdx.x][2]};
-        Mom b = {sm[threadIdx.x + s][0], sm[threadIdx.x + s][1], sm[threadIdx.x + s][2]};
-        a = mom_merge(a, b);
-        sm[threadIdx.x][0] = a.n;
-        sm[threadIdx.x][1] = a.mean;
-        sm[threadIdx.x][2] = a.m2;
-        sm[threadIdx.x][3] = fmax(sm[threadIdx.x][3], sm[threadIdx.x + s][3]);
-      }
-      __syncthreads();
+    an = wave_sum(an);
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    m = wave_max(m);
+    if (lane == 0) {
+      rec[q * 4 + 0] = an;
+      rec[q * 4 + 1] = ref + a1 / an;
+      rec[q * 4 + 2] = fmax(a2 - a1 * a1 / an, 0.0);
+      rec[q * 4 + 3] = m;
     }
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) rec[q * 4 + c] = sm[0][c];
-    }
-    __syncthreads();
   }
+  __syncthreads();
   if (threadIdx.x == 0) {
     const double n = rec[0];
     out[0] = rec[1];
@@ -422,53 +425,83 @@ __global__ __launch_bounds__(NIS_TPB) void k_loss_final(const double* __restrict
     out[3] = rec[10] / (n - 1.0);
     out[4] = n;
     out[5] = rec[5];
+    out[6] = out[7] = 0.0;
   }
 }
 
+static int loss_grid(int G, int64_t N) { return std::min(nis_stream_grid(N), std::max(1, 2 * nis_device_cus() / G)); }
+extern "C" size_t nis_loss_workspace_bytes_batched(int32_t n_batches, int64_t N) {
+  if (n_batches < 1 || N < 1) return 0;
+  return (size_t)n_batches * loss_grid(n_batches, N) * 12 * sizeof(double);
+}
 extern "C" size_t nis_loss_workspace_bytes(void) { return (size_t)NIS_MAXB * 12 * sizeof(double); }
 
-extern "C" int nis_loss_terms(const double* fv_in, const double* xrows, int64_t xstride, int32_t d, int32_t f_kind, const double* f_params_host,
-                              double* fv_out, const double* jac, int64_t jstride, int64_t N, const double* maxf_dev, int32_t preburn,
-                              int32_t est, double* rec12, double* out8, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!jac || !maxf_dev || !rec12 || !out8 || N < 1 || jstride < 1) return NIS_E_ARG;
-  if (!fv_in && (!xrows || !fv_out || d < 1 || d > NIS_MAX_DIM || xstride < d)) return NIS_E_ARG;
+// G minibatches per call: fv_in / fv_out (G, N), rec12 (G, 12), out8 (G, 8).  Built-in integrand (fv_in == null): element
+// (column c, sample i) of minibatch g is read at xbase[g * x_batch_stride + x_cols[c] * x_col_stride + i * x_row_stride] -- the
+// rows of a (G, N, d) matrix (col stride 1, row stride d) or the column planes of the model output (col stride ld, row stride 1,
+// x_cols = the model's output column map; null: identity).
+extern "C" int nis_loss_terms_batched(const double* fv_in, const double* xbase, int64_t x_col_stride, int64_t x_row_stride,
+                                      int64_t x_batch_stride, const int32_t* x_cols_host, int32_t d, int32_t f_kind,
+                                      const double* f_params_host, double* fv_out, const double* jac, int64_t jstride, int64_t jac_batch_stride,
+                                      int32_t n_batches, int64_t N, const double* maxf_dev, int32_t preburn, int32_t est, double* rec12,
+                                      double* out8, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!jac || !maxf_dev || !rec12 || !out8 || N < 1 || jstride < 1 || n_batches < 1 || n_batches > 65535) return NIS_E_ARG;
+  if (!fv_in && (!xbase || !fv_out || d < 1 || d > NIS_MAX_DIM)) return NIS_E_ARG;
   if (!fv_in && f_kind != NIS_F_CAMEL && f_kind != NIS_F_NORMAL && f_kind != NIS_F_ONE) return NIS_E_ARG;
   if (!fv_in && f_kind == NIS_F_CAMEL && d < 2) return NIS_E_ARG;
-  if (!workspace || workspace_bytes < nis_loss_workspace_bytes()) return NIS_E_WORKSPACE;
+  if (!workspace || workspace_bytes < nis_loss_workspace_bytes_batched(n_batches, N)) return NIS_E_WORKSPACE;
   LossSrc src;
   memset(&src, 0, sizeof(src));
   src.fv_in = fv_in;
-  src.xrows = xrows;
-  src.xstride = (long)xstride;
+  src.xbase = xbase;
+  src.xcs = (long)x_col_stride;
+  src.xss = (long)x_row_stride;
+  src.x_gs = (long)x_batch_stride;
   src.fv_out = fv_out;
   src.jac = jac;
   src.jstride = (long)jstride;
+  src.jac_gs = (long)jac_batch_stride;
   src.maxf = maxf_dev;
   src.preburn = preburn;
   IntegrandArgs a;
   memset(&a, 0, sizeof(a));
-  for (int c = 0; c < d && c < NIS_MAX_DIM; ++c) a.out_col[c] = c;
+  for (int c = 0; c < d && c < NIS_MAX_DIM; ++c) a.out_col[c] = x_cols_host ? x_cols_host[c] : c;
   a.d = d;
   a.kind = f_kind;
   for (int k = 0; k < 4; ++k) a.p[k] = f_params_host ? f_params_host[k] : 0.0;
   hipStream_t s = (hipStream_t)stream;
-  // two workgroups per CU: the pass streams 16-24 B per sample, and every record costs the one-workgroup merge three Chan updates
-  const int grid = std::min(nis_stream_grid(N), 2 * nis_device_cus());
+  // two workgroups per CU over all minibatches: the pass streams 16-24 B per sample, and every record costs the merge three updates
+  const int grid = loss_grid(n_batches, N);
   {
     NisProfScope ps(NIS_K_MOMENTS, s);
-    hipLaunchKernelGGL(k_loss_terms, dim3(grid), dim3(NIS_TPB), 0, s, src, a, (long)N, (double*)workspace);
+    hipLaunchKernelGGL(k_loss_terms, dim3(grid, n_batches), dim3(NIS_TPB), 0, s, src, a, (long)N, (double*)workspace);
   }
   HIP_OK(hipGetLastError());
-  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(NIS_TPB), 0, s, (const double*)workspace, grid, maxf_dev, est, rec12, out8);
+  hipLaunchKernelGGL(k_loss_final, dim3(n_batches), dim3(NIS_TPB), 0, s, (const double*)workspace, grid, maxf_dev, est, rec12, out8);
   HIP_OK(hipGetLastError());
   return NIS_OK;
 }
 
-// dL/dJ_i of the variance ("var") or second-moment ("est") loss of a minibatch, times the upstream cotangent gloss (device
-// scalar), into gradient plane d; the d coordinate planes get zeros (f is evaluated on the detached X, manager.py:244).
+extern "C" int nis_loss_terms(const double* fv_in, const double* xrows, int64_t xstride, int32_t d, int32_t f_kind, const double* f_params_host,
+                              double* fv_out, const double* jac, int64_t jstride, int64_t N, const double* maxf_dev, int32_t preburn,
+                              int32_t est, double* rec12, double* out8, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!fv_in && xstride < d) return NIS_E_ARG;
+  return nis_loss_terms_batched(fv_in, xrows, 1, xstride, 0, nullptr, d, f_kind, f_params_host, fv_out, jac, jstride, 0, 1, N, maxf_dev, preburn,
+                                est, rec12, out8, workspace, workspace_bytes, stream);
+}
+
+// dL/dJ_i of the variance ("var") or second-moment ("est") loss of minibatch g = blockIdx.y, times the upstream cotangent gloss
+// (device scalar), into gradient plane d of that minibatch; the d coordinate planes get zeros (f is evaluated on the detached X,
+// manager.py:244).  fv (G, N), rec (G, 12), jac at jac[g * jac_gs + i * jstride], gradient planes at g[g * g_gs + ...].
 __global__ __launch_bounds__(NIS_TPB) void k_loss_cotangent(const double* __restrict__ fv, const double* __restrict__ jac, long jstride, long N,
                                                             const double* __restrict__ maxf, const double* __restrict__ rec,
-                                                            const double* __restrict__ gloss, int est, int d, double* __restrict__ g, long ld) {
+                                                            const double* __restrict__ gloss, int est, int d, double* __restrict__ g, long ld,
+                                                            long jac_gs, long g_gs) {
+  const int gi = blockIdx.y;
+  fv += (size_t)gi * N;
+  jac += (size_t)gi * jac_gs;
+  rec += (size_t)gi * 12;
+  g += (size_t)gi * g_gs;
   const double imax = 1.0 / maxf[0], n = rec[4], mean_u = rec[5], gl = gloss[0];
   const double cvar = 2.0 / (n - 1.0) * gl, cest = 2.0 / n * gl;
   const long stride = (long)gridDim.x * NIS_TPB;
@@ -481,7 +514,8 @@ __global__ __launch_bounds__(NIS_TPB) void k_loss_cotangent(const double* __rest
 }
 
 hipError_t nis_launch_loss_cotangent(const double* fv, const double* jac, long jstride, long N, const double* maxf, const double* rec12,
-                                     const double* gloss, int est, int d, double* g, long ld, hipStream_t s) {
-  hipLaunchKernelGGL(k_loss_cotangent, dim3(nis_grid_for(8, 1, N, NIS_TPB)), dim3(NIS_TPB), 0, s, fv, jac, jstride, N, maxf, rec12, gloss, est, d, g, ld);
+                                     const double* gloss, int est, int d, double* g, long ld, hipStream_t s, int G, long jac_gs, long g_gs) {
+  hipLaunchKernelGGL(k_loss_cotangent, dim3(nis_grid_for(8, G, N, NIS_TPB), G), dim3(NIS_TPB), 0, s, fv, jac, jstride, N, maxf, rec12, gloss,
+                     est, d, g, ld, jac_gs, g_gs);
   return hipGetLastError();
 }

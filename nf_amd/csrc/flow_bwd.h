@@ -23,6 +23,14 @@ struct BwdK {
   long ldw;                   // leading dimension of the workspace planes dyp / alp / dzp (wide adjoint: multiple of 16)
   double invN;                // 1 / N with train-mode BatchNorm; 0 in eval mode: dx = scale dy, the batch-mean terms of the
                               //   train-mode backward (mean(dy), xhat mean(dy xhat)) vanish, d gamma / d beta keep their sums
+  // ---- batched minibatches (narrow adjoint, flow_bwd.hip): blockIdx.y = g selects one of G independent minibatches
+  int G;
+  long x_gs;                  // doubles between the history plane sets (x, xo) of consecutive minibatches
+  long g_gs;                  // ... between their gradient plane sets
+  long wsp_gs;                // ... between their workspace planes (dyp / alp / dzp)
+  long bn_gs;                 // ... between their saved BatchNorm records (0 in eval mode: running statistics, one record)
+  const double* prev;         // records of the launch that produced dy of the layer being processed: (G, nprev, BNACC); the consumer
+  int nprev, prev_off;        //   merges the 2 WM batch sums at prev_off in its prologue (no reduction launch in between)
 };
 
 // ---- wide conditioners (register width 16 / 32 / 64), one translation unit per width

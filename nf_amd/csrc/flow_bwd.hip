@@ -1,25 +1,33 @@
 // Hand-written adjoint (backward) of a coupling cell with a narrow conditioner (register width WM = 4 or 8, any
-// number of transformed columns, PWQuad n_bins <= 32, PWLin any n_bins, AffineCoupling), train-mode BatchNorm.  Wider conditioners
-// (WM = 16 / 32 / 64) run the same chain on the f64 matrix cores: flow_bwd_wm.hip.
+// number of transformed columns, PWQuad n_bins <= 32, PWLin any n_bins, AffineCoupling), train- or eval-mode BatchNorm.  Wider
+// conditioners (WM = 16 / 32 / 64) run the same chain on the f64 matrix cores: flow_bwd_wm.hip.
 //
 // Reverse of:  BN_0 -> Lin_0 -> [BN_l -> ReLU -> Lin_l]_{l=1..L} -> exp / normalise -> quadratic (linear) CDF, J *= dy/dx
 // (reference forward: normalizing_flows/layers/coupling_cells.py:107-142, :159-228, :236-254; the reference obtains these
 // gradients from torch.autograd at manager.py:275-278).
 //
-// Train-mode BatchNorm couples all samples, so the adjoint is again a chain of launches, one per BN layer, in reverse:
-//   head    : recompute the cell; per transformed column the bijector adjoint -> dZ rows (stored as planes) -> d a_L;
-//             dy_L (grad at BN_L's output) + the two batch sums BN_L's backward needs
-//   wlast   : dW_L = dZ^T a_L, db_L = sum dZ  (rows in chunks of 8: a tall-skinny reduction over the samples)
+// Train-mode BatchNorm couples all samples of a minibatch, so the adjoint is again a chain of launches, one per BN layer, in reverse:
+//   head    : recompute the cell; per transformed column the bijector adjoint -> dZ -> d a_L; dy_L (grad at BN_L's output) +
+//             the two batch sums BN_L's backward needs.  d = 2 class (PWQuad, 4 bins, one transformed column): dW_L = dZ^T a_L and
+//             db_L accumulate in registers of the same launch (FUSEW); otherwise dZ / a_L go to planes and k_bwd_wlast reduces them
 //   layer l : dh_l = scale_l (dy_l - mean(dy_l) - xhat_l mean(dy_l xhat_l)) -> dW_{l-1}, dy_{l-1}, sums of BN_{l-1}
 //   input   : BN_0 backward -> gradient of the pass-through columns
-// Per-thread partial sums (registers) -> per-workgroup records -> k_bwd_reduce (fixed order: bitwise reproducible).
+//   finish  : every record of the chain -> the gradient blob in the reference's parameter order (one launch per cell)
+// The G minibatches of an optimizer step (manager.py:219-270: the loss is their mean, ONE backward) are blockIdx.y of every
+// launch: own history planes, own BatchNorm records, own batch sums; the parameter gradient is the sum over all of them.
+// A consumer merges the batch sums of its producer's per-workgroup records in its prologue (fixed order: bitwise reproducible),
+// so no reduction launch sits between the links of the chain.
 #include <algorithm>
 #include <cstring>
 
 #include "flow_bwd.h"
 
+int nis_grid_for(int blocks_per_cu, int G, int64_t N, int tpb);      // api.hip
+int nis_env_int(const char* name, int dflt);
+
+// per-thread accumulators -> slots [0, NACC) of this workgroup's record
 template <int NACC>
-__device__ __forceinline__ void bw_block_reduce(const double (&acc)[NACC], double* part) {
+__device__ __forceinline__ void bw_block_reduce(const double (&acc)[NACC], double* rec) {
   __shared__ double sm[NIS_TPB / 64][NACC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -31,107 +39,123 @@ __device__ __forceinline__ void bw_block_reduce(const double (&acc)[NACC], doubl
   if ((int)threadIdx.x < NACC) {
     double t = 0.0;
     for (int w = 0; w < NIS_TPB / 64; ++w) t += sm[w][threadIdx.x];
-    part[(size_t)blockIdx.x * BNACC + threadIdx.x] = t;
+    rec[threadIdx.x] = t;
   }
+  __syncthreads();
 }
 
-// records -> one summed record per y-slice: a workgroup owns 4 elements and sums 64 interleaved slices of the records,
-// then an LDS tree -- fixed order (bitwise reproducible).  grid: (ceil(nacc / 4), y-slices).
-__global__ __launch_bounds__(NIS_TPB) void k_bwd_reduce(const double* __restrict__ part, int nparts, int nacc, double* __restrict__ out,
-                                                        long part_ystride) {
-  __shared__ double sm[64][4];
-  const int el = threadIdx.x & 3, slice = threadIdx.x >> 2;
-  const int e = blockIdx.x * 4 + el;
-  part += (size_t)blockIdx.y * part_ystride;
-  out += (size_t)blockIdx.y * BNACC;
-  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-  if (e < nacc) {
-    int b = slice;
-    for (; b + 192 < nparts; b += 256) {
-      t0 += part[(size_t)b * BNACC + e];
-      t1 += part[(size_t)(b + 64) * BNACC + e];
-      t2 += part[(size_t)(b + 128) * BNACC + e];
-      t3 += part[(size_t)(b + 192) * BNACC + e];
+// Prologue of every chain kernel: this minibatch's saved BatchNorm records -> LDS (lbn: (L+1) x 4 x WM  scale | shift | mean | rstd),
+// and the producer's batch sums (2 WM values at k.prev_off of its records) merged in a fixed order -> lsum = sums / N.
+template <int WM>
+__device__ __forceinline__ void bw_prologue(const BwdK& k, int g, double* lbn, double* lsum) {
+  __shared__ double red[NIS_TPB];
+  const int nb = (k.c.L + 1) * 4 * WM;
+  const double* bn = k.bn + (size_t)g * k.bn_gs;
+  for (int i = threadIdx.x; i < nb; i += NIS_TPB) lbn[i] = bn[i];
+  if (k.prev) {
+    constexpr int NV = 2 * WM, S = NIS_TPB / NV;
+    const int j = threadIdx.x % NV, sl = threadIdx.x / NV;
+    const double* p = k.prev + (size_t)g * k.nprev * BNACC + k.prev_off + j;
+    double t0 = 0.0, t1 = 0.0;
+    int b = sl;
+    for (; b + S < k.nprev; b += 2 * S) {
+      t0 += p[(size_t)b * BNACC];
+      t1 += p[(size_t)(b + S) * BNACC];
     }
-    for (; b < nparts; b += 64) t0 += part[(size_t)b * BNACC + e];
-  }
-  sm[slice][el] = (t0 + t1) + (t2 + t3);
-  __syncthreads();
-  for (int h = 32; h > 0; h >>= 1) {
-    if (slice < h) sm[slice][el] += sm[slice + h][el];
+    if (b < k.nprev) t0 += p[(size_t)b * BNACC];
+    red[sl * NV + j] = t0 + t1;
     __syncthreads();
+#pragma unroll
+    for (int h = S / 2; h > 0; h >>= 1) {
+      if (sl < h) red[sl * NV + j] += red[(sl + h) * NV + j];
+      __syncthreads();
+    }
+    if (sl == 0) lsum[j] = red[j] * k.invN;
   }
-  if (slice == 0 && e < nacc) out[e] = sm[0][el];
+  __syncthreads();
 }
 
 // forward recompute of the hidden stack with the SAVED statistics; returns for layer `upto` (1..L):
 //   h[]   pre-BN activations of BN_upto        a_in[] input of Linear_{upto-1} (post-ReLU of BN_{upto-1}; BN_0 output if upto == 1)
 //   o_in[] BN_{upto-1} output before ReLU      xh_in[] normalised input of BN_{upto-1}
-template <int WM>
-__device__ __forceinline__ void bw_forward(const BwdK& k, long i, int upto, double (&h)[WM], double (&a_in)[WM], double (&o_in)[WM],
-                                           double (&xh_in)[WM]) {
+template <int WM, int WX>
+__device__ __forceinline__ void bw_forward(const BwdK& k, const double* __restrict__ x, const double* lbn, long i, int upto, double (&h)[WM],
+                                           double (&a_in)[WM], double (&o_in)[WM], double (&xh_in)[WM]) {
   nis_cptr wp = as_const(k.c.wp);
-  nis_cptr bn = as_const(k.bn);
   double cur[WM];
 #pragma unroll
-  for (int p = 0; p < WM; ++p) cur[p] = (p < k.c.P) ? k.x[(size_t)k.c.in_plane[p] * k.ld + i] : 0.0;
+  for (int p = 0; p < WM; ++p) cur[p] = (p < k.c.P) ? x[(size_t)k.c.in_plane[p] * k.ld + i] : 0.0;
   for (int l = 0; l < upto; ++l) {
 #pragma unroll
     for (int j = 0; j < WM; ++j) {
-      xh_in[j] = (cur[j] - bn[(l * 4 + 2) * WM + j]) * bn[(l * 4 + 3) * WM + j];
-      o_in[j] = fma(cur[j], bn[(l * 4 + 0) * WM + j], bn[(l * 4 + 1) * WM + j]);
+      xh_in[j] = (cur[j] - lbn[(l * 4 + 2) * WM + j]) * lbn[(l * 4 + 3) * WM + j];
+      o_in[j] = fma(cur[j], lbn[(l * 4 + 0) * WM + j], lbn[(l * 4 + 1) * WM + j]);
       a_in[j] = (l == 0) ? o_in[j] : fmax(o_in[j], 0.0);
     }
-    dense<WM>(wp + (size_t)l * WM * WM, a_in, cur);
+    dense<WM, WX>(wp + (size_t)l * WM * WM, a_in, cur);
   }
 #pragma unroll
   for (int j = 0; j < WM; ++j) h[j] = cur[j];
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int KIND, int WM, int KM>
+// WX: exact common width of the hidden layers (3 for the README / C1 / C2 nets), else WM.  FUSEW (PWQuad, K == KM, T == 1): the
+// last Linear's weight / bias gradients accumulate here, record slots [2 WM + r (WM + 1) + q], nothing but dy goes to planes.
+template <int KIND, int WM, int KM, int WX, bool FUSEW>
 __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
   __shared__ double etab[NIS_EXP_N];
+  __shared__ double lbn[(NIS_MAX_HIDDEN + 1) * 4 * WM];
+  __shared__ double lsum[2 * WM];
+  const int g = blockIdx.y;
   nis_exp_init(etab);
-  __syncthreads();
+  bw_prologue<WM>(k, g, lbn, lsum);
   const CellK& c = k.c;
   nis_cptr wl = as_const(c.wlast);
   nis_cptr bias = as_const(c.bias);
-  nis_cptr bn = as_const(k.bn);
-  const int L = c.L, K = c.K;
+  const int L = c.L, K = FUSEW ? KM : c.K;
+  const double* __restrict__ x = k.x + (size_t)g * k.x_gs;
+  const double* __restrict__ xo = k.xo + (size_t)g * k.x_gs;
+  double* __restrict__ gp = k.g + (size_t)g * k.g_gs;
+  double* __restrict__ dyp = k.dyp + (size_t)g * k.wsp_gs;
+  double* __restrict__ alp = k.alp + (size_t)g * k.wsp_gs;
+  double* __restrict__ dzp = k.dzp + (size_t)g * k.wsp_gs;
   double acc[2 * WM];
 #pragma unroll
   for (int a = 0; a < 2 * WM; ++a) acc[a] = 0.0;
+  constexpr int NW = FUSEW ? (2 * KM + 1) * (WM + 1) : 1;
+  double accw[NW];
+#pragma unroll
+  for (int a = 0; a < NW; ++a) accw[a] = 0.0;
   const long stride = (long)gridDim.x * NIS_TPB;
   for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < k.N; i += stride) {
     double h[WM], a_in[WM], o_in[WM], xh_in[WM];
-    bw_forward<WM>(k, i, L, h, a_in, o_in, xh_in);
+    bw_forward<WM, WX>(k, x, lbn, i, L, h, a_in, o_in, xh_in);
     double aL[WM], oL[WM], xhL[WM], da[WM];
 #pragma unroll
     for (int j = 0; j < WM; ++j) {
-      xhL[j] = (h[j] - bn[(L * 4 + 2) * WM + j]) * bn[(L * 4 + 3) * WM + j];
-      oL[j] = fma(h[j], bn[(L * 4 + 0) * WM + j], bn[(L * 4 + 1) * WM + j]);
+      xhL[j] = (h[j] - lbn[(L * 4 + 2) * WM + j]) * lbn[(L * 4 + 3) * WM + j];
+      oL[j] = fma(h[j], lbn[(L * 4 + 0) * WM + j], lbn[(L * 4 + 1) * WM + j]);
       aL[j] = fmax(oL[j], 0.0);
-      k.alp[(size_t)j * k.ld + i] = aL[j];
+      if (!FUSEW) alp[(size_t)j * k.ldw + i] = aL[j];
       da[j] = 0.0;
     }
-    const double gJ = k.g[(size_t)c.jplane * k.ld + i];
-    const double Jout = k.xo[(size_t)c.jplane * k.ld + i];
+    const double gJ = gp[(size_t)c.jplane * k.ld + i];
+    const double Jout = xo[(size_t)c.jplane * k.ld + i];
     double jfprod = 1.0;
     for (int t = 0; t < c.T; ++t) {
       const int colp = c.in_plane[c.P + t];
       const int row0 = t * c.out;
-      const double xraw = k.x[(size_t)colp * k.ld + i];
-      const double gy = k.g[(size_t)colp * k.ld + i];
+      const double xraw = x[(size_t)colp * k.ld + i];
+      const double gy = gp[(size_t)colp * k.ld + i];
       double gx = 0.0, jf = 1.0;
       if (KIND == NIS_PWQUAD) {
         const bool clamped = xraw > 1.0 - 1e-6;
         const double xb = clamped ? 1.0 - 1e-6 : xraw;
         double V[KM + 1], W[KM];
 #pragma unroll
-        for (int q = 0; q < KM + 1; ++q) V[q] = (q <= K) ? nis_exp(last_dot<WM>(wl, bias, row0 + q, aL), etab) : 0.0;
+        for (int q = 0; q < KM + 1; ++q) V[q] = (q <= K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + q, aL), etab) : 0.0;
 #pragma unroll
-        for (int q = 0; q < KM; ++q) W[q] = (q < K) ? nis_exp(last_dot<WM>(wl, bias, row0 + K + 1 + q, aL), etab) : 0.0;
+        for (int q = 0; q < KM; ++q) W[q] = (q < K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + K + 1 + q, aL), etab) : 0.0;
         // forward quantities exactly as k_cell_apply forms them
         double wn = 0.0;
 #pragma unroll
@@ -139,7 +163,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
           if (q < K) wn += W[q];
         int b;
         double left;
-        pwquad_bin<KM, false>(xb, K, W, wn, &b, &left);
+        pwquad_bin<KM, FUSEW>(xb, K, W, wn, &b, &left);
         const double iwn = 1.0 / wn;
         double area = 0.0;
 #pragma unroll
@@ -210,24 +234,36 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
         for (int q = 0; q < KM + 1; ++q)
           if (q <= K) {
             const double dz = V[q];
-            k.dzp[(size_t)(row0 + q) * k.ld + i] = dz;
+            if (FUSEW) {
 #pragma unroll
-            for (int j = 0; j < WM; ++j) da[j] = fma(wl[(size_t)(row0 + q) * WM + j], dz, da[j]);
+              for (int j = 0; j < WX; ++j) accw[q * (WM + 1) + j] = fma(dz, aL[j], accw[q * (WM + 1) + j]);
+              accw[q * (WM + 1) + WM] += dz;
+            } else {
+              dzp[(size_t)(row0 + q) * k.ldw + i] = dz;
+            }
+#pragma unroll
+            for (int j = 0; j < WX; ++j) da[j] = fma(wl[(size_t)(row0 + q) * WM + j], dz, da[j]);
           }
 #pragma unroll
         for (int q = 0; q < KM; ++q)
           if (q < K) {
             const double dz = W[q];
-            k.dzp[(size_t)(row0 + K + 1 + q) * k.ld + i] = dz;
+            if (FUSEW) {
 #pragma unroll
-            for (int j = 0; j < WM; ++j) da[j] = fma(wl[(size_t)(row0 + K + 1 + q) * WM + j], dz, da[j]);
+              for (int j = 0; j < WX; ++j) accw[(KM + 1 + q) * (WM + 1) + j] = fma(dz, aL[j], accw[(KM + 1 + q) * (WM + 1) + j]);
+              accw[(KM + 1 + q) * (WM + 1) + WM] += dz;
+            } else {
+              dzp[(size_t)(row0 + K + 1 + q) * k.ldw + i] = dz;
+            }
+#pragma unroll
+            for (int j = 0; j < WX; ++j) da[j] = fma(wl[(size_t)(row0 + K + 1 + q) * WM + j], dz, da[j]);
           }
       } else if (KIND == NIS_AFFINE) {
         // AffineCoupling (coupling_cells.py:56-68): rows [scale | shift][T]; u = 20 e^z0 x + relu(z1), y = atan(u) 2/pi,
         // jf = 20 e^z0 / (u^2 + 1)  (the cell-wide factor 2/pi of the Jacobian is applied once, below)
         const int rs = t, rh = c.T + t;
-        const double z1 = last_dot<WM>(wl, bias, rh, aL);
-        const double s0 = 20.0 * nis_exp(last_dot<WM>(wl, bias, rs, aL), etab);
+        const double z1 = last_dot<WM, WX>(wl, bias, rh, aL);
+        const double s0 = 20.0 * nis_exp(last_dot<WM, WX>(wl, bias, rs, aL), etab);
         const double u = xraw * s0 + (z1 > 0.0 ? z1 : 0.0);
         const double q = 1.0 / (u * u + 1.0);
         jf = s0 * q;
@@ -236,10 +272,10 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
         gx = gu * s0;
         const double dz0 = (gu * xraw + gjf * q) * s0;
         const double dz1 = z1 > 0.0 ? gu : 0.0;
-        k.dzp[(size_t)rs * k.ld + i] = dz0;
-        k.dzp[(size_t)rh * k.ld + i] = dz1;
+        dzp[(size_t)rs * k.ldw + i] = dz0;
+        dzp[(size_t)rh * k.ldw + i] = dz1;
 #pragma unroll
-        for (int j = 0; j < WM; ++j) da[j] = fma(wl[(size_t)rs * WM + j], dz0, fma(wl[(size_t)rh * WM + j], dz1, da[j]));
+        for (int j = 0; j < WX; ++j) da[j] = fma(wl[(size_t)rs * WM + j], dz0, fma(wl[(size_t)rh * WM + j], dz1, da[j]));
       } else {
         // PWLin: Q_q = K e_q / tot, y = Q_b alpha + sum_{q<b} e_q / tot, jf = Q_b, alpha = x - b/K  (two streamed passes)
         const double ak = xraw * K;
@@ -248,7 +284,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
         const int b = (int)bf;
         double tot = 0.0, below = 0.0, eb = 0.0;
         for (int q = 0; q < K; ++q) {
-          const double e = nis_exp(last_dot<WM>(wl, bias, row0 + q, aL), etab);
+          const double e = nis_exp(last_dot<WM, WX>(wl, bias, row0 + q, aL), etab);
           const bool hit = q == b;
           below = hit ? tot : below;
           eb = hit ? e : eb;
@@ -261,36 +297,41 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
         const double gQb = gy * alpha + gjf, gQs = gy;
         gx = gy * Qb;
         for (int q = 0; q < K; ++q) {
-          const double e = nis_exp(last_dot<WM>(wl, bias, row0 + q, aL), etab);
+          const double e = nis_exp(last_dot<WM, WX>(wl, bias, row0 + q, aL), etab);
           const double pq = e / tot;
           const double dz = gQb * ((q == b ? Qb : 0.0) - Qb * pq) + gQs * ((q < b ? pq : 0.0) - Qs * pq);
-          k.dzp[(size_t)(row0 + q) * k.ld + i] = dz;
+          dzp[(size_t)(row0 + q) * k.ldw + i] = dz;
 #pragma unroll
-          for (int j = 0; j < WM; ++j) da[j] = fma(wl[(size_t)(row0 + q) * WM + j], dz, da[j]);
+          for (int j = 0; j < WX; ++j) da[j] = fma(wl[(size_t)(row0 + q) * WM + j], dz, da[j]);
         }
       }
-      k.g[(size_t)colp * k.ld + i] = gx;
+      gp[(size_t)colp * k.ld + i] = gx;
       jfprod *= jf;
     }
     if (KIND == NIS_AFFINE) jfprod *= 1.0 / (M_PI / 2);
-    k.g[(size_t)c.jplane * k.ld + i] = gJ * jfprod;              // dL/dJ_in = dL/dJ_out * prod_t dy_t/dx_t
+    gp[(size_t)c.jplane * k.ld + i] = gJ * jfprod;              // dL/dJ_in = dL/dJ_out * prod_t dy_t/dx_t
     // ---- through ReLU to BN_L's output; sums for BN_L
 #pragma unroll
-    for (int j = 0; j < WM; ++j) {
+    for (int j = 0; j < WX; ++j) {
       const double dy = (oL[j] > 0.0) ? da[j] : 0.0;
-      k.dyp[(size_t)j * k.ld + i] = dy;
+      dyp[(size_t)j * k.ldw + i] = dy;
       acc[j] += dy;
       acc[WM + j] = fma(dy, xhL[j], acc[WM + j]);
     }
   }
-  bw_block_reduce<2 * WM>(acc, k.part);
+  double* rec = k.part + ((size_t)g * gridDim.x + blockIdx.x) * BNACC;
+  bw_block_reduce<2 * WM>(acc, rec);
+  if (FUSEW) bw_block_reduce<NW>(accw, rec + 2 * WM);
 }
 
-// dW_L[r][j] = sum_s dZ[r][s] a_L[j][s],  db_L[r] = sum_s dZ[r][s]   for the BRC rows of chunk blockIdx.y
+// dW_L[r][j] = sum_s dZ[r][s] a_L[j][s],  db_L[r] = sum_s dZ[r][s]   for the BRC rows of chunk blockIdx.y, minibatch blockIdx.z
 template <int WM>
 __global__ __launch_bounds__(NIS_TPB) void k_bwd_wlast(BwdK k) {
+  const int g = blockIdx.z;
   const int r0 = blockIdx.y * BRC;
   const int nr = min(BRC, k.c.R - r0);
+  const double* __restrict__ alp = k.alp + (size_t)g * k.wsp_gs;
+  const double* __restrict__ dzp = k.dzp + (size_t)g * k.wsp_gs;
   double acc[BRC * (WM + 1)];
 #pragma unroll
   for (int a = 0; a < BRC * (WM + 1); ++a) acc[a] = 0.0;
@@ -298,123 +339,192 @@ __global__ __launch_bounds__(NIS_TPB) void k_bwd_wlast(BwdK k) {
   for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < k.N; i += stride) {
     double a[WM];
 #pragma unroll
-    for (int j = 0; j < WM; ++j) a[j] = k.alp[(size_t)j * k.ld + i];
+    for (int j = 0; j < WM; ++j) a[j] = alp[(size_t)j * k.ldw + i];
 #pragma unroll
     for (int r = 0; r < BRC; ++r)
       if (r < nr) {
-        const double dz = k.dzp[(size_t)(r0 + r) * k.ld + i];
+        const double dz = dzp[(size_t)(r0 + r) * k.ldw + i];
 #pragma unroll
         for (int j = 0; j < WM; ++j) acc[r * (WM + 1) + j] = fma(dz, a[j], acc[r * (WM + 1) + j]);
         acc[r * (WM + 1) + WM] += dz;
       }
   }
-  bw_block_reduce<BRC*(WM + 1)>(acc, k.part + (size_t)blockIdx.y * BMAXB * BNACC);
+  bw_block_reduce<BRC*(WM + 1)>(acc, k.part + (((size_t)g * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * BNACC);
 }
 
-// BN_l backward (l >= 1) -> Linear_{l-1} backward -> dy_{l-1}
-template <int WM>
-__global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_layer(BwdK k, int l, int sums_off) {
+// BN_l backward (l >= 1) -> Linear_{l-1} backward -> dy_{l-1}.  Record: [dW_{l-1} (WM x WM) | sum dy_{l-1} | sum dy_{l-1} xhat_{l-1}]
+template <int WM, int WX>
+__global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_layer(BwdK k, int l) {
+  __shared__ double lbn[(NIS_MAX_HIDDEN + 1) * 4 * WM];
+  __shared__ double lsum[2 * WM];
+  const int g = blockIdx.y;
+  bw_prologue<WM>(k, g, lbn, lsum);
   const CellK& c = k.c;
   nis_cptr wp = as_const(c.wp);
-  nis_cptr bn = as_const(k.bn);
-  nis_cptr sm = as_const(k.sums);
-  const double invN = k.invN;
+  const double* __restrict__ x = k.x + (size_t)g * k.x_gs;
+  double* __restrict__ dyp = k.dyp + (size_t)g * k.wsp_gs;
   double acc[WM * WM + 2 * WM];
 #pragma unroll
   for (int a = 0; a < WM * WM + 2 * WM; ++a) acc[a] = 0.0;
   const long stride = (long)gridDim.x * NIS_TPB;
   for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < k.N; i += stride) {
     double h[WM], a_in[WM], o_in[WM], xh_in[WM];
-    bw_forward<WM>(k, i, l, h, a_in, o_in, xh_in);
+    bw_forward<WM, WX>(k, x, lbn, i, l, h, a_in, o_in, xh_in);
     double dh[WM];
 #pragma unroll
     for (int j = 0; j < WM; ++j) {
-      const double xh = (h[j] - bn[(l * 4 + 2) * WM + j]) * bn[(l * 4 + 3) * WM + j];
-      const double dy = k.dyp[(size_t)j * k.ld + i];
-      const double m1 = sm[sums_off + j] * invN, m2 = sm[sums_off + WM + j] * invN;
-      dh[j] = bn[(l * 4 + 0) * WM + j] * (dy - m1 - xh * m2);       // scale_l = gamma_l * rstd_l
+      const double xh = (h[j] - lbn[(l * 4 + 2) * WM + j]) * lbn[(l * 4 + 3) * WM + j];
+      const double dy = j < WX ? dyp[(size_t)j * k.ldw + i] : 0.0;
+      dh[j] = lbn[(l * 4 + 0) * WM + j] * (dy - lsum[j] - xh * lsum[WM + j]);       // scale_l = gamma_l * rstd_l
     }
     double da[WM];
 #pragma unroll
     for (int q = 0; q < WM; ++q) da[q] = 0.0;
 #pragma unroll
-    for (int j = 0; j < WM; ++j)
+    for (int j = 0; j < WX; ++j)
 #pragma unroll
-      for (int q = 0; q < WM; ++q) {
+      for (int q = 0; q < WX; ++q) {
         acc[j * WM + q] = fma(dh[j], a_in[q], acc[j * WM + q]);      // dW_{l-1}[j][q]
         da[q] = fma(wp[(size_t)(l - 1) * WM * WM + j * WM + q], dh[j], da[q]);
       }
 #pragma unroll
-    for (int q = 0; q < WM; ++q) {
+    for (int q = 0; q < WX; ++q) {
       const double dy = (l - 1 == 0 || o_in[q] > 0.0) ? da[q] : 0.0;   // BN_0 has no ReLU behind it
-      k.dyp[(size_t)q * k.ld + i] = dy;
+      dyp[(size_t)q * k.ldw + i] = dy;
       acc[WM * WM + q] += dy;
       acc[WM * WM + WM + q] = fma(dy, xh_in[q], acc[WM * WM + WM + q]);
     }
   }
-  bw_block_reduce<WM * WM + 2 * WM>(acc, k.part);
+  bw_block_reduce<WM * WM + 2 * WM>(acc, k.part + ((size_t)g * gridDim.x + blockIdx.x) * BNACC);
 }
 
 // BN_0 backward: gradient of the pass-through columns
 template <int WM>
-__global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_input(BwdK k, int sums_off) {
+__global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_input(BwdK k) {
+  __shared__ double lbn[(NIS_MAX_HIDDEN + 1) * 4 * WM];
+  __shared__ double lsum[2 * WM];
+  const int g = blockIdx.y;
+  bw_prologue<WM>(k, g, lbn, lsum);
   const CellK& c = k.c;
-  nis_cptr bn = as_const(k.bn);
-  nis_cptr sm = as_const(k.sums);
-  const double invN = k.invN;
+  const double* __restrict__ x = k.x + (size_t)g * k.x_gs;
+  double* __restrict__ gp = k.g + (size_t)g * k.g_gs;
+  const double* __restrict__ dyp = k.dyp + (size_t)g * k.wsp_gs;
   const long stride = (long)gridDim.x * NIS_TPB;
   for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < k.N; i += stride) {
 #pragma unroll
     for (int p = 0; p < WM; ++p)
       if (p < c.P) {
         const size_t at = (size_t)c.in_plane[p] * k.ld + i;
-        const double xh = (k.x[at] - bn[2 * WM + p]) * bn[3 * WM + p];
-        const double dy = k.dyp[(size_t)p * k.ld + i];
-        const double m1 = sm[sums_off + p] * invN, m2 = sm[sums_off + WM + p] * invN;
-        k.g[at] += bn[p] * (dy - m1 - xh * m2);
+        const double xh = (x[at] - lbn[2 * WM + p]) * lbn[3 * WM + p];
+        const double dy = dyp[(size_t)p * k.ldw + i];
+        gp[at] += lbn[p] * (dy - lsum[p] - xh * lsum[WM + p]);
       }
   }
 }
 
-// Summed records -> gradient blob in the reference's parameter order (include/nis_hip.h).
-//   sums: [pass 0 = head (BN_L sums) | pass 1 = layer L | ... | pass L = layer 1], each BNACC doubles;
-//   wsum: one BNACC record per chunk of BRC last-layer rows, [r][WM weights | bias].
-// hidden_bias (NIS_AFFINE): 1 = train-mode BatchNorm, 2 = eval mode (`bn`: the saved scale | shift | mean | rstd records).
-__global__ void k_bwd_scatter(CellK c, int WM, const double* __restrict__ sums, const double* __restrict__ wsum,
-                              double* __restrict__ gparams, int hidden_bias, const double* __restrict__ bn) {
-  const int L = c.L;
-  size_t off = 0;
-  const int tid = threadIdx.x, nth = blockDim.x;
-  for (int l = 0; l <= L; ++l) {
-    const int F = cellk_feat(c, l);
-    const int O = l < L ? c.width[l] : c.R;
-    // d gamma_l = sum dy_l xhat_l, d beta_l = sum dy_l: emitted by the pass that produced dy_l
-    //   dy_L by the head (pass 0, offset 0); dy_l (l < L) by layer pass l+1 = pass index L-l, offset WM*WM
-    const double* s = (l == L) ? sums : sums + (size_t)(L - l) * BNACC + WM * WM;
-    for (int j = tid; j < F; j += nth) {
-      gparams[off + j] = s[WM + j];
-      gparams[off + F + j] = s[j];
-    }
-    off += 2 * (size_t)F;
-    if (l < L) {                       // dW_l from layer pass l+1 (pass index L-l)
-      const double* w = sums + (size_t)(L - l) * BNACC;
-      for (int e = tid; e < O * F; e += nth) gparams[off + e] = w[(e / F) * WM + (e % F)];
-      if (hidden_bias) {                 // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0;
-        // in eval mode dh_{l+1} = scale_{l+1} dy_{l+1}, so the bias of Linear_l gets scale_{l+1} * sum dy_{l+1}
-        const double* s1 = (l + 1 == L) ? sums : sums + (size_t)(L - l - 1) * BNACC + WM * WM;
-        for (int e = tid; e < O; e += nth)
-          gparams[off + (size_t)O * F + e] = hidden_bias == 2 ? bn[((l + 1) * 4 + 0) * WM + e] * s1[e] : 0.0;
+// Every record of a cell's chain -> gradient blob in the reference's parameter order (include/nis_hip.h), summed over the G
+// minibatches and the workgroups in a fixed order.  A workgroup owns 4 blob elements and 64 interleaved slices of the records.
+//   rh: head records (G, nparts, BNACC): [sum dy_L | sum dy_L xhat_L | fused: dW_L rows (WM + 1 each: weights | bias)]
+//   rl: layer-pass records, pass p = L - l + 1 of layer kernel l at rl + (p - 1) G nparts BNACC: [dW_{l-1} | sum dy_{l-1} | sum dy xhat]
+//   rw: k_bwd_wlast records (G, nch, nparts, BNACC), chunk = BRC rows of (WM + 1) -- null in the fused mode
+// hidden_bias (NIS_AFFINE): 1 = train-mode BatchNorm (zero gradient), 2 = eval mode (`bn`: saved scale | shift | mean | rstd).
+struct BwdFin {
+  CellK c;
+  int WM, G, nparts, nch, hidden_bias, nelem;
+  const double* rh;
+  const double* rl;
+  const double* rw;
+  const double* bn;
+  double* gparams;
+};
+__global__ __launch_bounds__(NIS_TPB) void k_bwd_finish(BwdFin f) {
+  __shared__ double sm[64][4];
+  const CellK& c = f.c;
+  const int el = threadIdx.x & 3, slice = threadIdx.x >> 2;
+  const int e = blockIdx.x * 4 + el;
+  const int WM = f.WM, L = c.L;
+  const size_t lay = (size_t)f.G * f.nparts * BNACC;        // one launch's records
+  const double* base = nullptr;      // record 0 of minibatch 0
+  size_t gstride = (size_t)f.nparts * BNACC;
+  double mult = 1.0;
+  if (e < f.nelem) {
+    int off = 0;
+    bool found = false;
+    for (int l = 0; l <= L && !found; ++l) {
+      const int F = cellk_feat(c, l);
+      const int O = l < L ? c.width[l] : c.R;
+      // d gamma_l = sum dy_l xhat_l, d beta_l = sum dy_l: emitted by the launch that produced dy_l (head: l == L, slot 0; layer kernel l+1: slot WM*WM)
+      const double* sl = (l == L) ? f.rh : f.rl + (size_t)(L - l - 1) * lay + WM * WM;
+      if (e < off + 2 * F) {
+        const int j = (e - off) % F;
+        base = sl + ((e - off) < F ? WM + j : j);
+        found = true;
+        break;
       }
-    } else {
-      for (int e = tid; e < O * F; e += nth) {
-        const int r = e / F, q = e % F;
-        gparams[off + e] = wsum[(size_t)(r / BRC) * BNACC + (r % BRC) * (WM + 1) + q];
+      off += 2 * F;
+      if (e < off + O * F) {
+        const int r = (e - off) / F, q = (e - off) % F;
+        if (l < L) {
+          base = f.rl + (size_t)(L - l - 1) * lay + r * WM + q;
+        } else if (f.rw) {
+          base = f.rw + (size_t)(r / BRC) * f.nparts * BNACC + (r % BRC) * (WM + 1) + q;
+          gstride = (size_t)f.nch * f.nparts * BNACC;
+        } else {
+          base = f.rh + 2 * WM + r * (WM + 1) + q;
+        }
+        found = true;
+        break;
+      }
+      off += O * F;
+      if (f.hidden_bias && l < L) {
+        if (e < off + O) {
+          const int j = e - off;
+          base = ((l + 1 == L) ? f.rh : f.rl + (size_t)(L - l - 2) * lay + WM * WM) + j;
+          mult = f.hidden_bias == 2 ? f.bn[((l + 1) * 4 + 0) * WM + j] : 0.0;
+          found = true;
+          break;
+        }
+        off += O;
       }
     }
-    off += (size_t)O * F;
-    if (hidden_bias && l < L) off += O;
+    if (!found) {                                      // bias of the last Linear
+      const int r = e - off;
+      if (f.rw) {
+        base = f.rw + (size_t)(r / BRC) * f.nparts * BNACC + (r % BRC) * (WM + 1) + WM;
+        gstride = (size_t)f.nch * f.nparts * BNACC;
+      } else {
+        base = f.rh + 2 * WM + r * (WM + 1) + WM;
+      }
+    }
   }
-  for (int r = tid; r < c.R; r += nth) gparams[off + r] = wsum[(size_t)(r / BRC) * BNACC + (r % BRC) * (WM + 1) + WM];
+  double t0 = 0.0, t1 = 0.0;
+  if (base) {
+    const int tot = f.G * f.nparts;
+    int idx = slice;
+    for (; idx + 64 < tot; idx += 128) {
+      const int i1 = idx + 64;
+      t0 += base[(size_t)(idx / f.nparts) * gstride + (size_t)(idx % f.nparts) * BNACC];
+      t1 += base[(size_t)(i1 / f.nparts) * gstride + (size_t)(i1 % f.nparts) * BNACC];
+    }
+    if (idx < tot) t0 += base[(size_t)(idx / f.nparts) * gstride + (size_t)(idx % f.nparts) * BNACC];
+  }
+  sm[slice][el] = t0 + t1;
+  __syncthreads();
+  for (int h = 32; h > 0; h >>= 1) {
+    if (slice < h) sm[slice][el] += sm[slice + h][el];
+    __syncthreads();
+  }
+  if (slice == 0 && e < f.nelem) f.gparams[e] = sm[0][el] * mult;
+}
+
+// dst = src (first) or dst += src: the wide adjoint runs one minibatch at a time, its per-minibatch blobs are added up here
+__global__ __launch_bounds__(NIS_TPB) void k_blob_add(double* __restrict__ dst, const double* __restrict__ src, int n, int first) {
+  const int i = blockIdx.x * NIS_TPB + threadIdx.x;
+  if (i < n) dst[i] = first ? src[i] : dst[i] + src[i];
+}
+hipError_t nis_launch_blob_add(double* dst, const double* src, int n, int first, hipStream_t s) {
+  hipLaunchKernelGGL(k_blob_add, dim3((n + NIS_TPB - 1) / NIS_TPB), dim3(NIS_TPB), 0, s, dst, src, n, first);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -429,67 +539,129 @@ bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm) {
 
 static size_t bwd_chunks(int R) { return (size_t)(R + BRC - 1) / BRC; }
 
-size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N) {
-  if (wm == 16) return bwd_wide_workspace_doubles<16>(cd, N);
+// the d = 2 class whose last-layer gradients ride in the head kernel
+static bool bwd_fused_w(const nis_cell_desc& cd, int wm) { return wm == 4 && cd.kind == NIS_PWQUAD && cd.K == 4 && cd.d - cd.P == 1; }
+
+static int bwd_grid(int G, int64_t N) {
+  static const int bpc = nis_env_int("NIS_BWD_BPC", 4);
+  return std::min(BMAXB, nis_grid_for(bpc, G, N, NIS_TPB));
+}
+
+size_t nis_bwd_cell_params(const nis_cell_desc& cd) {
+  const int T = cd.d - cd.P;
+  const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K);
+  size_t n = 0;
+  for (int l = 0; l <= cd.n_hidden; ++l) {
+    const int F = l == 0 ? cd.P : cd.width[l - 1];
+    const int O = l < cd.n_hidden ? cd.width[l] : R;
+    n += 2 * (size_t)F + (size_t)O * F;
+    if (cd.kind == NIS_AFFINE && l < cd.n_hidden) n += O;
+  }
+  return n + R;
+}
+
+size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N, int G) {
+  if (wm == 16) return bwd_wide_workspace_doubles<16>(cd, N);       // wide cells run one minibatch at a time
   if (wm == 32) return bwd_wide_workspace_doubles<32>(cd, N);
   if (wm == 64) return bwd_wide_workspace_doubles<64>(cd, N);
   const int T = cd.d - cd.P;
   const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K);
-  const size_t nch = bwd_chunks(R);
-  return (size_t)(2 * wm + R) * N + std::max<size_t>(1, nch) * BMAXB * BNACC + (size_t)(cd.n_hidden + 2) * BNACC + nch * BNACC;
+  const bool fused = bwd_fused_w(cd, wm);
+  const size_t nch = fused ? 0 : bwd_chunks(R);
+  const size_t planes = fused ? (size_t)wm : (size_t)(2 * wm + R);
+  const size_t rec = (size_t)G * bwd_grid(G, N) * BNACC;
+  return planes * N * G + (size_t)(cd.n_hidden + 1) * rec + nch * rec;
 }
 
 template <int WM>
-static int bwd_run(const CellK& c, BwdK k, double* ws, double* gparams, hipStream_t s) {
+static int bwd_run(const CellK& c, BwdK k, const nis_cell_desc& cd, double* ws, double* gparams, hipStream_t s) {
   const long N = k.N;
+  const int G = k.G, L = c.L;
+  const bool fused = bwd_fused_w(cd, WM);
+  const size_t nch = fused ? 0 : bwd_chunks(c.R);
+  const size_t planes = fused ? (size_t)WM : (size_t)(2 * WM + c.R);
+  k.ldw = N;
+  k.wsp_gs = (long)(planes * N);
   k.dyp = ws;
   k.alp = ws + (size_t)WM * N;
   k.dzp = ws + (size_t)2 * WM * N;
-  const size_t nch = bwd_chunks(c.R);
-  double* part = ws + (size_t)(2 * WM + c.R) * N;
-  double* sums = part + std::max<size_t>(1, nch) * BMAXB * BNACC;
-  double* wsum = sums + (size_t)(c.L + 2) * BNACC;
-  k.part = part;
-  const int grid = (int)std::max<long>(1, std::min<long>(BMAXB, (N + NIS_TPB - 1) / NIS_TPB));
-  const int L = c.L;
-  const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : c.K <= 16 ? 16 : 32;
-  if (c.kind == NIS_PWLIN)
-    hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWLIN, WM, 4>), dim3(grid), dim3(NIS_TPB), 0, s, k);
-  else if (c.kind == NIS_AFFINE)
-    hipLaunchKernelGGL((k_cell_bwd_head<NIS_AFFINE, WM, 4>), dim3(grid), dim3(NIS_TPB), 0, s, k);
-  else if (km == 4)
-    hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 4>), dim3(grid), dim3(NIS_TPB), 0, s, k);
-  else if (km == 8)
-    hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 8>), dim3(grid), dim3(NIS_TPB), 0, s, k);
-  else if (km == 16)
-    hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 16>), dim3(grid), dim3(NIS_TPB), 0, s, k);
-  else
-    hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 32>), dim3(grid), dim3(NIS_TPB), 0, s, k);
-  hipLaunchKernelGGL(k_bwd_reduce, dim3((2 * WM + 3) / 4, 1), dim3(NIS_TPB), 0, s, (const double*)part, grid, 2 * WM, sums, 0L);
-  // last-layer weight / bias gradients (its own records, reduced per chunk)
-  {
-    const int gw = grid;                 // as many workgroups as the chain kernels: the reduction is issue- and latency-bound
-    hipLaunchKernelGGL((k_bwd_wlast<WM>), dim3(gw, (unsigned)nch), dim3(NIS_TPB), 0, s, k);
-    hipLaunchKernelGGL(k_bwd_reduce, dim3((BRC * (WM + 1) + 3) / 4, (unsigned)nch), dim3(NIS_TPB), 0, s, (const double*)part, gw, BRC * (WM + 1), wsum,
-                       (long)BMAXB * BNACC);
+  const int grid = bwd_grid(G, N);
+  const size_t rec = (size_t)G * grid * BNACC;
+  double* rh = ws + planes * N * G;
+  double* rl = rh + rec;
+  double* rw = rl + (size_t)L * rec;
+  int wx = WM;
+  if (WM == 4 && c.P <= 3) {
+    wx = 3;
+    for (int l = 0; l < L; ++l)
+      if (c.width[l] > 3) wx = WM;
   }
+  k.part = rh;
+  k.prev = nullptr;
+  const dim3 gr(grid, G), tb(NIS_TPB);
+  const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : c.K <= 16 ? 16 : 32;
+#define NIS_HEAD(KIND, KMV)                                                                            \
+  do {                                                                                                 \
+    if (wx == 3) hipLaunchKernelGGL((k_cell_bwd_head<KIND, WM, KMV, (WM == 4 ? 3 : WM), false>), gr, tb, 0, s, k); \
+    else hipLaunchKernelGGL((k_cell_bwd_head<KIND, WM, KMV, WM, false>), gr, tb, 0, s, k);             \
+  } while (0)
+  if (fused) {
+    if (wx == 3) hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 4, (WM == 4 ? 3 : WM), true>), gr, tb, 0, s, k);
+    else hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 4, WM, true>), gr, tb, 0, s, k);
+  } else if (c.kind == NIS_PWLIN)
+    NIS_HEAD(NIS_PWLIN, 4);
+  else if (c.kind == NIS_AFFINE)
+    NIS_HEAD(NIS_AFFINE, 4);
+  else if (km == 4)
+    NIS_HEAD(NIS_PWQUAD, 4);
+  else if (km == 8)
+    NIS_HEAD(NIS_PWQUAD, 8);
+  else if (km == 16)
+    NIS_HEAD(NIS_PWQUAD, 16);
+  else
+    NIS_HEAD(NIS_PWQUAD, 32);
+#undef NIS_HEAD
+  if (!fused) {                          // last-layer weight / bias gradients: their own records, one chunk of BRC rows per blockIdx.y
+    BwdK kw = k;
+    kw.part = rw;
+    hipLaunchKernelGGL((k_bwd_wlast<WM>), dim3(grid, (unsigned)nch, G), tb, 0, s, kw);
+  }
+  k.prev = rh;
+  k.nprev = grid;
+  k.prev_off = 0;
   for (int l = L; l >= 1; --l) {
     const int pass = L - l + 1;                              // 1..L
-    k.sums = sums + (size_t)(pass - 1) * BNACC;
-    const int soff = (pass == 1) ? 0 : WM * WM;
-    hipLaunchKernelGGL((k_cell_bwd_layer<WM>), dim3(grid), dim3(NIS_TPB), 0, s, k, l, soff);
-    hipLaunchKernelGGL(k_bwd_reduce, dim3((WM * WM + 2 * WM + 3) / 4, 1), dim3(NIS_TPB), 0, s, (const double*)part, grid, WM * WM + 2 * WM,
-                       sums + (size_t)pass * BNACC, 0L);
+    k.part = rl + (size_t)(pass - 1) * rec;
+    if (wx == 3) hipLaunchKernelGGL((k_cell_bwd_layer<WM, (WM == 4 ? 3 : WM)>), gr, tb, 0, s, k, l);
+    else hipLaunchKernelGGL((k_cell_bwd_layer<WM, WM>), gr, tb, 0, s, k, l);
+    k.prev = k.part;
+    k.prev_off = WM * WM;
   }
-  k.sums = sums + (size_t)L * BNACC;
-  hipLaunchKernelGGL((k_cell_bwd_input<WM>), dim3(grid), dim3(NIS_TPB), 0, s, k, WM * WM);
-  hipLaunchKernelGGL(k_bwd_scatter, dim3(1), dim3(NIS_TPB), 0, s, c, WM, (const double*)sums, (const double*)wsum, gparams,
-                     c.kind == NIS_AFFINE ? (k.invN == 0.0 ? 2 : 1) : 0, k.bn);
+  hipLaunchKernelGGL((k_cell_bwd_input<WM>), gr, tb, 0, s, k);
+  BwdFin f;
+  memset(&f, 0, sizeof(f));
+  f.c = c;
+  f.WM = WM;
+  f.G = G;
+  f.nparts = grid;
+  f.nch = (int)nch;
+  f.hidden_bias = c.kind == NIS_AFFINE ? (k.invN == 0.0 ? 2 : 1) : 0;
+  f.nelem = (int)nis_bwd_cell_params(cd);
+  f.rh = rh;
+  f.rl = rl;
+  f.rw = fused ? nullptr : rw;
+  f.bn = k.bn;
+  f.gparams = gparams;
+  hipLaunchKernelGGL(k_bwd_finish, dim3((f.nelem + 3) / 4), tb, 0, s, f);
   return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
 }
 
-int nis_bwd_cell_run(const CellK& c, int wm, const double* x, const double* xo, double* g, const double* bnsave, long ld, long N,
-                     double* ws, double* gparams, const MfmaW& mw, bool eval_bn, hipStream_t s) {
+// One cell's adjoint for G minibatches: x / xo / g / bnsave point at minibatch 0, x_gs / g_gs / bn_gs are the strides between
+// minibatches.  gparams receives the SUM over the minibatches.  Wide cells (matrix-core kernels) run one minibatch at a time
+// into `gtmp` (>= nis_bwd_cell_params doubles) and are added up.
+int nis_bwd_cell_run(const CellK& c, const nis_cell_desc& cd, int wm, const double* x, const double* xo, double* g, const double* bnsave,
+                     long ld, long N, int G, long x_gs, long g_gs, long bn_gs, double* ws, double* gparams, double* gtmp, const MfmaW& mw,
+                     bool eval_bn, hipStream_t s) {
   BwdK k;
   memset(&k, 0, sizeof(k));
   k.c = c;
@@ -501,10 +673,28 @@ int nis_bwd_cell_run(const CellK& c, int wm, const double* x, const double* xo, 
   k.ldw = ld;
   k.N = N;
   k.invN = eval_bn ? 0.0 : 1.0 / (double)N;
-  if (wm == 4) return bwd_run<4>(c, k, ws, gparams, s);
-  if (wm == 8) return bwd_run<8>(c, k, ws, gparams, s);
-  if (wm == 16) return bwd_wide_run<16>(c, k, mw, ws, gparams, s);
-  if (wm == 32) return bwd_wide_run<32>(c, k, mw, ws, gparams, s);
-  if (wm == 64) return bwd_wide_run<64>(c, k, mw, ws, gparams, s);
-  return NIS_E_UNSUPPORTED;
+  k.G = G;
+  k.x_gs = x_gs;
+  k.g_gs = g_gs;
+  k.bn_gs = bn_gs;
+  if (wm == 4) return bwd_run<4>(c, k, cd, ws, gparams, s);
+  if (wm == 8) return bwd_run<8>(c, k, cd, ws, gparams, s);
+  const int np = (int)nis_bwd_cell_params(cd);
+  for (int gi = 0; gi < G; ++gi) {
+    BwdK kg = k;
+    kg.G = 1;
+    kg.x = x + (size_t)gi * x_gs;
+    kg.xo = xo + (size_t)gi * x_gs;
+    kg.g = g + (size_t)gi * g_gs;
+    kg.bn = bnsave + (size_t)gi * bn_gs;
+    double* out = G == 1 ? gparams : gtmp;
+    int rc;
+    if (wm == 16) rc = bwd_wide_run<16>(c, kg, mw, ws, out, s);
+    else if (wm == 32) rc = bwd_wide_run<32>(c, kg, mw, ws, out, s);
+    else if (wm == 64) rc = bwd_wide_run<64>(c, kg, mw, ws, out, s);
+    else return NIS_E_UNSUPPORTED;
+    if (rc != NIS_OK) return rc;
+    if (G > 1 && nis_launch_blob_add(gparams, gtmp, np, gi == 0, s) != hipSuccess) return NIS_E_HIP;
+  }
+  return NIS_OK;
 }

@@ -111,16 +111,17 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
       if (writer) {
         coef_g[(fresh * 2 + 0) * WM + j] = scale;
         coef_g[(fresh * 2 + 1) * WM + j] = shift;
-        if (c.bnsave && c.G == 1) {
+        if (c.bnsave) {
           double mean_s = 0.0, rstd_s = 0.0;
           if (j < F) {
             mean_s = ref + s1 / n;
             rstd_s = 1.0 / sqrt(fmax(s2 - s1 * s1 / n, 0.0) / n + NIS_BN_EPS);
           }
-          c.bnsave[(fresh * 4 + 0) * WM + j] = scale;
-          c.bnsave[(fresh * 4 + 1) * WM + j] = shift;
-          c.bnsave[(fresh * 4 + 2) * WM + j] = mean_s;
-          c.bnsave[(fresh * 4 + 3) * WM + j] = rstd_s;
+          double* bs = c.bnsave + (size_t)g * c.bnsave_gs;
+          bs[(fresh * 4 + 0) * WM + j] = scale;
+          bs[(fresh * 4 + 1) * WM + j] = shift;
+          bs[(fresh * 4 + 2) * WM + j] = mean_s;
+          bs[(fresh * 4 + 3) * WM + j] = rstd_s;
         }
       }
       if (fresh == 0 && c.derive1 && j == 0) {       // hand BN_0's statistics to the BN_1 derivation below
@@ -217,11 +218,12 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
         if (writer) {
           coef_g[(1 * 2 + 0) * WM + tid] = scale;
           coef_g[(1 * 2 + 1) * WM + tid] = shift;
-          if (c.bnsave && c.G == 1) {
-            c.bnsave[(1 * 4 + 0) * WM + tid] = scale;
-            c.bnsave[(1 * 4 + 1) * WM + tid] = shift;
-            c.bnsave[(1 * 4 + 2) * WM + tid] = mean1;
-            c.bnsave[(1 * 4 + 3) * WM + tid] = tid < F1 ? 1.0 / sqrt(var1 + NIS_BN_EPS) : 0.0;
+          if (c.bnsave) {
+            double* bs = c.bnsave + (size_t)g * c.bnsave_gs;
+            bs[(1 * 4 + 0) * WM + tid] = scale;
+            bs[(1 * 4 + 1) * WM + tid] = shift;
+            bs[(1 * 4 + 2) * WM + tid] = mean1;
+            bs[(1 * 4 + 3) * WM + tid] = tid < F1 ? 1.0 / sqrt(var1 + NIS_BN_EPS) : 0.0;
           }
         }
       }
@@ -262,11 +264,12 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
         if (writer) {
           coef_g[(1 * 2 + 0) * WM + tid] = scale;
           coef_g[(1 * 2 + 1) * WM + tid] = shift;
-          if (c.bnsave && c.G == 1) {
-            c.bnsave[(1 * 4 + 0) * WM + tid] = scale;
-            c.bnsave[(1 * 4 + 1) * WM + tid] = shift;
-            c.bnsave[(1 * 4 + 2) * WM + tid] = mean1;
-            c.bnsave[(1 * 4 + 3) * WM + tid] = tid < F1 ? 1.0 / sqrt(var1 + NIS_BN_EPS) : 0.0;
+          if (c.bnsave) {
+            double* bs = c.bnsave + (size_t)g * c.bnsave_gs;
+            bs[(1 * 4 + 0) * WM + tid] = scale;
+            bs[(1 * 4 + 1) * WM + tid] = shift;
+            bs[(1 * 4 + 2) * WM + tid] = mean1;
+            bs[(1 * 4 + 3) * WM + tid] = tid < F1 ? 1.0 / sqrt(var1 + NIS_BN_EPS) : 0.0;
           }
         }
       }

@@ -233,6 +233,7 @@ struct CellK {
   int wx;                                // exact common width of the hidden layers when a specialised kernel exists (WM = 4: 3), else 0
   long out_off;                          // doubles from a cell's input planes to its output planes (0: in place)
   double* bnsave;                        // (L+1) x 4 x WM: scale | shift | batch mean | 1/sqrt(var+eps)  (may be null)
+  long bnsave_gs;                        // doubles between the saved statistics of consecutive batches g (the whole model's record)
 };
 
 __host__ __device__ static inline int cellk_feat(const CellK& c, int l) { return l == 0 ? c.P : c.width[l - 1]; }

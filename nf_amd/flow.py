@@ -342,6 +342,94 @@ class FlowEngine:
         _lib.check(rc, "nis_flow_backward_loss")
         return gflat
 
+    # ---- the G minibatches of one optimizer step per library call (manager.py:219-270)
+    def forward_train_batched(self, w, train=True, want_xj=False):
+        """w: (G, N, d) float64 / float32 CUDA tensor, one minibatch per g (own BatchNorm batch).  Returns (xj (G, N, d+1) or None,
+        saved) with saved = (hist (G, n_cells+1, d+1, N), bnsave, train)."""
+        if w.dim() != 3:
+            raise ValueError(f"expected minibatches of shape (G, N, {self.d}), got {tuple(w.shape)}")
+        G, N = int(w.shape[0]), int(w.shape[1])
+        w2 = self._check_input(w.reshape(G * N, w.shape[2]), self.d, False)
+        if train and N < 2:
+            raise ValueError("Expected more than 1 value per channel when training")
+        dev = w2.device
+        pp, rp, tp = self._pointers(dev)
+        ws, wsb = self._workspace(dev, G)
+        hist = torch.empty((G, len(self.cells) + 1, self.d + 1, N), dtype=torch.double, device=dev)
+        nbn = self.L.nis_flow_bnsave_count(self.handle)
+        bnsave = torch.empty((G if train else 1, nbn), dtype=torch.double, device=dev)
+        xj = torch.empty((G, N, self.d + 1), dtype=torch.double, device=dev) if want_xj else None
+        with _lib.on_device(dev):
+            rc = self.L.nis_flow_forward_hist_batched(self.handle, w2.data_ptr(), _lib.NIS_F32 if w2.dtype == torch.float32 else _lib.NIS_F64,
+                                                      G, N, pp, rp, tp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL, self.pack_token(),
+                                                      hist.data_ptr(), N, bnsave.data_ptr(), xj.data_ptr() if want_xj else None,
+                                                      ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+        _lib.check(rc, "nis_flow_forward_hist_batched")
+        if train:
+            self._stats_bump(1)
+        self._raise_on_status(ws[:4].view(torch.int32))
+        return xj, (hist, bnsave, bool(train))
+
+    def loss_terms_batched(self, saved, maxf, preburn, est, f=None, fvals=None, w=None):
+        """The loss bookkeeping of G minibatches in two launches (`nis_loss_terms_batched`, manager.py:223-268).  A built-in
+        integrand `f` is evaluated in the kernel straight from the output planes of the history (or on the latent rows `w`
+        (G, N, d) float64 during the preburn); fvals: (G, N) values of an arbitrary callable.  Returns (fv (G, N), rec (G, 12), out (G, 8))."""
+        hist = saved[0]
+        G, nset, dd, N = hist.shape
+        d, dev = dd - 1, hist.device
+        set_ = dd * N
+        rec = torch.empty((G, 12), dtype=torch.double, device=dev)
+        out = torch.empty((G, 8), dtype=torch.double, device=dev)
+        wsb = self.L.nis_loss_workspace_bytes_batched(G, N)
+        ws = _moments_ws(dev, wsb)
+        if fvals is None:
+            fv = torch.empty((G, N), dtype=torch.double, device=dev)
+            fp = (C.c_double * 4)(*(list(f.nis_params) + [0.0] * 4)[:4])
+            if preburn:
+                if w.dtype != torch.double or not w.is_contiguous():
+                    w = w.to(torch.double).contiguous()
+                src = (w.data_ptr(), 1, d, N * d, None)
+                keep = w
+            else:
+                oc = (C.c_int32 * d)(*self.out_col)
+                src = (hist.data_ptr() + 8 * (nset - 1) * set_, N, 1, nset * set_, oc)
+                keep = None
+            args = (None,) + src + (d, f.nis_kind, fp, fv.data_ptr())
+        else:
+            fv = fvals.detach().to(torch.double).contiguous()
+            keep = None
+            args = (fv.data_ptr(), None, 0, 0, 0, None, d, -1, None, None)
+        with _lib.on_device(dev):
+            rc = self.L.nis_loss_terms_batched(*args, hist.data_ptr() + 8 * ((nset - 1) * set_ + d * N), 1, nset * set_, G, N,
+                                               maxf.data_ptr(), 1 if preburn else 0, 1 if est else 0, rec.data_ptr(), out.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
+        del keep
+        _lib.check(rc, "nis_loss_terms_batched")
+        return fv, rec, out
+
+    def backward_loss_batched(self, saved, fvals, maxf, rec, gloss, est):
+        """Adjoint of G minibatches seeded by their losses (`nis_flow_backward_loss_batched`): [flat parameter-gradient blob per cell],
+        each the sum over the minibatches of gloss * d loss_g / d parameters."""
+        hist, bnsave, train = saved
+        G, _, _, N = hist.shape
+        dev = hist.device
+        pp, _, _ = self._pointers(dev)
+        n = len(self.cells)
+        gflat = [torch.empty_like(c._flat) for c in self.cells]
+        gp = (C.c_void_p * n)(*[g.data_ptr() for g in gflat])
+        wsb = self.L.nis_flow_backward_workspace_bytes_batched(self.handle, G, N)
+        ws = getattr(self, "_bws", None)
+        if ws is None or ws.device != dev or ws.numel() < wsb:
+            self._bws = ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        gloss = gloss.detach().to(device=dev, dtype=torch.double).reshape(1)
+        with _lib.on_device(dev):
+            rc = self.L.nis_flow_backward_loss_batched(self.handle, hist.data_ptr(), N, G, N, pp, bnsave.data_ptr(),
+                                                       _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL, fvals.data_ptr(), maxf.data_ptr(),
+                                                       rec.data_ptr(), gloss.data_ptr(), 1 if est else 0, gp, ws.data_ptr(), ws.numel(),
+                                                       _lib.stream_ptr(dev))
+        _lib.check(rc, "nis_flow_backward_loss_batched")
+        return gflat
+
     def backward(self, saved, gxj, want_gx):
         """dL/dXJ (N, d+1) -> ([flat parameter-gradient blob per cell], dL/dx or None)."""
         hist, bnsave, has_jac, train = saved

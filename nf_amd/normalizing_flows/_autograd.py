@@ -75,6 +75,55 @@ class _HipLossFn(torch.autograd.Function):
         return (None, None, None, None, None, None) + tuple(grads)
 
 
+class _HipEpochLossFn(torch.autograd.Function):
+    """The G minibatches of ONE optimizer step (manager.py:219-270: the epoch's loss is the mean of the minibatch losses and
+    backward runs once) as three library calls: nis_flow_forward_hist_batched -> nis_loss_terms_batched -> (backward)
+    nis_flow_backward_loss_batched.  The minibatches are the y dimension of every launch.  Returns (sum of the G minibatch
+    losses, out (G, 8) bookkeeping rows)."""
+
+    @staticmethod
+    def forward(ctx, engine, w, f, maxf, preburn, est, *params):
+        w = w.detach()
+        builtin = hasattr(f, "nis_kind")
+        xj, saved = engine.forward_train_batched(w, True, want_xj=not builtin and not preburn)
+        if builtin:
+            fv, rec, out = engine.loss_terms_batched(saved, maxf, preburn, est, f=f, w=w)
+        else:
+            with torch.no_grad():               # the callable sees one minibatch at a time, as in the reference's loop
+                vals = torch.stack([f(w[g]) if preburn else f(xj[g, :, :-1]) for g in range(w.shape[0])])
+            fv, rec, out = engine.loss_terms_batched(saved, maxf, preburn, est, fvals=vals)
+        ctx.engine, ctx.saved, ctx.fv, ctx.rec, ctx.maxf, ctx.est = engine, saved, fv, rec, maxf, est
+        ctx.sizes = [[p.numel() for p in c.parameters()] for c in engine.cells]
+        ctx.shapes = [[p.shape for p in c.parameters()] for c in engine.cells]
+        ctx.mark_non_differentiable(out)
+        return out[:, 2].sum(), out
+
+    @staticmethod
+    def backward(ctx, gloss, _gout):
+        gflat = ctx.engine.backward_loss_batched(ctx.saved, ctx.fv, ctx.maxf, ctx.rec, gloss, ctx.est)
+        ctx.saved = ctx.fv = None
+        grads = []
+        for gf, sizes, shapes in zip(gflat, ctx.sizes, ctx.shapes):
+            off = 0
+            for n, sh in zip(sizes, shapes):
+                grads.append(gf[off:off + n].view(sh))
+                off += n
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+def flow_loss_batched(model, w, f, maxf, preburn, est):
+    """(sum of the minibatch losses: 0-d tensor with grad, out (G, 8) rows {mean(a), var(a), loss, var(u^2), n, mean(u), -, -}) for
+    the minibatches w (G, N, d), or None when the model is outside the class the fused path covers."""
+    engine = model.engine()
+    if not (model.training and engine.backward_supported() and w.is_cuda and w.dtype == torch.double and torch.is_grad_enabled()):
+        return None
+    from ..flow import ensure_flat
+    for c in engine.cells:
+        ensure_flat(c, w.device)
+    params = [p for c in engine.cells for p in c.parameters()]
+    return _HipEpochLossFn.apply(engine, w, f, maxf, preburn, est, *params)
+
+
 def flow_loss(model, w, f, maxf, preburn, est):
     """(loss 0-d tensor with grad, out8 device tensor {mean(a), var(a), loss, var(u^2), n, mean(u)}) of one minibatch, or None
     when the model is outside the class the fused path covers (then the caller runs the piecewise path)."""

@@ -27,7 +27,7 @@ from ..flow import moments as hip_moments, moments_of
 from .layers.coupling_cells import AffineCoupling, PWLin, PWQuad
 from .layers.layers import AddJacobian, DeMaskLayer, MaskLayer, RollLayer
 from .sequential import FlowSequential
-from ._autograd import flow_loss
+from ._autograd import flow_loss, flow_loss_batched
 
 
 def get_bin(x, n=0):
@@ -217,8 +217,34 @@ class BasicManager(ModelAPI):
             loss = 0
             var = 0
             optimizer_object.zero_grad()
-            for _ in range(n_minibatches):                                          # :219-270
-                w = self._uniform(mini_batch_size, dev, torch.double, "train")
+            done = 0
+            fuse_ok = self.fused_minibatch and loss_mode in ("var", "est") and torch.is_tensor(maxf) and self._stock_input() and \
+                isinstance(self.model, FlowSequential)
+            while fuse_ok and done < n_minibatches:
+                # The epoch's minibatches are independent given the parameters (the loss is their mean, backward runs once, :219-275):
+                # G of them travel as the y dimension of every launch -- forward with history, integrand, loss bookkeeping and (in
+                # loss.backward()) the adjoint are three library calls per G minibatches instead of ~60 launches per minibatch.
+                G = min(n_minibatches - done, self._minibatches_per_call(mini_batch_size))
+                if self.sample_hook is not None:
+                    w3 = torch.stack([self._uniform(mini_batch_size, dev, torch.double, "train") for _ in range(G)])
+                else:
+                    w3 = torch.rand(G, mini_batch_size, d, dtype=torch.double, device=dev)
+                fused = flow_loss_batched(self.model, w3, f, maxf, preburner, loss_mode == "est")
+                if fused is None:                   # outside the fused class: the per-minibatch path below takes these draws
+                    pending = list(w3)
+                    fuse_ok = False
+                    break
+                loss_sum, t = fused                 # t (G, 8): rows {mean(a), var(a), loss, var(u^2), n, mean(u), -, -}
+                ts = t.sum(0)
+                integ[i + 1] += ts[0] / n_minibatches
+                err[i + 1] += ts[1] / n_minibatches
+                loss = loss + loss_sum
+                var = var + ts[3] / mini_batch_size                                 # variance of the mean (:268)
+                done += G
+            else:
+                pending = []
+            for _ in range(n_minibatches - done):                                   # :219-270
+                w = pending.pop(0) if pending else self._uniform(mini_batch_size, dev, torch.double, "train")
                 fused = None
                 if self.fused_minibatch and loss_mode in ("var", "est") and torch.is_tensor(maxf) and self._stock_input() and \
                         isinstance(self.model, FlowSequential):
@@ -405,6 +431,13 @@ class BasicManager(ModelAPI):
         p = next(self.best_model.parameters())
         return p.device if p.is_cuda else torch.device("cuda:0")
 
+    def _minibatches_per_call(self, mini_batch_size):
+        """How many minibatches one fused training call carries: all of an epoch's, within ~2 GiB of history planes."""
+        n_cells = sum(1 for m in self.model if hasattr(m, "KIND")) if isinstance(self.model, FlowSequential) else 1
+        per = (n_cells + 1) * (self.n_flow + 1) * int(mini_batch_size) * 8
+        return int(max(1, min(self.minibatches_per_call, (2 << 30) // max(per, 1))))
+
+    minibatches_per_call = 4096  # training: upper bound on the minibatches of one optimizer step carried by one fused call
     batch_iterations = 20      # integrate(): iterations fused into one launch set (independent BN batches)
     fused_minibatch = True     # training: forward -> integrand -> loss bookkeeping -> adjoint as library calls only (False: the piecewise
                                # path through torch's autograd graph, kept for A/B tests and for models outside the adjoint kernels' class)

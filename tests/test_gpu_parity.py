@@ -1857,3 +1857,107 @@ def test_fused_integrand_rider_on_the_matrix_core_kernels(kind, c, fname):
     model.load_state_dict(sd0)
     eng.integrate_steps(w[0], True, f.nis_kind, f.nis_params, one)
     np.testing.assert_allclose(t2n(one[0]), t2n(out[0]), rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------ minibatches of one optimizer step as grid.y
+def _batched_models():
+    from nf_amd.normalizing_flows.manager import AffineManager, PWLinManager, PWQuadManager
+    out = []
+
+    def add(name, mk):
+        out.append(pytest.param(mk, id=name))
+
+    def quad(d, nc, K, NN):
+        def mk():
+            NF = PWQuadManager(n_flow=d)
+            NF.create_model(nc, K, NN)
+            return NF
+        return mk
+
+    def lin(d, P, nc, K, NN, roll):
+        def mk():
+            NF = PWLinManager(n_flow=d)
+            NF.create_model(P, nc, K, NN, roll)
+            return NF
+        return mk
+
+    def aff(d, P, nc, NN):
+        def mk():
+            NF = AffineManager(n_flow=d)
+            NF.create_model(P, nc, NN, 2)
+            return NF
+        return mk
+
+    add("c2-class", quad(2, 2, 4, [3, 3, 3]))               # last-layer gradients ride in the head kernel
+    add("d2-k8-w4", quad(2, 2, 8, [4, 4]))                   # narrow, separate last-layer reduction
+    add("d5-k6-w8", quad(5, 4, 6, [7, 8, 5]))                # WM = 8, several transformed columns
+    add("pwlin-d4", lin(4, 2, 3, 24, [6, 6], 2))
+    add("affine-d4", aff(4, 2, 3, [5, 5]))
+    add("wide-d6", quad(6, 3, 8, [16, 16]))                  # matrix-core adjoint: one minibatch at a time, blobs added up
+    return out
+
+
+@pytest.mark.parametrize("mk", _batched_models())
+@pytest.mark.parametrize("mode", ["var", "est", "preburn"])
+def test_batched_minibatches_equal_single_minibatch_calls(mk, mode):
+    """nis_flow_forward_hist_batched / nis_loss_terms_batched / nis_flow_backward_loss_batched (G minibatches as the y dimension of
+    every launch) against G calls of the per-minibatch entry points (pinned to the reference by the golden training runs): history
+    planes, saved BatchNorm records, loss bookkeeping rows, running statistics after the call, and the summed parameter gradients."""
+    import copy
+    from nf_amd import integrands
+    torch.manual_seed(11)
+    NF = mk()
+    model = NF._model.to(dev()).train()
+    d = NF.n_flow
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.2 * torch.randn_like(p))
+    G, N = 3, 1537
+    w = torch.rand(G, N, d, dtype=torch.double, device=dev()) * (1 - 1e-9)
+    f = integrands.Camel() if d == 2 else integrands.Normal(0.5, 0.35, d)
+    maxf = torch.tensor(1.7, dtype=torch.double, device=dev())
+    gloss = torch.tensor(1.0 / G, dtype=torch.double, device=dev())
+    preburn, est = mode == "preburn", mode == "est"
+    model_b = copy.deepcopy(model)
+    ea, eb = model.engine(), model_b.engine()
+    assert ea.backward_supported()
+    # per minibatch
+    hist_a, bn_a, out_a, g_a = [], [], [], None
+    for g in range(G):
+        xj, saved = ea.forward_train(w[g], False)
+        fv, rec, out = ea.loss_terms(xj, maxf, preburn, est, f=f, w=w[g])
+        gf = ea.backward_loss(saved, fv, maxf, rec, gloss, est)
+        hist_a.append(saved[0])
+        bn_a.append(saved[1])
+        out_a.append(out)
+        g_a = [x.clone() for x in gf] if g_a is None else [a + x for a, x in zip(g_a, gf)]
+    # batched
+    _, saved = eb.forward_train_batched(w, True)
+    fv, rec, out = eb.loss_terms_batched(saved, maxf, preburn, est, f=f, w=w)
+    g_b = eb.backward_loss_batched(saved, fv, maxf, rec, gloss, est)
+    hb, ha = saved[0].clone(), torch.stack(hist_a)
+    hb[:, 0, d], ha[:, 0, d] = 0.0, 0.0            # the input set's Jacobian plane is implied (AddJacobian: ones), never written
+    np.testing.assert_allclose(t2n(hb), t2n(ha), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(t2n(saved[1]), t2n(torch.stack(bn_a)), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(t2n(out)[:, :6], t2n(torch.stack(out_a))[:, :6], rtol=1e-11, atol=1e-14)
+    for (ka, va), (kb, vb) in zip(model.state_dict().items(), model_b.state_dict().items()):
+        np.testing.assert_allclose(t2n(vb), t2n(va), rtol=1e-12, atol=1e-14, err_msg=ka)      # running statistics: minibatch order
+    for ci, (a, b) in enumerate(zip(g_a, g_b)):
+        scale = float(a.abs().max())
+        np.testing.assert_allclose(t2n(b), t2n(a), rtol=1e-9, atol=1e-12 * max(scale, 1.0), err_msg=f"cell {ci}")
+
+
+def test_batched_minibatches_with_a_callable_integrand_and_xj():
+    """The callable-integrand form of the fused epoch: xj (G, N, d+1) of the batched forward equals the per-minibatch outputs."""
+    from nf_amd.normalizing_flows.manager import PWQuadManager
+    torch.manual_seed(4)
+    NF = PWQuadManager(n_flow=3)
+    NF.create_model(3, 5, [6, 6])
+    model = NF._model.to(dev()).train()
+    w = torch.rand(4, 700, 3, dtype=torch.double, device=dev())
+    import copy
+    mb = copy.deepcopy(model)
+    xj_b, _ = mb.engine().forward_train_batched(w, True, want_xj=True)
+    for g in range(4):
+        xj, _ = model.engine().forward_train(w[g], False)
+        np.testing.assert_allclose(t2n(xj_b[g]), t2n(xj), rtol=1e-12, atol=1e-14)
