@@ -45,9 +45,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(os.path.dirname(HERE), "include", "nis_hip.h")]
+
+
+_FORCE = False
+
+
 def _compile(unit):
+    """Compile one translation unit unless its object is newer than its source and every header (units share the headers, not
+    each other's sources: editing one .hip file rebuilds one object)."""
     name, src, defs = unit
     obj = os.path.join(OBJ, name + ".o")
+    if not _FORCE and not os.environ.get("NIS_EXTRA_FLAGS") and not _stale(obj, [os.path.join(CSRC, src)] + _headers()):
+        return obj, ""
     cmd = [HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -63,6 +74,8 @@ def _link(lib, objs):
 
 
 def build(force=False, verbose=False, diag=False):
+    global _FORCE
+    _FORCE = bool(force)
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     deps = _sources()

@@ -22,6 +22,9 @@
 
 #include "flow_bwd.h"
 
+#ifndef NIS_BWD_LAYER_WAVES
+#define NIS_BWD_LAYER_WAVES 4     // waves per SIMD the 3-wide layer kernel is allocated for (4: 128 VGPRs, 14 dwords of scratch)
+#endif
 int nis_grid_for(int blocks_per_cu, int G, int64_t N, int tpb);      // api.hip
 int nis_env_int(const char* name, int dflt);
 
@@ -56,14 +59,19 @@ __device__ __forceinline__ void bw_prologue(const BwdK& k, int g, double* lbn, d
     constexpr int NV = 2 * WM, S = NIS_TPB / NV;
     const int j = threadIdx.x % NV, sl = threadIdx.x / NV;
     const double* p = k.prev + (size_t)g * k.nprev * BNACC + k.prev_off + j;
-    double t0 = 0.0, t1 = 0.0;
-    int b = sl;
-    for (; b + S < k.nprev; b += 2 * S) {
-      t0 += p[(size_t)b * BNACC];
-      t1 += p[(size_t)(b + S) * BNACC];
+    // every workgroup of the launch pays this merge before its first sample: eight record loads in flight per thread (the chain of
+    // one-at-a-time round trips cost ~25 us per launch at 1024 records), fixed order
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = 0.0;
+    for (int b = sl; b < k.nprev; b += 8 * S) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (b + u * S < k.nprev) ? p[(size_t)(b + u * S) * BNACC] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] += v[u];
     }
-    if (b < k.nprev) t0 += p[(size_t)b * BNACC];
-    red[sl * NV + j] = t0 + t1;
+    red[sl * NV + j] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     __syncthreads();
 #pragma unroll
     for (int h = S / 2; h > 0; h >>= 1) {
@@ -78,13 +86,18 @@ __device__ __forceinline__ void bw_prologue(const BwdK& k, int g, double* lbn, d
 // forward recompute of the hidden stack with the SAVED statistics; returns for layer `upto` (1..L):
 //   h[]   pre-BN activations of BN_upto        a_in[] input of Linear_{upto-1} (post-ReLU of BN_{upto-1}; BN_0 output if upto == 1)
 //   o_in[] BN_{upto-1} output before ReLU      xh_in[] normalised input of BN_{upto-1}
+template <int WM>
+__device__ __forceinline__ void bw_load_x(const BwdK& k, const double* __restrict__ x, long i, double (&cur)[WM]) {
+#pragma unroll
+  for (int p = 0; p < WM; ++p) cur[p] = (p < k.c.P) ? x[(size_t)k.c.in_plane[p] * k.ld + i] : 0.0;
+}
 template <int WM, int WX>
-__device__ __forceinline__ void bw_forward(const BwdK& k, const double* __restrict__ x, const double* lbn, long i, int upto, double (&h)[WM],
+__device__ __forceinline__ void bw_forward(const BwdK& k, const double (&xin)[WM], const double* lbn, int upto, double (&h)[WM],
                                            double (&a_in)[WM], double (&o_in)[WM], double (&xh_in)[WM]) {
   nis_cptr wp = as_const(k.c.wp);
   double cur[WM];
 #pragma unroll
-  for (int p = 0; p < WM; ++p) cur[p] = (p < k.c.P) ? x[(size_t)k.c.in_plane[p] * k.ld + i] : 0.0;
+  for (int p = 0; p < WM; ++p) cur[p] = xin[p];
   for (int l = 0; l < upto; ++l) {
 #pragma unroll
     for (int j = 0; j < WM; ++j) {
@@ -128,8 +141,9 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
   for (int a = 0; a < NW; ++a) accw[a] = 0.0;
   const long stride = (long)gridDim.x * NIS_TPB;
   for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < k.N; i += stride) {
-    double h[WM], a_in[WM], o_in[WM], xh_in[WM];
-    bw_forward<WM, WX>(k, x, lbn, i, L, h, a_in, o_in, xh_in);
+    double h[WM], a_in[WM], o_in[WM], xh_in[WM], xin[WM];
+    bw_load_x<WM>(k, x, i, xin);
+    bw_forward<WM, WX>(k, xin, lbn, L, h, a_in, o_in, xh_in);
     double aL[WM], oL[WM], xhL[WM], da[WM];
 #pragma unroll
     for (int j = 0; j < WM; ++j) {
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_bwd_wlast(BwdK k) {
 
 // BN_l backward (l >= 1) -> Linear_{l-1} backward -> dy_{l-1}.  Record: [dW_{l-1} (WM x WM) | sum dy_{l-1} | sum dy_{l-1} xhat_{l-1}]
 template <int WM, int WX>
-__global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_layer(BwdK k, int l) {
+__global__ __launch_bounds__(NIS_TPB, (WX == 3) ? NIS_BWD_LAYER_WAVES : 1) void k_cell_bwd_layer(BwdK k, int l) {
   __shared__ double lbn[(NIS_MAX_HIDDEN + 1) * 4 * WM];
   __shared__ double lsum[2 * WM];
   const int g = blockIdx.y;
@@ -367,14 +381,33 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_layer(BwdK k, int l) {
 #pragma unroll
   for (int a = 0; a < WM * WM + 2 * WM; ++a) acc[a] = 0.0;
   const long stride = (long)gridDim.x * NIS_TPB;
-  for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < k.N; i += stride) {
-    double h[WM], a_in[WM], o_in[WM], xh_in[WM];
-    bw_forward<WM, WX>(k, x, lbn, i, l, h, a_in, o_in, xh_in);
+  // the inputs of the NEXT sample are requested before the current one is worked on (a thread owns ~5 samples of a 1e6 minibatch and
+  // the launch streams 56 B per sample: without this every sample sat out a full HBM round trip); the last round re-reads its own sample
+  const long i0 = (long)blockIdx.x * NIS_TPB + threadIdx.x;
+  double xq[WM], dyq[WX];
+  if (i0 < k.N) {
+    bw_load_x<WM>(k, x, i0, xq);
+#pragma unroll
+    for (int j = 0; j < WX; ++j) dyq[j] = dyp[(size_t)j * k.ldw + i0];
+  }
+  for (long i = i0; i < k.N; i += stride) {
+    double h[WM], a_in[WM], o_in[WM], xh_in[WM], xin[WM], dyc[WX];
+#pragma unroll
+    for (int p = 0; p < WM; ++p) xin[p] = xq[p];
+#pragma unroll
+    for (int j = 0; j < WX; ++j) dyc[j] = dyq[j];
+    {
+      const long ic = i + stride < k.N ? i + stride : i;
+      bw_load_x<WM>(k, x, ic, xq);
+#pragma unroll
+      for (int j = 0; j < WX; ++j) dyq[j] = dyp[(size_t)j * k.ldw + ic];
+    }
+    bw_forward<WM, WX>(k, xin, lbn, l, h, a_in, o_in, xh_in);
     double dh[WM];
 #pragma unroll
     for (int j = 0; j < WM; ++j) {
       const double xh = (h[j] - lbn[(l * 4 + 2) * WM + j]) * lbn[(l * 4 + 3) * WM + j];
-      const double dy = j < WX ? dyp[(size_t)j * k.ldw + i] : 0.0;
+      const double dy = j < WX ? dyc[j < WX ? j : 0] : 0.0;
       dh[j] = lbn[(l * 4 + 0) * WM + j] * (dy - lsum[j] - xh * lsum[WM + j]);       // scale_l = gamma_l * rstd_l
     }
     double da[WM];
@@ -430,7 +463,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_input(BwdK k) {
 // hidden_bias (NIS_AFFINE): 1 = train-mode BatchNorm (zero gradient), 2 = eval mode (`bn`: saved scale | shift | mean | rstd).
 struct BwdFin {
   CellK c;
-  int WM, G, nparts, nch, hidden_bias, nelem;
+  int WM, G, nparts, nparts_h, nch, hidden_bias, nelem;      // nparts_h: records per minibatch of the head launch, nparts: of every other
   const double* rh;
   const double* rl;
   const double* rw;
@@ -446,6 +479,8 @@ __global__ __launch_bounds__(NIS_TPB) void k_bwd_finish(BwdFin f) {
   const size_t lay = (size_t)f.G * f.nparts * BNACC;        // one launch's records
   const double* base = nullptr;      // record 0 of minibatch 0
   size_t gstride = (size_t)f.nparts * BNACC;
+  int np = f.nparts;                 // records per minibatch in the selected buffer
+  bool in_head = false;
   double mult = 1.0;
   if (e < f.nelem) {
     int off = 0;
@@ -458,6 +493,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_bwd_finish(BwdFin f) {
       if (e < off + 2 * F) {
         const int j = (e - off) % F;
         base = sl + ((e - off) < F ? WM + j : j);
+        in_head = l == L;
         found = true;
         break;
       }
@@ -471,6 +507,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_bwd_finish(BwdFin f) {
           gstride = (size_t)f.nch * f.nparts * BNACC;
         } else {
           base = f.rh + 2 * WM + r * (WM + 1) + q;
+          in_head = true;
         }
         found = true;
         break;
@@ -480,6 +517,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_bwd_finish(BwdFin f) {
         if (e < off + O) {
           const int j = e - off;
           base = ((l + 1 == L) ? f.rh : f.rl + (size_t)(L - l - 2) * lay + WM * WM) + j;
+          in_head = l + 1 == L;
           mult = f.hidden_bias == 2 ? f.bn[((l + 1) * 4 + 0) * WM + j] : 0.0;
           found = true;
           break;
@@ -494,19 +532,24 @@ __global__ __launch_bounds__(NIS_TPB) void k_bwd_finish(BwdFin f) {
         gstride = (size_t)f.nch * f.nparts * BNACC;
       } else {
         base = f.rh + 2 * WM + r * (WM + 1) + WM;
+        in_head = true;
       }
+    }
+    if (in_head) {
+      np = f.nparts_h;
+      gstride = (size_t)np * BNACC;
     }
   }
   double t0 = 0.0, t1 = 0.0;
   if (base) {
-    const int tot = f.G * f.nparts;
+    const int tot = f.G * np;
     int idx = slice;
     for (; idx + 64 < tot; idx += 128) {
       const int i1 = idx + 64;
-      t0 += base[(size_t)(idx / f.nparts) * gstride + (size_t)(idx % f.nparts) * BNACC];
-      t1 += base[(size_t)(i1 / f.nparts) * gstride + (size_t)(i1 % f.nparts) * BNACC];
+      t0 += base[(size_t)(idx / np) * gstride + (size_t)(idx % np) * BNACC];
+      t1 += base[(size_t)(i1 / np) * gstride + (size_t)(i1 % np) * BNACC];
     }
-    if (idx < tot) t0 += base[(size_t)(idx / f.nparts) * gstride + (size_t)(idx % f.nparts) * BNACC];
+    if (idx < tot) t0 += base[(size_t)(idx / np) * gstride + (size_t)(idx % np) * BNACC];
   }
   sm[slice][el] = t0 + t1;
   __syncthreads();
@@ -542,9 +585,11 @@ static size_t bwd_chunks(int R) { return (size_t)(R + BRC - 1) / BRC; }
 // the d = 2 class whose last-layer gradients ride in the head kernel
 static bool bwd_fused_w(const nis_cell_desc& cd, int wm) { return wm == 4 && cd.kind == NIS_PWQUAD && cd.K == 4 && cd.d - cd.P == 1; }
 
-static int bwd_grid(int G, int64_t N) {
-  static const int bpc = nis_env_int("NIS_BWD_BPC", 4);
-  return std::min(BMAXB, nis_grid_for(bpc, G, N, NIS_TPB));
+// workgroups (x extent) of the chain launches: as many as are resident at once (head: 2 per CU at ~240 VGPRs, layer kernels: 3-4), so a
+// thread amortises its prologue (record merge) and epilogue (one wave reduction per accumulator) over as many samples as possible
+static int bwd_grid(int G, int64_t N, bool head) {
+  static const int bh = nis_env_int("NIS_BWD_BPC_HEAD", 2), bl = nis_env_int("NIS_BWD_BPC", 3);
+  return std::min(BMAXB, nis_grid_for(head ? bh : bl, G, N, NIS_TPB));
 }
 
 size_t nis_bwd_cell_params(const nis_cell_desc& cd) {
@@ -569,8 +614,8 @@ size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N
   const bool fused = bwd_fused_w(cd, wm);
   const size_t nch = fused ? 0 : bwd_chunks(R);
   const size_t planes = fused ? (size_t)wm : (size_t)(2 * wm + R);
-  const size_t rec = (size_t)G * bwd_grid(G, N) * BNACC;
-  return planes * N * G + (size_t)(cd.n_hidden + 1) * rec + nch * rec;
+  const size_t rech = (size_t)G * bwd_grid(G, N, true) * BNACC, recl = (size_t)G * bwd_grid(G, N, false) * BNACC;
+  return planes * N * G + rech + (size_t)cd.n_hidden * recl + nch * recl;
 }
 
 template <int WM>
@@ -585,10 +630,10 @@ static int bwd_run(const CellK& c, BwdK k, const nis_cell_desc& cd, double* ws, 
   k.dyp = ws;
   k.alp = ws + (size_t)WM * N;
   k.dzp = ws + (size_t)2 * WM * N;
-  const int grid = bwd_grid(G, N);
-  const size_t rec = (size_t)G * grid * BNACC;
+  const int gridh = bwd_grid(G, N, true), grid = bwd_grid(G, N, false);
+  const size_t rech = (size_t)G * gridh * BNACC, rec = (size_t)G * grid * BNACC;
   double* rh = ws + planes * N * G;
-  double* rl = rh + rec;
+  double* rl = rh + rech;
   double* rw = rl + (size_t)L * rec;
   int wx = WM;
   if (WM == 4 && c.P <= 3) {
@@ -598,16 +643,16 @@ static int bwd_run(const CellK& c, BwdK k, const nis_cell_desc& cd, double* ws, 
   }
   k.part = rh;
   k.prev = nullptr;
-  const dim3 gr(grid, G), tb(NIS_TPB);
+  const dim3 gr(grid, G), grh(gridh, G), tb(NIS_TPB);
   const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : c.K <= 16 ? 16 : 32;
 #define NIS_HEAD(KIND, KMV)                                                                            \
   do {                                                                                                 \
-    if (wx == 3) hipLaunchKernelGGL((k_cell_bwd_head<KIND, WM, KMV, (WM == 4 ? 3 : WM), false>), gr, tb, 0, s, k); \
-    else hipLaunchKernelGGL((k_cell_bwd_head<KIND, WM, KMV, WM, false>), gr, tb, 0, s, k);             \
+    if (wx == 3) hipLaunchKernelGGL((k_cell_bwd_head<KIND, WM, KMV, (WM == 4 ? 3 : WM), false>), grh, tb, 0, s, k); \
+    else hipLaunchKernelGGL((k_cell_bwd_head<KIND, WM, KMV, WM, false>), grh, tb, 0, s, k);             \
   } while (0)
   if (fused) {
-    if (wx == 3) hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 4, (WM == 4 ? 3 : WM), true>), gr, tb, 0, s, k);
-    else hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 4, WM, true>), gr, tb, 0, s, k);
+    if (wx == 3) hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 4, (WM == 4 ? 3 : WM), true>), grh, tb, 0, s, k);
+    else hipLaunchKernelGGL((k_cell_bwd_head<NIS_PWQUAD, WM, 4, WM, true>), grh, tb, 0, s, k);
   } else if (c.kind == NIS_PWLIN)
     NIS_HEAD(NIS_PWLIN, 4);
   else if (c.kind == NIS_AFFINE)
@@ -627,7 +672,7 @@ static int bwd_run(const CellK& c, BwdK k, const nis_cell_desc& cd, double* ws, 
     hipLaunchKernelGGL((k_bwd_wlast<WM>), dim3(grid, (unsigned)nch, G), tb, 0, s, kw);
   }
   k.prev = rh;
-  k.nprev = grid;
+  k.nprev = gridh;
   k.prev_off = 0;
   for (int l = L; l >= 1; --l) {
     const int pass = L - l + 1;                              // 1..L
@@ -635,6 +680,7 @@ static int bwd_run(const CellK& c, BwdK k, const nis_cell_desc& cd, double* ws, 
     if (wx == 3) hipLaunchKernelGGL((k_cell_bwd_layer<WM, (WM == 4 ? 3 : WM)>), gr, tb, 0, s, k, l);
     else hipLaunchKernelGGL((k_cell_bwd_layer<WM, WM>), gr, tb, 0, s, k, l);
     k.prev = k.part;
+    k.nprev = grid;
     k.prev_off = WM * WM;
   }
   hipLaunchKernelGGL((k_cell_bwd_input<WM>), gr, tb, 0, s, k);
@@ -644,6 +690,7 @@ static int bwd_run(const CellK& c, BwdK k, const nis_cell_desc& cd, double* ws, 
   f.WM = WM;
   f.G = G;
   f.nparts = grid;
+  f.nparts_h = gridh;
   f.nch = (int)nch;
   f.hidden_bias = c.kind == NIS_AFFINE ? (k.invN == 0.0 ? 2 : 1) : 0;
   f.nelem = (int)nis_bwd_cell_params(cd);

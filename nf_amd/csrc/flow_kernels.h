@@ -968,6 +968,8 @@ __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const do
 // FIRST (ROWS kernels): the flow's first cell -- both inputs come from the row, the incoming Jacobian is 1: ONE load per sample.
 // BINS (SPEC kernels, test instantiation): the selected bin indices are written to bins_out although the production SPEC
 // kernels never output them -- tests assert them bit-exact against the oracle on the very code path the bench runs.
+// SPEC 3 / 4 (plane input): the same cells in the TRAINING forward -- outputs and the pass-through column go to the next plane set
+// (CellK::out_off, the adjoint's history); 3 carries the next cell's BN_0 rider like SPEC 1, 4 is the last cell (no rider, no integrand).
 // PLN (ROWS kernels): w is two float32 column planes (CellK::wplanar): the first cell takes one float from each, a later cell one
 // float of its transformed column.
 #ifndef NIS_SPEC_WAVES
@@ -1027,17 +1029,17 @@ __global__ __launch_bounds__(NIS_TPB, (SPEC != 0 && KM <= 4) ? NIS_SPEC_WAVES : 
   fold_coefs<WM>(c, lds_coef, c.L + 1, w_fold);
   const bool fold = SP ? true : c.fold != 0;
   const int cP = SP ? 1 : c.P, cT = SP ? 1 : c.T;
-  const long out_off = SP ? 0 : c.out_off;
+  const long out_off = (SPEC == 0 || SPEC >= 3) ? c.out_off : 0;      // SPEC 3 / 4: the training forward's history (next plane set)
   int* const bins_o = SP ? (BINS ? bins_out : nullptr) : bins_out;
   nis_cptr wl = as_const(c.wlast);
   nis_cptr bias = as_const(c.bias);
   constexpr bool GATHER = SP && KM <= 8;    // (2 KM + 1) x 2 KB of LDS per workgroup: 18 KB at KM = 4, 34 KB at KM = 8
   __shared__ double lds_gather[GATHER ? (2 * KM + 1) * NIS_TPB : 1];   // per-thread column of V | W for the indexed read-back
   constexpr bool RIDERS = WM <= 8;          // wide conditioners keep their registers for the GEMV
-  const bool next = SPEC == 1 ? true : SPEC == 2 ? false : (RIDERS && c.next_P > 0);
-  const bool fuse = SPEC == 2 ? true : SPEC == 1 ? false : (RIDERS && fz.kind >= 0);
+  const bool next = (SPEC == 1 || SPEC == 3) ? true : (SPEC == 2 || SPEC == 4) ? false : (RIDERS && c.next_P > 0);
+  const bool fuse = SPEC == 2 ? true : SPEC != 0 ? false : (RIDERS && fz.kind >= 0);
   const int fkind = SPEC == 2 ? (int)NIS_F_CAMEL : fz.kind;
-  const bool wplanes = SPEC == 1 ? true : SPEC == 2 ? false : fz.write_planes != 0;
+  const bool wplanes = SPEC == 2 ? false : SPEC != 0 ? true : fz.write_planes != 0;
   double* const fres = SP ? nullptr : fz.fres;
   // SPEC, K = 4: the bijector only sees V up to a common factor and W up to a common factor (y and the Jacobian divide by
   // the area sum (V_k + V_k+1) W_k and by sum W), so the last height and the last width are taken as exp(0) = 1 and every

@@ -11,6 +11,11 @@
 #endif
 #include "flow_kernels.h"
 
+static bool nis_env_int_wm(const char* name) {
+  const char* v = getenv(name);
+  return v && *v && atoi(v) != 0;
+}
+
 #ifndef NIS_WM
 #error "compile with -DNIS_WM=<4|8|16|32|64>"
 #endif
@@ -203,6 +208,29 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
   const bool rows = c.wrows && c.xb_wcol >= 0;           // transformed input (and maybe the pass-through one) from the rows of w
   if (c.wrows && c.x_wcol >= 0 && !rows) return hipErrorInvalidValue;
   if (rows && (c.first != 0) != (c.x_wcol >= 0)) return hipErrorInvalidValue;   // row kernels: first cell <=> both inputs in w
+  if (c.wx == 3 && c.kind == NIS_PWQUAD && km < 0 && c.P == 1 && c.T == 1 && c.L == 3 && c.fold && c.out_off != 0 && !rows && !bins && !fz.fres && fz.kind < 0 &&
+      fz.write_planes && !nis_env_int_wm("NIS_NO_SPEC_HIST")) {
+    // the same two cells in the training forward (history: outputs to the next plane set): 3 = next-cell rider, 4 = last cell
+    const int spec = (c.next_P == 1 && c.next_src[0] == 1) ? 3 : c.next_P == 0 ? 4 : 0;
+#define NIS_APPLY3H(KMV, SP) \
+  hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
+    if (spec == 3) {
+      switch (km) {
+        case -4: NIS_APPLY3H(4, 3); return hipGetLastError();
+        case -8: NIS_APPLY3H(8, 3); return hipGetLastError();
+        case -16: NIS_APPLY3H(16, 3); return hipGetLastError();
+        default: break;
+      }
+    } else if (spec == 4) {
+      switch (km) {
+        case -4: NIS_APPLY3H(4, 4); return hipGetLastError();
+        case -8: NIS_APPLY3H(8, 4); return hipGetLastError();
+        case -16: NIS_APPLY3H(16, 4); return hipGetLastError();
+        default: break;
+      }
+    }
+#undef NIS_APPLY3H
+  }
   if (c.wx == 3 && c.kind == NIS_PWQUAD && km < 0 && c.P == 1 && c.T == 1 && c.L == 3 && c.fold && c.out_off == 0 && (!bins || (rows && km == -4)) && !fz.fres) {
     // the two cells of a d = 2 chain: every wave-uniform switch resolved at compile time (k_cell_apply, SPEC)
     // 1: the next cell passes THIS cell's output through (next_src[0] == 1: the alternating roll of a d = 2 chain);

@@ -15,15 +15,30 @@ from ._lib import CellDesc
 
 def _param_tensors(cell):
     """Parameters / BN buffers of a cell in C-ABI blob order (= order of the reference's nn.Sequential)."""
+    # the nn.Parameter OBJECTS of a module survive .to() / .double() / load_state_dict (their .data is swapped), so the walk over
+    # the conditioner is done once per set of parameter objects (the training step asks four times per optimizer step)
+    cache = getattr(cell, "_pt_cache", None)
+    if cache is not None and all(a is b for a, b in zip(cache[3], cell.NN._modules.values())) and len(cache[3]) == len(cell.NN._modules) \
+            and all(p is q for p, q in zip(cache[0], cache[4]())):
+        return cache[0], cache[1], cache[2]
     bns = [m for m in cell.NN if isinstance(m, torch.nn.BatchNorm1d)]
     lins = [m for m in cell.NN if isinstance(m, torch.nn.Linear)]
     ps, rs = [], []
+    getters = []
     for l, bn in enumerate(bns):
         ps += [bn.weight, bn.bias, lins[l].weight]
+        getters += [(bn, "weight"), (bn, "bias"), (lins[l], "weight")]
         if l < len(bns) - 1 and lins[l].bias is not None:       # AffineCoupling: biased hidden Linears
             ps.append(lins[l].bias)
+            getters.append((lins[l], "bias"))
         rs += [(bn, "running_mean"), (bn, "running_var")]
     ps.append(lins[-1].bias)
+    getters.append((lins[-1], "bias"))
+
+    def current(getters=getters):
+        return [m._parameters[n] for m, n in getters]
+
+    cell._pt_cache = (ps, rs, bns, list(cell.NN._modules.values()), current)
     return ps, rs, bns
 
 

@@ -12,6 +12,7 @@ tests/torch_adjoint.py).
 import torch
 
 from .. import _lib
+from ..flow import _param_tensors, ensure_flat
 
 
 class _HipFlowFn(torch.autograd.Function):
@@ -93,8 +94,6 @@ class _HipEpochLossFn(torch.autograd.Function):
                 vals = torch.stack([f(w[g]) if preburn else f(xj[g, :, :-1]) for g in range(w.shape[0])])
             fv, rec, out = engine.loss_terms_batched(saved, maxf, preburn, est, fvals=vals)
         ctx.engine, ctx.saved, ctx.fv, ctx.rec, ctx.maxf, ctx.est = engine, saved, fv, rec, maxf, est
-        ctx.sizes = [[p.numel() for p in c.parameters()] for c in engine.cells]
-        ctx.shapes = [[p.shape for p in c.parameters()] for c in engine.cells]
         ctx.mark_non_differentiable(out)
         return out[:, 2].sum(), out
 
@@ -103,10 +102,11 @@ class _HipEpochLossFn(torch.autograd.Function):
         gflat = ctx.engine.backward_loss_batched(ctx.saved, ctx.fv, ctx.maxf, ctx.rec, gloss, ctx.est)
         ctx.saved = ctx.fv = None
         grads = []
-        for gf, sizes, shapes in zip(gflat, ctx.sizes, ctx.shapes):
+        for gf, c in zip(gflat, ctx.engine.cells):
             off = 0
-            for n, sh in zip(sizes, shapes):
-                grads.append(gf[off:off + n].view(sh))
+            for p in _param_tensors(c)[0]:
+                n = p.numel()
+                grads.append(gf[off:off + n].view(p.shape))
                 off += n
         return (None, None, None, None, None, None) + tuple(grads)
 
@@ -117,10 +117,9 @@ def flow_loss_batched(model, w, f, maxf, preburn, est):
     engine = model.engine()
     if not (model.training and engine.backward_supported() and w.is_cuda and w.dtype == torch.double and torch.is_grad_enabled()):
         return None
-    from ..flow import ensure_flat
     for c in engine.cells:
         ensure_flat(c, w.device)
-    params = [p for c in engine.cells for p in c.parameters()]
+    params = [p for c in engine.cells for p in _param_tensors(c)[0]]        # = c.parameters() order (the blob order)
     return _HipEpochLossFn.apply(engine, w, f, maxf, preburn, est, *params)
 
 
