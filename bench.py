@@ -265,17 +265,22 @@ def bench_config(name, rank, ws, dev, steps=6):
 
 
 TRAIN_CASES = {
-    # "integrate(...) and one train step with mbs = 1e6"; C5 topology at the minibatch the adjoint's workspace is sized for
-    "C2": ("C2", 1_000_000, 360.0),        # forward flop per sample (2 cells x 180)
-    "C5": ("C5", 200_000, 1.9e5),
+    # "integrate(...) and one train step with mbs = 1e6"; C5 topology at the minibatch the adjoint's workspace is sized for;
+    # C1_epoch: one optimizer step of the reference's DEFAULT regime (manager.py:66-69: batch_size 10000, mini_batch_size 2000 -> five
+    # minibatches per backward), which is launch-bound: the five minibatches travel as grid.y of every launch
+    "C2": ("C2", 1_000_000, 1, 360.0),        # (model, minibatch size, minibatches per optimizer step, forward flop per sample: 2 cells x 180)
+    "C5": ("C5", 200_000, 1, 1.9e5),
+    "C1_epoch": ("C2", 2_000, 5, 360.0),
 }
 
 
 def bench_train_step(name, rank, ws, dev, steps=5):
     """One training minibatch (reference manager.py:219-280 with n_minibatches = 1): draw w, train-mode forward with history, integrand,
     loss bookkeeping (nis_loss_terms), hand-written adjoint seeded by the loss, optimizer step.  `steps` timed after 2 warm-up steps."""
-    from nf_amd.normalizing_flows._autograd import flow_loss
-    cfg, mbs, fwd_flop = TRAIN_CASES[name]
+    from nf_amd.normalizing_flows._autograd import flow_loss_batched
+    cfg, mbs, G, fwd_flop = TRAIN_CASES[name]
+    if G > 1:
+        steps = 50
     torch.manual_seed(20 + rank)
     if cfg == "C2":
         NF = PWQuadManager(n_flow=2)
@@ -291,10 +296,11 @@ def bench_train_step(name, rank, ws, dev, steps=5):
     optim = torch.optim.Adamax(model.parameters(), lr=2e-3, weight_decay=1e-4)       # README.md:42
     maxf = torch.ones((), dtype=torch.double, device=dev)
 
-    def step():
+    def step():                      # what one epoch of _train_variance_forward_seq does between zero_grad() and optimizer.step()
         optim.zero_grad()
-        w = torch.rand(mbs, d, dtype=torch.double, device=dev)
-        loss, t = flow_loss(model, w, f, maxf, False, False)
+        w = torch.rand(G, mbs, d, dtype=torch.double, device=dev)
+        loss_sum, t = flow_loss_batched(model, w, f, maxf, False, False)
+        loss = loss_sum / G
         loss.backward()
         optim.step()
         return loss
@@ -307,10 +313,11 @@ def bench_train_step(name, rank, ws, dev, steps=5):
         loss = step()
     barrier_sync(ws)
     dt = max_over_ranks(time.perf_counter() - t0, ws, dev)
-    rate = mbs * steps * ws / dt
+    rate = G * mbs * steps * ws / dt
     tf = 3.0 * fwd_flop * rate / ws / 1e12          # forward + adjoint ~ 3x the forward's algorithmic flop (dX and dW products per layer)
-    return {"workload": f"{cfg} training minibatch: draw, forward with history, f(X)*J, loss + bookkeeping, adjoint, Adamax step", "mbs": mbs,
-            "value": rate, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "loss": float(loss),
+    return {"workload": f"{cfg} optimizer step: draw, forward with history, f(X)*J, loss + bookkeeping, adjoint, Adamax step "
+                        f"({G} minibatch{'es as grid.y' if G > 1 else ''} of {mbs})", "mbs": mbs, "minibatches_per_step": G,
+            "value": rate, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "loss": float(loss.detach()),
             "roofline": {"bound": "valu_f64" if cfg == "C2" else "mfma_f64", "achieved": round(tf, 3), "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_F64_PEAK_TF, 4), "flop_per_sample": 3.0 * fwd_flop,
                          "note": "3 x SURVEY 8(d) forward flop/sample x samples/s of the whole step"}}

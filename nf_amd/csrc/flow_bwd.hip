@@ -23,7 +23,7 @@
 #include "flow_bwd.h"
 
 #ifndef NIS_BWD_LAYER_WAVES
-#define NIS_BWD_LAYER_WAVES 4     // waves per SIMD the 3-wide layer kernel is allocated for (4: 128 VGPRs, 14 dwords of scratch)
+#define NIS_BWD_LAYER_WAVES 1     // waves per SIMD the 3-wide layer kernel is allocated for (1: unconstrained, 129 VGPRs = three waves; 4: 128 VGPRs with 14 dwords of scratch measured 15 % slower)
 #endif
 int nis_grid_for(int blocks_per_cu, int G, int64_t N, int tpb);      // api.hip
 int nis_env_int(const char* name, int dflt);
