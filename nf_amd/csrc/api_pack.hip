@@ -45,7 +45,7 @@ size_t nis_flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay, s
     CellLayout L;
     L.WM = nis_pick_wm(m);
     L.KM = c.kind == NIS_PWQUAD ? nis_pick_km(c.K) : 4;
-    if (c.kind == NIS_PWQUAD && L.KM == c.K) L.KM = -L.KM;        // K == KM: guard-free specialisation
+    if (c.kind == NIS_PWQUAD && L.KM == c.K && L.KM <= 32) L.KM = -L.KM;        // K == KM: guard-free specialisation
     const size_t WM = L.WM, R = cell_R(c), nl = c.n_hidden;
     L.off_wp = off;      off += nl * WM * WM;
     L.off_wlast = off;   off += R * WM;

@@ -162,10 +162,75 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
       const double xraw = x[(size_t)colp * k.ld + i];
       const double gy = gp[(size_t)colp * k.ld + i];
       double gx = 0.0, jf = 1.0;
-      if (KIND == NIS_PWQUAD) {
+#define NIS_GV(q, wm1, wq) (((q) >= 1 && (q) - 1 < b ? hgy * (wm1) : 0.0) + ((q) < b ? hgy * (wq) : 0.0) + ((q) == b ? A0 : 0.0) + ((q) == b + 1 ? A1 : 0.0))
+#define NIS_GW0(q) (((q) < b ? hgy * (V[q] + V[(q) + 1]) + gleft : 0.0) + ((q) == b ? B0 : 0.0))
+      if constexpr (KIND == NIS_PWQUAD && KM > 32) {
+        // 33 .. NIS_MAX_BINS bins: the same adjoint with the height / width arrays in per-thread scratch memory and runtime loops
         const bool clamped = xraw > 1.0 - 1e-6;
         const double xb = clamped ? 1.0 - 1e-6 : xraw;
-        double V[KM + 1], W[KM];
+        double V[NIS_KM_BIG + 1], W[NIS_KM_BIG];
+        for (int q = 0; q <= K; ++q) V[q] = nis_exp(last_dot<WM, WX>(wl, bias, row0 + q, aL), etab);
+        for (int q = 0; q < K; ++q) W[q] = nis_exp(last_dot<WM, WX>(wl, bias, row0 + K + 1 + q, aL), etab);
+        double wn = 0.0;
+        for (int q = 0; q < K; ++q) wn += W[q];
+        int b;
+        double left;
+        pwquad_bin_big(xb, K, W, wn, &b, &left);
+        left = left / wn;
+        const double iwn = 1.0 / wn;
+        double area = 0.0;
+        for (int q = 0; q < K; ++q) {
+          W[q] = W[q] * iwn;
+          area += (V[q] + V[q + 1]) / 2 * W[q];
+        }
+        const double iarea = 1.0 / area;
+        for (int q = 0; q <= K; ++q) V[q] = V[q] * iarea;
+        const double Wb = W[b], Vb = V[b], Vb1 = V[b + 1];
+        const double alpha = (xb - left) / Wb;
+        const double D = Vb1 - Vb;
+        jf = lerp_torch(Vb, Vb1, alpha);
+        const double gjf = gJ * Jout / jf;
+        const double galpha = gy * jf * Wb + gjf * D;
+        gx = clamped ? 0.0 : galpha / Wb;
+        const double gleft = -galpha / Wb;
+        const double hgy = gy / 2;
+        const double A0 = gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha);
+        const double A1 = gy * alpha * alpha / 2 * Wb + gjf * alpha;
+        const double B0 = gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb;
+        double S = 0.0;
+        for (int q = 0; q <= K; ++q) {
+          const double wm1 = q >= 1 ? W[q - 1] : 0.0;
+          const double wq = q < K ? W[q] : 0.0;
+          S += NIS_GV(q, wm1, wq) * V[q];
+        }
+        double Sw = 0.0;
+        for (int q = 0; q < K; ++q) Sw += (NIS_GW0(q) - S * (V[q] + V[q + 1]) / 2) * W[q];
+        double wprev = 0.0;
+        for (int q = 0; q <= K; ++q) {
+          const bool hasw = q < K;
+          const double wq = hasw ? W[q] : 0.0;
+          const double vq = V[q];
+          const double dzv = NIS_GV(q, wprev, wq) * vq - S * vq * (wprev + wq) / 2;
+          if (hasw) W[q] = wq * (NIS_GW0(q) - S * (vq + V[q + 1]) / 2 - Sw);
+          V[q] = dzv;
+          wprev = wq;
+        }
+        for (int q = 0; q <= K; ++q) {
+          const double dz = V[q];
+          dzp[(size_t)(row0 + q) * k.ldw + i] = dz;
+#pragma unroll
+          for (int j = 0; j < WX; ++j) da[j] = fma(wl[(size_t)(row0 + q) * WM + j], dz, da[j]);
+        }
+        for (int q = 0; q < K; ++q) {
+          const double dz = W[q];
+          dzp[(size_t)(row0 + K + 1 + q) * k.ldw + i] = dz;
+#pragma unroll
+          for (int j = 0; j < WX; ++j) da[j] = fma(wl[(size_t)(row0 + K + 1 + q) * WM + j], dz, da[j]);
+        }
+      } else if (KIND == NIS_PWQUAD) {
+        const bool clamped = xraw > 1.0 - 1e-6;
+        const double xb = clamped ? 1.0 - 1e-6 : xraw;
+        double V[KM + 1], W[KM];                           // KM <= 32 here (the branch above took the scratch-array variant)
 #pragma unroll
         for (int q = 0; q < KM + 1; ++q) V[q] = (q <= K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + q, aL), etab) : 0.0;
 #pragma unroll
@@ -215,8 +280,6 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
         const double A0 = gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha);
         const double A1 = gy * alpha * alpha / 2 * Wb + gjf * alpha;
         const double B0 = gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb;
-#define NIS_GV(q, wm1, wq) (((q) >= 1 && (q) - 1 < b ? hgy * (wm1) : 0.0) + ((q) < b ? hgy * (wq) : 0.0) + ((q) == b ? A0 : 0.0) + ((q) == b + 1 ? A1 : 0.0))
-#define NIS_GW0(q) (((q) < b ? hgy * (V[q] + V[(q) + 1]) + gleft : 0.0) + ((q) == b ? B0 : 0.0))
         double S = 0.0;                                    // through v = eV / area: S = sum_q gv(q) v_q
 #pragma unroll
         for (int q = 0; q < KM + 1; ++q)
@@ -242,8 +305,6 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
             V[q] = dzv;
             wprev = wq;
           }
-#undef NIS_GV
-#undef NIS_GW0
 #pragma unroll
         for (int q = 0; q < KM + 1; ++q)
           if (q <= K) {
@@ -319,6 +380,8 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
           for (int j = 0; j < WX; ++j) da[j] = fma(wl[(size_t)(row0 + q) * WM + j], dz, da[j]);
         }
       }
+#undef NIS_GV
+#undef NIS_GW0
       gp[(size_t)colp * k.ld + i] = gx;
       jfprod *= jf;
     }
@@ -576,8 +639,7 @@ bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm) {
   if (wm == 32) return bwd_wide_supported<32>(cd);
   if (wm == 64) return bwd_wide_supported<64>(cd);
   if (wm != 4 && wm != 8) return false;
-  if (cd.kind == NIS_PWQUAD) return cd.K <= 32;
-  return cd.K <= NIS_MAX_BINS;
+  return cd.K <= NIS_MAX_BINS;                        // PWQuad with more than 32 bins: scratch-array variant of the head (narrow conditioners only)
 }
 
 static size_t bwd_chunks(int R) { return (size_t)(R + BRC - 1) / BRC; }
@@ -663,8 +725,10 @@ static int bwd_run(const CellK& c, BwdK k, const nis_cell_desc& cd, double* ws, 
     NIS_HEAD(NIS_PWQUAD, 8);
   else if (km == 16)
     NIS_HEAD(NIS_PWQUAD, 16);
-  else
+  else if (c.K <= 32)
     NIS_HEAD(NIS_PWQUAD, 32);
+  else
+    NIS_HEAD(NIS_PWQUAD, NIS_KM_BIG);
 #undef NIS_HEAD
   if (!fused) {                          // last-layer weight / bias gradients: their own records, one chunk of BRC rows per blockIdx.y
     BwdK kw = k;

@@ -920,6 +920,64 @@ __device__ __forceinline__ double pwquad_column(double xb, int Krt, const double
   return num * iA;
 }
 
+// More than 32 bins (up to NIS_MAX_BINS): the same transform with V (K + 1 raw heights) and W (K raw widths) in per-thread arrays
+// the compiler keeps in scratch memory, every loop over the bins a runtime loop.  Bin selection is pwquad_bin_raw's, statement by
+// statement (guard band, exact re-test with the reference's division when a lane falls inside it, sentinel, clamp).
+__device__ __forceinline__ void pwquad_bin_big(double xb, int K, const double* W, double wn, int* idx_out, double* run_out) {
+  const double q = xb * wn;
+  const double qlo = q * (1.0 - 0x1p-50), qhi = q * (1.0 + 0x1p-50);
+  double run = 0.0, bestrun = 0.0;
+  int idx = 0;
+  bool ambany = false;
+  for (int k = 0; k < K; ++k) {
+    run += W[k];
+    const bool le = run <= qlo;
+    ambany |= (run > qlo) && (run < qhi);
+    const bool up = le && (run > bestrun);
+    bestrun = up ? run : bestrun;
+    idx = up ? k + 1 : idx;
+  }
+  if (__any(ambany)) {
+    run = 0.0;
+    bestrun = 0.0;
+    idx = 0;
+    for (int k = 0; k < K; ++k) {
+      run += W[k];
+      const bool le = !((run / wn) > xb);                // the reference's comparison, verbatim
+      const bool up = le && (run > bestrun);
+      bestrun = up ? run : bestrun;
+      idx = up ? k + 1 : idx;
+    }
+  }
+  const bool none = !(bestrun > 1e-30 * wn);
+  idx = none ? 0 : idx;
+  bestrun = none ? 0.0 : bestrun;
+  idx = (idx > K - 1) ? K - 1 : idx;
+  *idx_out = idx;
+  *run_out = bestrun;                                    // raw cumulative width left of the bin
+}
+__device__ __forceinline__ double pwquad_column_big(double xb, int K, const double* V, const double* W, double* jf, int* bin) {
+  xb = (xb > 1.0 - 1e-6) ? 1.0 - 1e-6 : xb;                       // :167
+  double wn = 0.0;
+  for (int k = 0; k < K; ++k) wn += W[k];                         // Wsum[-1]  :180-182
+  int idx;
+  double bestrun;
+  pwquad_bin_big(xb, K, W, wn, &idx, &bestrun);
+  double A = 0.0, pre = 0.0;
+  for (int k = 0; k < K; ++k) {
+    pre = (k == idx) ? A : pre;                                   // VW[idx] A  :209-211
+    A = fma(V[k] + V[k + 1], W[k], A);                            // :194
+  }
+  const double Vb = V[idx], Vb1 = V[idx + 1], Wb = W[idx];
+  const double r = nis_rcp(Wb * A);                               // one reciprocal for both divisions (see pwquad_column)
+  const double iA = r * Wb;
+  const double alpha = (xb * wn - bestrun) * (r * A);             // :206-207
+  const double num = ((alpha * alpha) / 2 * (Vb1 - Vb) + alpha * Vb) * (2 * Wb) + pre;   // :213-220
+  *jf = lerp_torch(Vb, Vb1, alpha) * ((2 * wn) * iA);             // :224-225
+  *bin = idx;
+  return num * iA;
+}
+
 // Same transform with the raw heights / widths in an LDS image (element k of the column at zr[k * ZS]: rows 0..K heights,
 // K+1..2K widths), as the matrix-core kernels keep them: the widths are streamed for the bin search, the trapezoid sums
 // stream the heights, and V_b, V_{b+1}, W_b are read BY INDEX instead of through K-long select chains.
@@ -1126,8 +1184,15 @@ __global__ __launch_bounds__(NIS_TPB, (SPEC != 0 && KM <= 4) ? NIS_SPEC_WAVES : 
       const int row0 = t * c.out;
       double y, jf;
       int bin;
-      if (KIND == NIS_PWQUAD) {
-        double V[KM + 1], W[KM];
+      if constexpr (KIND == NIS_PWQUAD && KM > 32) {             // 33 .. NIS_MAX_BINS bins: scratch arrays, runtime loops
+        double V[NIS_KM_BIG + 1], W[NIS_KM_BIG];
+        const int Kq = c.K;
+        for (int k = 0; k <= Kq; ++k) V[k] = nis_exp(last_dot<WM, WX>(wl, bias, row0 + k, a), etab);                     // :173,189
+        for (int k = 0; k < Kq; ++k) W[k] = nis_exp(last_dot<WM, WX>(wl, bias, row0 + Kq + 1 + k, a), etab);             // :175,178
+        y = pwquad_column_big(xb, Kq, V, W, &jf, &bin);
+      } else if (KIND == NIS_PWQUAD) {
+        constexpr int KA = KM > 32 ? 1 : KM;                     // (the branch above took KM > 32)
+        double V[KA + 1], W[KA];
         const int Kq = KEXACT ? KM : c.K;
         if (SHIFT) {
 #pragma unroll
@@ -1142,7 +1207,7 @@ __global__ __launch_bounds__(NIS_TPB, (SPEC != 0 && KM <= 4) ? NIS_SPEC_WAVES : 
           for (int k = 0; k < KM; ++k)
             W[k] = (KEXACT || k < c.K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + Kq + 1 + k, a), etab) : 0.0;           // :175,178
         }
-        y = pwquad_column<KM, KEXACT>(xb, c.K, V, W, &jf, &bin, GATHER ? lds_gather + tid : nullptr);
+        y = pwquad_column<KA, KEXACT>(xb, c.K, V, W, &jf, &bin, GATHER ? lds_gather + tid : nullptr);
       } else if (KIND == NIS_AFFINE) {
         // AffineCoupling (coupling_cells.py:56-68): rows [scale | shift][T];  y = atan(20 e^z0 x + relu(z1)) / (pi/2)
         const double s0 = 20.0 * nis_exp(last_dot<WM, WX>(wl, bias, t, a), etab);

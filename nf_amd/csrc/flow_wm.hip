@@ -131,6 +131,11 @@ int apply_blocks_per_cu<NIS_WM>(int kind, int km, int wx) {
   static int cache[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
   const bool exact = km < 0;
   const int kk = exact ? -km : km;
+  if (kind == NIS_PWQUAD && kk > 32) {                  // scratch-array variant (33 .. NIS_MAX_BINS bins)
+    static int big = -1;
+    if (big < 0) big = occ_of(k_cell_apply<NIS_PWQUAD, NIS_WM, NIS_KM_BIG, false>);
+    return big;
+  }
 #if NIS_WM == 4
   if (wx == 3 && kk <= 16 && kind != NIS_AFFINE) {           // the 3-wide instantiations have their own register budget
     static int c3[7] = {-1, -1, -1, -1, -1, -1, -1};
@@ -283,6 +288,7 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
       case 8: NIS_APPLY(NIS_PWQUAD, 8, false); break;
       case 16: NIS_APPLY(NIS_PWQUAD, 16, false); break;
       case 32: NIS_APPLY(NIS_PWQUAD, 32, false); break;
+      case NIS_KM_BIG: NIS_APPLY(NIS_PWQUAD, NIS_KM_BIG, false); break;
       case -4: NIS_APPLY(NIS_PWQUAD, 4, true); break;
       case -8: NIS_APPLY(NIS_PWQUAD, 8, true); break;
       case -16: NIS_APPLY(NIS_PWQUAD, 16, true); break;

@@ -159,7 +159,10 @@ __device__ __forceinline__ double nis_sqrt(double x) {
 }
 
 static inline int nis_pick_wm(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 16 ? 16 : m <= 32 ? 32 : m <= 64 ? 64 : -1; }
-static inline int nis_pick_km(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : -1; }
+// bin-array size of the PWQuad kernels: register arrays up to 32 bins; NIS_KM_BIG (33 .. NIS_MAX_BINS bins): the heights / widths of
+// a column live in per-thread scratch arrays and every loop over the bins is a runtime loop (pwquad_column_big)
+#define NIS_KM_BIG 128
+static inline int nis_pick_km(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : k <= NIS_KM_BIG ? NIS_KM_BIG : -1; }
 // workgroup size of the statistics kernel: as many waves as the register budget of width WM allows
 #ifndef NIS_STATS_TPB_NARROW
 #define NIS_STATS_TPB_NARROW 1024     // statistics kernels of the narrow conditioners: ONE workgroup per CU (the prologue is paid per workgroup) of 16 waves

@@ -79,7 +79,11 @@ def test_cell_vs_reference_golden(case, g_cells):
                                              ("pwlin", 9, 3, 128, [64, 64], 700), ("pwquad", 3, 2, 32, [2, 2, 2, 2], 999),
                                              # matrix-core heads whose LDS image decides the columns per bijector batch (CellK::mf_ncb)
                                              ("pwlin", 5, 2, 128, [32, 32], 600), ("pwquad", 6, 3, 32, [32, 32], 800),
-                                             ("pwlin", 8, 4, 64, [32, 32, 32], 1500)])
+                                             ("pwlin", 8, 4, 64, [32, 32, 32], 1500),
+                                             # PWQuad with more than 32 bins: heights / widths in per-thread scratch arrays (pwquad_column_big);
+                                             # wide conditioners take the fp64 VALU kernel there (the matrix-core image kernel stops at 32)
+                                             ("pwquad", 3, 1, 33, [4, 4], 2000), ("pwquad", 5, 2, 100, [8, 6], 1200),
+                                             ("pwquad", 4, 2, 128, [3], 900), ("pwquad", 6, 3, 64, [32, 32], 700)])
 @pytest.mark.parametrize("train", [True, False])
 def test_cell_vs_oracle_seeded(kind, d, P, K, NN, N, train):
     from nf_amd.normalizing_flows.layers.coupling_cells import PWLin, PWQuad
@@ -138,7 +142,8 @@ def test_hip_backward_general_narrow_models(monkeypatch):
     cases = [("pwquad", dict(d=5, n_cells=2, K=6, NN=[8, 8])), ("pwquad", dict(d=7, n_cells=3, K=16, NN=[6])),
              ("pwquad", dict(d=2, n_cells=2, K=32, NN=[3, 3, 3])), ("pwquad", dict(d=4, n_cells=4, K=27, NN=[8])),
              ("pwquad", dict(d=9, n_cells=4, K=5, NN=[7, 4])), ("pwlin", dict(d=3, P=1, n_cells=3, K=33, NN=[5, 5], roll=1)),
-             ("pwlin", dict(d=6, P=4, n_cells=2, K=128, NN=[8], roll=2))]
+             ("pwlin", dict(d=6, P=4, n_cells=2, K=128, NN=[8], roll=2)),
+             ("pwquad", dict(d=3, n_cells=2, K=40, NN=[4, 4])), ("pwquad", dict(d=5, n_cells=3, K=128, NN=[8]))]     # > 32 bins: scratch-array head
     for kind, c in cases:
         torch.manual_seed(c["d"])
         if kind == "pwquad":
@@ -1961,3 +1966,39 @@ def test_batched_minibatches_with_a_callable_integrand_and_xj():
     for g in range(4):
         xj, _ = model.engine().forward_train(w[g], False)
         np.testing.assert_allclose(t2n(xj_b[g]), t2n(xj), rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("tag", ["C4", "C5"])
+def test_bench_topology_flow_into_rambo_moments_at_2e5_vs_oracle(tag, g_wide):
+    """The C4 / C5 bench legs as a COMPOSITION at N = 200 000: width-32 matrix-core flow (the models of wide.npz, whose forward the
+    reference pins at this N) with train-mode BatchNorm -> RAMBO weight (2 -> 4 massive / 2 -> 6 massless with pT / dR / eta cuts,
+    tau-y sampling) * J -> fused moment record (`nis_rambo_moments`: no momenta, no weights, no X materialised), against the
+    oracle's flow forward + oracle's phase-space weight on the same float32-lattice draws."""
+    from nf_amd import integrands
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    case = f"fwd_{tag}"
+    m = g_wide.meta[case]
+    d, N = m["d"], m["N"]
+    params = g_wide.sub(case, "sd")
+    NF = build_manager(m, params)
+    NF.best_model = NF._model
+    NF._model.train()
+    if tag == "C4":
+        init, final, E, cuts, pdgs = [0., 0.], [100.] * 4, 13000., (0, 0, -1), [2, -1]
+    else:
+        init, final, E, cuts, pdgs = [0., 0.], [0.] * 6, 13000., (20, 0.4, 2.5), [21, 21]
+    gen = FlatInvertiblePhasespace(init, final, pdf=None, pdf_active=True)
+    f = integrands.RamboWeight(gen, E, *cuts, pdgs)
+    w = kronecker_w(N, d).astype(np.float32)
+    w = np.minimum(w, np.float32(1.0 - 2.0 ** -24))          # float32 rounding must not produce 1.0 (uniform_ never does)
+    steps = oflow.plan_pwquad(d, m["n_cells"], m["K"])
+    XJ = oflow.model_forward(w.astype(np.float64), {k: np.asarray(v) for k, v in params.items()}, steps, True)
+    _, wref = orambo.generate_kinematics(init, final, E, XJ[:, :d], *cuts, pdf_active=True, tau=True)
+    v = wref * XJ[:, d]
+    NF.sample_hook = Replay([w])
+    got = t2n(NF.moments_batches(f, 1, N, dev()))[0]
+    assert got[0] == N
+    np.testing.assert_allclose(got[1], v.mean(), rtol=1e-8)
+    np.testing.assert_allclose(got[2], ((v - v.mean()) ** 2).sum(), rtol=1e-7)
+    np.testing.assert_allclose(got[3], v.max(), rtol=1e-8)
+    assert (v > 0).mean() > 0.01                              # the cuts leave a populated sample
