@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-tools/probe/rambo_traffic 1000000 40 > gpurun_out/rambo_traffic.txt 2>&1; cat gpurun_out/rambo_traffic.txt
-python tools/rambo_time.py > gpurun_out/rambo_time.txt 2>&1; tail -5 gpurun_out/rambo_time.txt
-timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/full.log 2>&1; tail -5 gpurun_out/full.log
+R=$GRAFT_REPO_ROOT
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench_r03b.json 2> gpurun_out/bench_r03b.err; tail -c 300 gpurun_out/bench_r03b.json; tail -3 gpurun_out/bench_r03b.err
+( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_C4 -o k -- python3 $R/tools/run_config_step.py C4 6 > /dev/null 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_C5 -o k -- python3 $R/tools/run_config_step.py C5 6 > /dev/null 2>&1 )
+ls gpurun_out/trace_C4

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 profile set, on the GPU box:   bash tools/profile_round3.sh [what]     what: all | bench | kernels | c2 | rambo | wide
+# Round-3 profile set, on the GPU box:   bash tools/profile_round3.sh [what]     what: all | bench | kernels | train | c2 | rambo | wide
 # Writes gpurun_out/r03_*; copy what should be judged into profiles/.  Counters run in their own passes, without tracing
 # (rocprofv3 --pmc only).  `kernels`: ONE config per rocprofv3 --kernel-trace --stats run, so that per-config kernel timings
 # (apply / statistics / ingest / tail split) are artefacts: r03_kernels_<cfg>.csv.
@@ -27,6 +27,20 @@ if [ $WHAT = all ] || [ $WHAT = kernels ]; then
   cp $OUT/r03_kt_C2/k_kernel_stats.csv $OUT/r03_kernels_C2.csv
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r03_kt_rambo -o k -- python3 tools/run_rambo.py > $OUT/r03_kt_rambo.log 2>&1
   cp $OUT/r03_kt_rambo/k_kernel_stats.csv $OUT/r03_kernels_rambo.csv
+fi
+if [ $WHAT = all ] || [ $WHAT = train ]; then
+  # training legs of bench.py (one optimizer step each): C2 at mbs 1e6, C5 at 2e5, the reference's default regime (5 x 2000 as grid.y)
+  for c in C2 C5 C1_epoch; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r03_kt_train_$c -o k -- python3 tools/run_train_leg.py $c 5 > $OUT/r03_kt_train_$c.log 2>&1
+    cp $OUT/r03_kt_train_$c/k_kernel_stats.csv $OUT/r03_kernels_train_$c.csv
+  done
+  python3 tools/train_probe.py C2 1e6 1 20 both 2>&1 | grep "^C" > $OUT/r03_train_probe.txt
+  python3 tools/train_probe.py C2 4e6 1 10 batched 2>&1 | grep "^C" >> $OUT/r03_train_probe.txt
+  python3 tools/train_probe.py C2 2000 5 50 both 2>&1 | grep "^C" >> $OUT/r03_train_probe.txt
+  python3 tools/train_probe.py C5 2e5 1 5 both 2>&1 | grep "^C" >> $OUT/r03_train_probe.txt
+  python3 tools/train_probe.py C5 2000 5 20 both 2>&1 | grep "^C" >> $OUT/r03_train_probe.txt
+  python3 tools/host_sections.py 2000 5 2>&1 | grep -v "Warn\|amdgpu" >> $OUT/r03_train_probe.txt
+  tools/probe/rambo_traffic 1000000 40 > $OUT/r03_rambo_traffic_probe.txt 2>&1 || true
 fi
 if [ $WHAT = all ] || [ $WHAT = c2 ]; then
   pmc c2_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" python3 tools/run_c2_set.py 20 4
