@@ -33,7 +33,7 @@ extern "C" {
 #define NIS_MAX_DIM     32   /* max flow dimension d (n_flow)                        */
 #define NIS_MAX_HIDDEN  8    /* max hidden layers of a conditioner                    */
 #define NIS_MAX_WIDTH   64   /* max hidden width / pass-through size                  */
-#define NIS_MAX_BINS    128  /* max n_bins for PWLin; PWQuad is limited to 32         */
+#define NIS_MAX_BINS    128  /* max n_bins (PWLin and PWQuad; PWQuad > 32: scratch-array kernels) */
 #define NIS_MAX_CELLS   64
 #define NIS_MAX_LEGS    10   /* RAMBO: max number of final-state particles            */
 
@@ -186,10 +186,9 @@ int nis_flow_forward_sync(nis_flow* f, const void* w, int32_t w_dtype, int32_t w
                           int32_t world, int32_t rank);
 
 /* Training forward + hand-written adjoint (replaces loss.backward() through the flow, manager.py:275-278, for the
- * cell class the adjoint kernels cover: conditioner widths and pass-through size <= 64 (<= 8: fp64 VALU kernels,
- * wider: v_mfma_f64_16x16x4_f64 kernels), PWQuad n_bins <= 32, PWLin any n_bins whose LDS
- * image fits, any number of
- * transformed columns; nis_flow_backward_supported tells).
+ * cell class the adjoint kernels cover: conditioner widths and pass-through size <= 64 -- <= 8: fp64 VALU kernels (PWQuad and
+ * PWLin up to NIS_MAX_BINS bins); wider: v_mfma_f64_16x16x4_f64 kernels (PWQuad n_bins <= 32, PWLin any n_bins whose LDS image
+ * fits) --, any number of transformed columns; nis_flow_backward_supported tells).
  *   nis_flow_forward_train: train-mode forward that keeps every cell's input: planes_hist holds n_cells+1 plane
  *     sets of (d+1, ld) doubles (set c = input of cell c, last set = model output); bnsave
  *     (nis_flow_bnsave_count doubles) receives scale | shift | batch mean | rstd of every BN layer.
