@@ -151,8 +151,8 @@ bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm);
 size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N, int G);
 size_t nis_bwd_cell_params(const nis_cell_desc& cd);
 int nis_bwd_cell_run(const CellK& c, const nis_cell_desc& cd, int wm, const double* x, const double* xo, double* g, const double* bnsave,
-                     long ld, long N, int G, long x_gs, long g_gs, long bn_gs, double* ws, double* gparams, double* gtmp, const MfmaW& mw,
-                     bool eval_bn, hipStream_t s);
+                     long ld, long N, int G, long x_gs, long g_gs, long bn_gs, double* ws, double* gparams, const MfmaW& mw, bool eval_bn,
+                     hipStream_t s);
 
 static bool use_mfma() {
   static const int off = nis_env_int("NIS_NO_MFMA", 0);
@@ -945,16 +945,14 @@ static size_t bwd_pack_doubles(const nis_cell_desc& cd, size_t WM) {
   return n;
 }
 
-// doubles of one call's adjoint scratch: gradient planes of the G minibatches, the largest cell workspace, the packed parameter
-// image, one cell's gradient blob (wide cells run one minibatch at a time and are added up)
-static void bwd_ws_layout(const nis_flow* f, int G, int64_t N, size_t* gplanes, size_t* cellws, size_t* pk, size_t* gtmp) {
+// doubles of one call's adjoint scratch: gradient planes of the G minibatches, the largest cell workspace, the packed parameter image
+static void bwd_ws_layout(const nis_flow* f, int G, int64_t N, size_t* gplanes, size_t* cellws, size_t* pk) {
   std::vector<CellLayout> lay;
   nis_flow_layout(f, 1, &lay, nullptr);
-  *cellws = *pk = *gtmp = 0;
+  *cellws = *pk = 0;
   for (int ci = 0; ci < f->n_cells; ++ci) {
     *cellws = std::max(*cellws, nis_bwd_cell_workspace_doubles(f->cells[ci], lay[ci].WM, N, G));
     *pk = std::max(*pk, bwd_pack_doubles(f->cells[ci], lay[ci].WM));
-    *gtmp = std::max(*gtmp, nis_bwd_cell_params(f->cells[ci]));
   }
   *gplanes = ((size_t)G * (f->d + 1) * N + 15) / 16 * 16;          // 128-byte aligned: the wide adjoint uses vector loads
   *cellws = (*cellws + 15) / 16 * 16;
@@ -963,9 +961,9 @@ static void bwd_ws_layout(const nis_flow* f, int G, int64_t N, size_t* gplanes, 
 
 extern "C" size_t nis_flow_backward_workspace_bytes_batched(const nis_flow* f, int32_t n_batches, int64_t N) {
   if (!f || n_batches < 1 || N < 1) return 0;
-  size_t gp, cw, pk, gt;
-  bwd_ws_layout(f, n_batches, N, &gp, &cw, &pk, &gt);
-  return (gp + cw + pk + gt + 64) * sizeof(double);
+  size_t gp, cw, pk;
+  bwd_ws_layout(f, n_batches, N, &gp, &cw, &pk);
+  return (gp + cw + pk + 64) * sizeof(double);
 }
 extern "C" size_t nis_flow_backward_workspace_bytes(const nis_flow* f, int64_t N) { return nis_flow_backward_workspace_bytes_batched(f, 1, N); }
 
@@ -994,12 +992,11 @@ static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld
   const int d = f->d;
   const long set = (long)(d + 1) * ld;
   const long hist_gs = (long)(f->n_cells + 1) * set;
-  size_t gpl, cw, pkd, gtd;
-  bwd_ws_layout(f, G, N, &gpl, &cw, &pkd, &gtd);
+  size_t gpl, cw, pkd;
+  bwd_ws_layout(f, G, N, &gpl, &cw, &pkd);
   double* g = (double*)workspace;                       // gradient planes (G, d+1, ld)
   double* cellws = g + gpl;
   double* pk = cellws + cw;
-  double* gtmp = pk + pkd;
   std::vector<CellLayout> lay;
   nis_flow_layout(f, 1, &lay, nullptr);
   const int tgrid = nis_grid_for(8, G, N, NIS_TPB);
@@ -1062,7 +1059,7 @@ static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld
       mw.bias_pad = bias_pad;
     }
     int rc = nis_bwd_cell_run(c, cd, L.WM, planes_hist + (size_t)ci * set, planes_hist + (size_t)(ci + 1) * set, g, bnsave + bn_off,
-                              (long)ld, (long)N, G, hist_gs, set, seed.eval_bn ? 0L : (long)bn_total, cellws, gparams[ci], gtmp, mw,
+                              (long)ld, (long)N, G, hist_gs, set, seed.eval_bn ? 0L : (long)bn_total, cellws, gparams[ci], mw,
                               seed.eval_bn, s);
     if (rc != NIS_OK) return rc;
   }

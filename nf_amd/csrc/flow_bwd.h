@@ -31,20 +31,21 @@ struct BwdK {
   long bn_gs;                 // ... between their saved BatchNorm records (0 in eval mode: running statistics, one record)
   const double* prev;         // records of the launch that produced dy of the layer being processed: (G, nprev, BNACC); the consumer
   int nprev, prev_off;        //   merges the 2 WM batch sums at prev_off in its prologue (no reduction launch in between)
+  long part_gs, sums_gs;      // wide adjoint (flow_bwd_wm.hip, minibatch = blockIdx.z): doubles between the minibatches' record areas / reduced sums
 };
 
 // ---- wide conditioners (register width 16 / 32 / 64), one translation unit per width
 template <int WM>
 bool bwd_wide_supported(const nis_cell_desc& cd);
 template <int WM>
-size_t bwd_wide_workspace_doubles(const nis_cell_desc& cd, int64_t N);
+size_t bwd_wide_workspace_doubles(const nis_cell_desc& cd, int64_t N, int G);
 template <int WM>
 int bwd_wide_run(const CellK& c, BwdK k, const MfmaW& mw, double* ws, double* gparams, hipStream_t s);
 #define NIS_DECL_BWD_WM(W)                                                                            \
   template <>                                                                                         \
   bool bwd_wide_supported<W>(const nis_cell_desc& cd);                                                \
   template <>                                                                                         \
-  size_t bwd_wide_workspace_doubles<W>(const nis_cell_desc& cd, int64_t N);                           \
+  size_t bwd_wide_workspace_doubles<W>(const nis_cell_desc& cd, int64_t N, int G);                    \
   template <>                                                                                         \
   int bwd_wide_run<W>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, double* gparams, hipStream_t s);
 NIS_DECL_BWD_WM(16)

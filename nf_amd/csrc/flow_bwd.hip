@@ -14,7 +14,8 @@
 //   input   : BN_0 backward -> gradient of the pass-through columns
 //   finish  : every record of the chain -> the gradient blob in the reference's parameter order (one launch per cell)
 // The G minibatches of an optimizer step (manager.py:219-270: the loss is their mean, ONE backward) are blockIdx.y of every
-// launch: own history planes, own BatchNorm records, own batch sums; the parameter gradient is the sum over all of them.
+// launch (blockIdx.z in the matrix-core chain): own history planes, own BatchNorm records, own batch sums; the parameter gradient is
+// the sum over all of them.
 // A consumer merges the batch sums of its producer's per-workgroup records in its prologue (fixed order: bitwise reproducible),
 // so no reduction launch sits between the links of the chain.
 #include <algorithm>
@@ -623,16 +624,6 @@ __global__ __launch_bounds__(NIS_TPB) void k_bwd_finish(BwdFin f) {
   if (slice == 0 && e < f.nelem) f.gparams[e] = sm[0][el] * mult;
 }
 
-// dst = src (first) or dst += src: the wide adjoint runs one minibatch at a time, its per-minibatch blobs are added up here
-__global__ __launch_bounds__(NIS_TPB) void k_blob_add(double* __restrict__ dst, const double* __restrict__ src, int n, int first) {
-  const int i = blockIdx.x * NIS_TPB + threadIdx.x;
-  if (i < n) dst[i] = first ? src[i] : dst[i] + src[i];
-}
-hipError_t nis_launch_blob_add(double* dst, const double* src, int n, int first, hipStream_t s) {
-  hipLaunchKernelGGL(k_blob_add, dim3((n + NIS_TPB - 1) / NIS_TPB), dim3(NIS_TPB), 0, s, dst, src, n, first);
-  return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------------------------
 bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm) {
   if (wm == 16) return bwd_wide_supported<16>(cd);
@@ -668,9 +659,9 @@ size_t nis_bwd_cell_params(const nis_cell_desc& cd) {
 }
 
 size_t nis_bwd_cell_workspace_doubles(const nis_cell_desc& cd, int wm, int64_t N, int G) {
-  if (wm == 16) return bwd_wide_workspace_doubles<16>(cd, N);       // wide cells run one minibatch at a time
-  if (wm == 32) return bwd_wide_workspace_doubles<32>(cd, N);
-  if (wm == 64) return bwd_wide_workspace_doubles<64>(cd, N);
+  if (wm == 16) return bwd_wide_workspace_doubles<16>(cd, N, G);
+  if (wm == 32) return bwd_wide_workspace_doubles<32>(cd, N, G);
+  if (wm == 64) return bwd_wide_workspace_doubles<64>(cd, N, G);
   const int T = cd.d - cd.P;
   const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K);
   const bool fused = bwd_fused_w(cd, wm);
@@ -768,11 +759,10 @@ static int bwd_run(const CellK& c, BwdK k, const nis_cell_desc& cd, double* ws, 
 }
 
 // One cell's adjoint for G minibatches: x / xo / g / bnsave point at minibatch 0, x_gs / g_gs / bn_gs are the strides between
-// minibatches.  gparams receives the SUM over the minibatches.  Wide cells (matrix-core kernels) run one minibatch at a time
-// into `gtmp` (>= nis_bwd_cell_params doubles) and are added up.
+// minibatches.  gparams receives the SUM over the minibatches (narrow chain: blockIdx.y = minibatch; matrix-core chain: blockIdx.z).
 int nis_bwd_cell_run(const CellK& c, const nis_cell_desc& cd, int wm, const double* x, const double* xo, double* g, const double* bnsave,
-                     long ld, long N, int G, long x_gs, long g_gs, long bn_gs, double* ws, double* gparams, double* gtmp, const MfmaW& mw,
-                     bool eval_bn, hipStream_t s) {
+                     long ld, long N, int G, long x_gs, long g_gs, long bn_gs, double* ws, double* gparams, const MfmaW& mw, bool eval_bn,
+                     hipStream_t s) {
   BwdK k;
   memset(&k, 0, sizeof(k));
   k.c = c;
@@ -790,22 +780,8 @@ int nis_bwd_cell_run(const CellK& c, const nis_cell_desc& cd, int wm, const doub
   k.bn_gs = bn_gs;
   if (wm == 4) return bwd_run<4>(c, k, cd, ws, gparams, s);
   if (wm == 8) return bwd_run<8>(c, k, cd, ws, gparams, s);
-  const int np = (int)nis_bwd_cell_params(cd);
-  for (int gi = 0; gi < G; ++gi) {
-    BwdK kg = k;
-    kg.G = 1;
-    kg.x = x + (size_t)gi * x_gs;
-    kg.xo = xo + (size_t)gi * x_gs;
-    kg.g = g + (size_t)gi * g_gs;
-    kg.bn = bnsave + (size_t)gi * bn_gs;
-    double* out = G == 1 ? gparams : gtmp;
-    int rc;
-    if (wm == 16) rc = bwd_wide_run<16>(c, kg, mw, ws, out, s);
-    else if (wm == 32) rc = bwd_wide_run<32>(c, kg, mw, ws, out, s);
-    else if (wm == 64) rc = bwd_wide_run<64>(c, kg, mw, ws, out, s);
-    else return NIS_E_UNSUPPORTED;
-    if (rc != NIS_OK) return rc;
-    if (G > 1 && nis_launch_blob_add(gparams, gtmp, np, gi == 0, s) != hipSuccess) return NIS_E_HIP;
-  }
-  return NIS_OK;
+  if (wm == 16) return bwd_wide_run<16>(c, k, mw, ws, gparams, s);
+  if (wm == 32) return bwd_wide_run<32>(c, k, mw, ws, gparams, s);
+  if (wm == 64) return bwd_wide_run<64>(c, k, mw, ws, gparams, s);
+  return NIS_E_UNSUPPORTED;
 }

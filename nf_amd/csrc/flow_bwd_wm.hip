@@ -162,6 +162,21 @@ __device__ __forceinline__ void bww_da(const double* __restrict__ wr, const doub
   }
 }
 
+// minibatch g = blockIdx.z of a launch: every per-minibatch pointer of the kernel's own copy of the arguments moves to its set
+__device__ __forceinline__ void bww_batch(BwdK& k, BwdW* w) {
+  const size_t g = blockIdx.z;
+  k.x += g * k.x_gs;
+  k.xo += g * k.x_gs;
+  k.g += g * k.g_gs;
+  k.bn += g * k.bn_gs;
+  k.dyp += g * k.wsp_gs;
+  k.alp += g * k.wsp_gs;
+  k.dzp += g * k.wsp_gs;
+  k.part += g * k.part_gs;
+  if (k.sums) k.sums += g * k.sums_gs;
+  if (w) w->dhp += g * k.wsp_gs;
+}
+
 __device__ __forceinline__ void bww_stage(const BwdK& k, double* lds_bn, int* lds_plane) {
   const int tid = threadIdx.x;
   if (tid < NIS_MAX_DIM) lds_plane[tid] = k.c.in_plane[tid];
@@ -170,13 +185,16 @@ __device__ __forceinline__ void bww_stage(const BwdK& k, double* lds_bn, int* ld
 
 // ---------------------------------------------------------------------------------------------
 // head: recompute the cell, bijector adjoint -> dZ planes, d a_L = W_L^T dZ, dy_L, sums of BN_L, a_L planes
-template <int KIND, int KM, bool KEXACT>
+// BATCH: the launch carries G > 1 minibatches as blockIdx.z.  Moving the kernel's pointers to minibatch g costs 15-30 VGPRs in these
+// kernels (the C5 head goes from 52 to 85 spilled dwords, +13 % on a 2e5 minibatch), so a single minibatch runs the BATCH = false build.
+template <int KIND, int KM, bool KEXACT, bool BATCH>
 __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, BwdW w) {
   extern __shared__ double mf_dyn[];                 // per wave: [NCB*out rows][16 samples] of exp(Z)
   __shared__ double lds_bn[BNLDS];
   __shared__ int lds_plane[NIS_MAX_DIM];
   __shared__ double etab[NIS_EXP_N];
   __shared__ double sm[NW][SREC];
+  if (BATCH) bww_batch(k, &w);
   const CellK& c = k.c;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
   bww_stage(k, lds_bn, lds_plane);
@@ -463,11 +481,13 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
 
 // ---------------------------------------------------------------------------------------------
 // layer l (L..1): BN_l backward -> d h_l planes, a_{l-1} planes, dy_{l-1} = relu'(.) W_{l-1}^T d h_l, sums of BN_{l-1}
+template <bool BATCH>
 __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l) {
   __shared__ double lds_bn[BNLDS];
   __shared__ int lds_plane[NIS_MAX_DIM];
   __shared__ double lds_m[SREC];
   __shared__ double sm[NW][SREC];
+  if (BATCH) bww_batch(k, &w);
   const CellK& c = k.c;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
   bww_stage(k, lds_bn, lds_plane);
@@ -539,6 +559,7 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
 
 // BN_0 backward: gradient of the pass-through columns
 __global__ __launch_bounds__(TPB) void k_bwd_input_w(BwdK k) {
+  bww_batch(k, nullptr);
   const CellK& c = k.c;
   const double invN = k.invN;
   const long stride = (long)gridDim.x * TPB;
@@ -585,8 +606,11 @@ __device__ __forceinline__ void xty_load(const double* __restrict__ Ap, int FA, 
 }
 
 __global__ __launch_bounds__(TPB, 2) void k_bwd_xty_w(const double* __restrict__ Ap, int FA, int R, const double* __restrict__ Bp, long N,
-                                                      double* __restrict__ part) {
+                                                      double* __restrict__ part, long wsp_gs, long part_gs) {
   __shared__ double sm[GREC];
+  Ap += (size_t)blockIdx.z * wsp_gs;                 // minibatch g = blockIdx.z: its planes, its record area
+  Bp += (size_t)blockIdx.z * wsp_gs;
+  part += (size_t)blockIdx.z * part_gs;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
   const int rb = blockIdx.y * RPW * 16;
   nis_d4 acc[RPW][JT];
@@ -643,11 +667,13 @@ __global__ __launch_bounds__(TPB, 2) void k_bwd_xty_w(const double* __restrict__
 }
 
 // records -> their sum: a workgroup owns 4 elements, 64 slices of the records each; fixed order (bitwise reproducible)
-__global__ __launch_bounds__(TPB) void k_bwd_reduce_w(const double* __restrict__ part, int nparts, int nacc, double* __restrict__ out) {
+__global__ __launch_bounds__(TPB) void k_bwd_reduce_w(const double* __restrict__ part, int nparts, int nacc, double* __restrict__ out, long part_gs,
+                                                      long out_gs) {
   __shared__ double sm[64][4];
   const int el = threadIdx.x & 3, slice = threadIdx.x >> 2;
   const int e = blockIdx.x * 4 + el;
-  part += (size_t)blockIdx.y * nparts * nacc;
+  part += (size_t)blockIdx.z * part_gs + (size_t)blockIdx.y * nparts * nacc;
+  out += (size_t)blockIdx.z * out_gs;
   double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
   if (e < nacc) {
     int b = slice;
@@ -672,33 +698,40 @@ __global__ __launch_bounds__(TPB) void k_bwd_reduce_w(const double* __restrict__
 //   sums : pass p (0 = head, L - l + 1 = layer kernel l) holds the sums of BN_{L-p}: [sum dy | sum dy xhat]
 //   glast: GEMM result of the last Linear (row groups of GREC); ghid + m*ngh*GREC: of hidden Linear m
 // hidden_bias (NIS_AFFINE): 1 = train-mode BatchNorm, 2 = eval mode (`bn`: the saved scale | shift | mean | rstd records).
+// G minibatches: minibatch g's reduced records sit sums_gs / gl_gs doubles behind minibatch g - 1's; the blob receives their SUM.
 __global__ void k_bwd_scatter_w(CellK c, const double* __restrict__ sums, const double* __restrict__ glast,
                                 const double* __restrict__ ghid, int ngh, double* __restrict__ gparams, int hidden_bias,
-                                const double* __restrict__ bn) {
+                                const double* __restrict__ bn, int G, long sums_gs, long gl_gs) {
   const int L = c.L, tid = threadIdx.x, nth = blockDim.x;
+  auto over_g = [&](const double* p, long gs) {
+    double t = 0.0;
+    for (int g = 0; g < G; ++g) t += p[(size_t)g * gs];
+    return t;
+  };
   size_t off = 0;
   for (int l = 0; l <= L; ++l) {
     const int F = cellk_feat(c, l);
     const int O = l < L ? c.width[l] : c.R;
     const double* sl = sums + (size_t)(L - l) * SREC;
     for (int j = tid; j < F; j += nth) {
-      gparams[off + j] = sl[WM + j];
-      gparams[off + F + j] = sl[j];
+      gparams[off + j] = over_g(sl + WM + j, sums_gs);
+      gparams[off + F + j] = over_g(sl + j, sums_gs);
     }
     off += 2 * (size_t)F;
     const double* src = l < L ? ghid + (size_t)l * ngh * GREC : glast;
     for (int e = tid; e < O * F; e += nth) {
       const int r = e / F, q = e % F;
-      gparams[off + e] = src[(size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + q];
+      gparams[off + e] = over_g(src + (size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + q, gl_gs);
     }
     off += (size_t)O * F;
     if (hidden_bias && l < L) {          // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0;
-      const double* s1 = sums + (size_t)(L - l - 1) * SREC;      // eval mode: scale_{l+1} * sum dy_{l+1}
-      for (int e = tid; e < O; e += nth) gparams[off + e] = hidden_bias == 2 ? bn[((l + 1) * 4 + 0) * WM + e] * s1[e] : 0.0;
+      const double* s1 = sums + (size_t)(L - l - 1) * SREC;      // eval mode: scale_{l+1} * sum dy_{l+1}  (one BatchNorm record for all minibatches)
+      for (int e = tid; e < O; e += nth) gparams[off + e] = hidden_bias == 2 ? bn[((l + 1) * 4 + 0) * WM + e] * over_g(s1 + e, sums_gs) : 0.0;
       off += O;
     }
   }
-  for (int r = tid; r < c.R; r += nth) gparams[off + r] = glast[(size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + WM];
+  for (int r = tid; r < c.R; r += nth)
+    gparams[off + r] = over_g(glast + (size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + WM, gl_gs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -725,16 +758,16 @@ struct Plan {
   size_t part;       // doubles of the shared record area
 };
 
-Plan plan_for(int R, long N) {
+Plan plan_for(int R, long N, int G) {         // the G minibatches of a launch (blockIdx.z) share the chip
   Plan p;
   const int cus = device_cus();
   const long per_wg = (long)NW * 16 * ST;
-  p.nb = (int)std::max<long>(1, std::min<long>((N + per_wg - 1) / per_wg, (long)cus * 2));
+  p.nb = (int)std::max<long>(1, std::min<long>((N + per_wg - 1) / per_wg, std::max<long>(1, (long)cus * 2 / G)));
   p.ngl = groups_of(R);
   p.ngh = groups_of(WM);
   const long tiles_wg = ((N + 15) / 16 + NW - 1) / NW;
-  p.nxl = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 2 / p.ngl)));      // 2 resident workgroups per CU
-  p.nxh = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 2 / p.ngh)));
+  p.nxl = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 2 / (p.ngl * G))));      // 2 resident workgroups per CU
+  p.nxh = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 2 / (p.ngh * G))));
   p.part = std::max<size_t>((size_t)p.nb * SREC, std::max((size_t)p.ngl * p.nxl, (size_t)p.ngh * p.nxh) * GREC);
   return p;
 }
@@ -749,36 +782,49 @@ bool bwd_wide_supported<NIS_WM>(const nis_cell_desc& cd) {
 }
 
 template <>
-size_t bwd_wide_workspace_doubles<NIS_WM>(const nis_cell_desc& cd, int64_t N) {
+size_t bwd_wide_workspace_doubles<NIS_WM>(const nis_cell_desc& cd, int64_t N, int G) {
   const int T = cd.d - cd.P;
   const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K);
-  const Plan p = plan_for(R, (long)N);
-  return (size_t)(3 * WM + R) * ldw_of((long)N) + p.part + (size_t)(cd.n_hidden + 2) * SREC + (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC;
+  const Plan p = plan_for(R, (long)N, G);
+  return (size_t)G * ((size_t)(3 * WM + R) * ldw_of((long)N) + p.part + (size_t)(cd.n_hidden + 2) * SREC + (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC);
 }
 
 template <>
 int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, double* gparams, hipStream_t s) {
   const long N = k.N;
-  const int L = c.L;
-  const Plan p = plan_for(c.R, N);
+  const int L = c.L, G = std::max(1, k.G);
+  const Plan p = plan_for(c.R, N, G);
   BwdW w;
   w.wm_all = mw.wm_all;
   w.wm_last = mw.wm_last;
   w.bias_pad = mw.bias_pad;
   const long ldw = ldw_of(N);                      // workspace planes: 16-sample aligned rows (vector loads in the GEMM)
+  // per minibatch (blockIdx.z): planes [dy | a | dh | dZ], then -- behind the planes of all minibatches -- the record areas, the
+  // reduced BatchNorm sums and the reduced GEMM results, each G sets
+  const size_t wsp = (size_t)(3 * WM + c.R) * ldw;
+  const size_t nsum = (size_t)(L + 2) * SREC, ngem = (size_t)(p.ngl + L * p.ngh) * GREC;
   k.ldw = ldw;
+  k.wsp_gs = (long)wsp;
+  k.part_gs = (long)p.part;
+  k.sums_gs = (long)nsum;
   k.dyp = ws;
   k.alp = ws + (size_t)WM * ldw;
   w.dhp = ws + (size_t)2 * WM * ldw;
   k.dzp = ws + (size_t)3 * WM * ldw;
-  double* part = k.dzp + (size_t)c.R * ldw;
-  double* sums = part + p.part;
-  double* glast = sums + (size_t)(L + 2) * SREC;
+  double* part = ws + (size_t)G * wsp;
+  double* sums = part + (size_t)G * p.part;
+  double* glast = sums + (size_t)G * nsum;                 // minibatch g: glast + g * ngem, its hidden-layer results ngl * GREC behind
   double* ghid = glast + (size_t)p.ngl * GREC;
   k.part = part;
+  k.sums = nullptr;
   const size_t ring = ring_bytes(c.out);
   const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : c.K <= 16 ? 16 : 32;
-#define NIS_HEAD(KIND, KMV, EX) hipLaunchKernelGGL((k_bwd_head_w<KIND, KMV, EX>), dim3(p.nb), dim3(TPB), ring, s, k, w)
+  const unsigned Gz = (unsigned)G;
+#define NIS_HEAD(KIND, KMV, EX)                                                                                        \
+  do {                                                                                                                 \
+    if (G > 1) hipLaunchKernelGGL((k_bwd_head_w<KIND, KMV, EX, true>), dim3(p.nb, 1, Gz), dim3(TPB), ring, s, k, w);    \
+    else hipLaunchKernelGGL((k_bwd_head_w<KIND, KMV, EX, false>), dim3(p.nb, 1, 1), dim3(TPB), ring, s, k, w);         \
+  } while (0)
   if (c.kind == NIS_PWLIN)
     NIS_HEAD(NIS_PWLIN, 4, false);
   else if (c.kind == NIS_AFFINE)
@@ -798,28 +844,30 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   else
     NIS_HEAD(NIS_PWQUAD, 32, false);
 #undef NIS_HEAD
-  hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + 3) / 4, 1), dim3(TPB), 0, s, (const double*)part, p.nb, SREC, sums);
+  hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + 3) / 4, 1, Gz), dim3(TPB), 0, s, (const double*)part, p.nb, SREC, sums, (long)p.part, (long)nsum);
   // dW_L = dZ a_L^T, db_L = row sums of dZ
-  hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.ngl), dim3(TPB), 0, s, (const double*)k.dzp, c.R, c.R, (const double*)k.alp, N, part);
-  hipLaunchKernelGGL(k_bwd_reduce_w, dim3((GREC + 3) / 4, p.ngl), dim3(TPB), 0, s, (const double*)part, p.nxl, GREC, glast);
+  hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.ngl, Gz), dim3(TPB), 0, s, (const double*)k.dzp, c.R, c.R, (const double*)k.alp, N, part, (long)wsp,
+                     (long)p.part);
+  hipLaunchKernelGGL(k_bwd_reduce_w, dim3((GREC + 3) / 4, p.ngl, Gz), dim3(TPB), 0, s, (const double*)part, p.nxl, GREC, glast, (long)p.part, (long)ngem);
   for (int l = L; l >= 1; --l) {
     const int pass = L - l + 1;
     k.sums = sums + (size_t)(pass - 1) * SREC;
-    hipLaunchKernelGGL(k_bwd_layer_w, dim3(p.nb), dim3(TPB), 0, s, k, w, l);
-    hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + 3) / 4, 1), dim3(TPB), 0, s, (const double*)part, p.nb, SREC,
-                       sums + (size_t)pass * SREC);
+    if (G > 1) hipLaunchKernelGGL(k_bwd_layer_w<true>, dim3(p.nb, 1, Gz), dim3(TPB), 0, s, k, w, l);
+    else hipLaunchKernelGGL(k_bwd_layer_w<false>, dim3(p.nb, 1, 1), dim3(TPB), 0, s, k, w, l);
+    hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + 3) / 4, 1, Gz), dim3(TPB), 0, s, (const double*)part, p.nb, SREC, sums + (size_t)pass * SREC,
+                       (long)p.part, (long)nsum);
     // dW_{l-1} = d h_l a_{l-1}^T
-    hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxh, p.ngh), dim3(TPB), 0, s, (const double*)w.dhp, WM, c.width[l - 1], (const double*)k.alp,
-                       N, part);
-    hipLaunchKernelGGL(k_bwd_reduce_w, dim3((GREC + 3) / 4, p.ngh), dim3(TPB), 0, s, (const double*)part, p.nxh, GREC,
-                       ghid + (size_t)(l - 1) * p.ngh * GREC);
+    hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxh, p.ngh, Gz), dim3(TPB), 0, s, (const double*)w.dhp, WM, c.width[l - 1], (const double*)k.alp, N, part,
+                       (long)wsp, (long)p.part);
+    hipLaunchKernelGGL(k_bwd_reduce_w, dim3((GREC + 3) / 4, p.ngh, Gz), dim3(TPB), 0, s, (const double*)part, p.nxh, GREC,
+                       ghid + (size_t)(l - 1) * p.ngh * GREC, (long)p.part, (long)ngem);
   }
   k.sums = sums + (size_t)L * SREC;
   {
-    const int gi = (int)std::max<long>(1, std::min<long>((N + TPB - 1) / TPB, (long)device_cus() * 8));
-    hipLaunchKernelGGL(k_bwd_input_w, dim3(gi), dim3(TPB), 0, s, k);
+    const int gi = (int)std::max<long>(1, std::min<long>((N + TPB - 1) / TPB, std::max<long>(1, (long)device_cus() * 8 / G)));
+    hipLaunchKernelGGL(k_bwd_input_w, dim3(gi, 1, Gz), dim3(TPB), 0, s, k);
   }
   hipLaunchKernelGGL(k_bwd_scatter_w, dim3(1), dim3(TPB), 0, s, c, (const double*)sums, (const double*)glast, (const double*)ghid, p.ngh,
-                     gparams, c.kind == NIS_AFFINE ? (k.invN == 0.0 ? 2 : 1) : 0, k.bn);
+                     gparams, c.kind == NIS_AFFINE ? (k.invN == 0.0 ? 2 : 1) : 0, k.bn, G, (long)nsum, (long)ngem);
   return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
 }
