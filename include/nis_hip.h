@@ -54,8 +54,9 @@ enum {
  * NIS_F_CAMEL : README.md:35-36   exp(-|x-.75|^2/s^2)+exp(-|x-.25|^2/s^2), p0=0.75 p1=0.25 p2=0.2 (2 columns)
  * NIS_F_NORMAL: manager.py:39-40  exp(-sum (x-mu)^2/(2 sigma^2))/(sigma sqrt((2pi)^d)), p0=mu p1=sigma
  * NIS_F_ONE   : f == 1 (integrates the Jacobian; mean J -> 1)
+ * NIS_F_NONE  : nis_integrate_steps[_rng] only, with keep_planes: no integrand, X / J stay in the planes for a caller-side f
  */
-enum { NIS_F_CAMEL = 0, NIS_F_NORMAL = 1, NIS_F_ONE = 2 };
+enum { NIS_F_NONE = -1, NIS_F_CAMEL = 0, NIS_F_NORMAL = 1, NIS_F_ONE = 2 };
 
 /* One coupling cell (PWLin: layers/coupling_cells.py:73-142, PWQuad: :144-228, AffineCoupling: :6-70; K is
  * ignored for NIS_AFFINE, whose conditioner has 2 outputs per transformed column laid out [scale|shift][T]) with its
@@ -129,7 +130,10 @@ int nis_flow_forward(nis_flow* f, const void* w, int32_t w_dtype, int32_t w_has_
  *   w     (n_batches, N, d) row-major;  planes (n_batches, d+1, ld);  out4 (n_batches, 4) = {count, mean, M2, max}
  * The built-in integrand f(X)*J is evaluated inside the last cell's kernel.  keep_planes == 0: X and J are
  * never written (nothing reads them); fres_out (n_batches, N) optional.  Running statistics receive the
- * n_batches momentum updates in batch order.  Workspace: nis_flow_workspace_bytes(f, n_batches). */
+ * n_batches momentum updates in batch order.  Workspace: nis_flow_workspace_bytes(f, n_batches).
+ * f_kind == NIS_F_NONE (-1) with keep_planes != 0: no integrand -- the call only leaves X and J of the n_batches iterations in
+ * `planes` (out4 is not written and may be NULL): the flow part of integrate()'s loop for an arbitrary caller-side f
+ * (manager.py:397-400 with a Python callable), still one launch set for all iterations, with the draw inside in the _rng form. */
 int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_batches, int64_t N,
                         const double* const* params, double* const* running, long long* const* tracked,
                         int32_t bn_mode, int64_t pack_token, int32_t f_kind, const double* f_params_host,

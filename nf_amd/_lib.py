@@ -17,6 +17,7 @@ NIS_PWLIN, NIS_PWQUAD, NIS_AFFINE = 0, 1, 2
 NIS_BN_EVAL, NIS_BN_TRAIN = 0, 1
 NIS_F64, NIS_F32 = 0, 1
 NIS_F_CAMEL, NIS_F_NORMAL, NIS_F_ONE = 0, 1, 2
+NIS_F_NONE = -1        # integrate_steps*: no integrand, X / J kept in the planes for a caller-side f
 NIS_RAMBO_PDF_ACTIVE, NIS_RAMBO_TAU, NIS_RAMBO_LAB_BOOST = 1, 2, 4
 
 ERRORS = {-1: "invalid argument", -2: "configuration outside the compiled kernel set",

@@ -751,14 +751,15 @@ extern "C" int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, 
                                    int64_t pack_token, int32_t f_kind, const double* f_params_host, double* planes, int64_t ld,
                                    int32_t keep_planes, double* fres_out, double* out4, void* workspace, size_t workspace_bytes,
                                    void* stream) {
-  if (!out4 || f_kind < 0) return NIS_E_ARG;
+  // f_kind < 0 (NIS_F_NONE): no integrand -- the G iterations only leave X and J in `planes` (keep_planes) for a caller-side f
+  if (f_kind < 0 ? (!keep_planes || !planes || fres_out) : !out4) return NIS_E_ARG;
   if (f_kind == NIS_F_CAMEL && f && f->d < 2) return NIS_E_ARG;
   RunOpts o;
   o.G = n_batches;
   o.bn_mode = bn_mode;
   o.pack_token = pack_token;
   o.tracked = tracked;
-  o.f_kind = f_kind;
+  o.f_kind = f_kind < 0 ? -1 : f_kind;
   o.f_params = f_params_host;
   o.fres_out = fres_out;
   o.out4 = out4;
@@ -771,14 +772,14 @@ extern "C" int nis_integrate_steps_rng(nis_flow* f, int32_t n_batches, int64_t N
                                        const double* f_params_host, uint64_t seed, uint64_t stream0, uint64_t* rng_state, float* w_out,
                                        double* planes, int64_t ld, int32_t keep_planes, double* out4, void* workspace,
                                        size_t workspace_bytes, void* stream) {
-  if (!out4 || f_kind < 0) return NIS_E_ARG;
+  if (f_kind < 0 ? (!keep_planes || !planes) : !out4) return NIS_E_ARG;      // NIS_F_NONE: see nis_integrate_steps
   if (f_kind == NIS_F_CAMEL && f && f->d < 2) return NIS_E_ARG;
   RunOpts o;
   o.G = n_batches;
   o.bn_mode = bn_mode;
   o.pack_token = pack_token;
   o.tracked = tracked;
-  o.f_kind = f_kind;
+  o.f_kind = f_kind < 0 ? -1 : f_kind;
   o.f_params = f_params_host;
   o.out4 = out4;
   o.keep_planes = keep_planes;

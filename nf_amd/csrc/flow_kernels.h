@@ -541,7 +541,8 @@ __global__ __launch_bounds__(TPB) void k_bn_stats_fold(CellK c, const double* __
   auto first_loads = [&]() {
     x_first = wbase < N ? sample(wbase, 0) : 0.0;
 #pragma unroll
-    for (int u = 0; u < U; ++u) xr[u] = load_raw(full ? wbase + u * stride : 0, lane);       // not full: a valid address, unused
+    for (int u = 0; u < U; ++u) xr[u] = load_raw(full ? wbase + u * stride : 0, full ? lane : 0);   // not full: element 0 for every lane (valid, unused;
+                                                                                                   // `lane` there read up to 63 elements past a batch of < 64 samples)
   };
   load_coefs<WM, TPB>(c, g, LAYER, c.pmerge ? cellk_fresh(c, LAYER) : -1, blockIdx.x == 0, lds_coef, red, first_loads);
   fold_coefs<WM>(c, lds_coef, LAYER, w_fold);

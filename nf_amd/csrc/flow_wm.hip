@@ -213,10 +213,11 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
   const bool rows = c.wrows && c.xb_wcol >= 0;           // transformed input (and maybe the pass-through one) from the rows of w
   if (c.wrows && c.x_wcol >= 0 && !rows) return hipErrorInvalidValue;
   if (rows && (c.first != 0) != (c.x_wcol >= 0)) return hipErrorInvalidValue;   // row kernels: first cell <=> both inputs in w
-  if (c.wx == 3 && c.kind == NIS_PWQUAD && km < 0 && c.P == 1 && c.T == 1 && c.L == 3 && c.fold && c.out_off != 0 && !rows && !bins && !fz.fres && fz.kind < 0 &&
+  if (c.wx == 3 && c.kind == NIS_PWQUAD && km < 0 && c.P == 1 && c.T == 1 && c.L == 3 && c.fold && !rows && !bins && !fz.fres && fz.kind < 0 &&
       fz.write_planes && !nis_env_int_wm("NIS_NO_SPEC_HIST")) {
-    // the same two cells in the training forward (history: outputs to the next plane set): 3 = next-cell rider, 4 = last cell
-    const int spec = (c.next_P == 1 && c.next_src[0] == 1) ? 3 : c.next_P == 0 ? 4 : 0;
+    // the same two cells in the training forward (history: outputs to the next plane set): 3 = next-cell rider, 4 = last cell; 4 also
+    // in place (out_off == 0): the last cell of an integrate() set that keeps X and J for a caller-side integrand (NIS_F_NONE)
+    const int spec = (c.next_P == 1 && c.next_src[0] == 1) ? (c.out_off != 0 ? 3 : 0) : c.next_P == 0 ? 4 : 0;
 #define NIS_APPLY3H(KMV, SP) \
   hipLaunchKernelGGL((k_cell_apply<NIS_PWQUAD, NIS_WM, KMV, true, 3, SP>), dim3(grid, c.Gy), dim3(NIS_TPB), 0, s, c, planes, ld, N, bn_train, bins, fz)
     if (spec == 3) {

@@ -493,7 +493,7 @@ class FlowEngine:
             rc = self.L.nis_integrate_steps(self.handle, w2.data_ptr(), _lib.NIS_F32 if w2.dtype == torch.float32 else _lib.NIS_F64,
                                             G, N, pp, rp, tp, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL, token, f_kind, fp,
                                             planes.data_ptr() if planes is not None else None, N, 1 if keep else 0,
-                                            fres.data_ptr() if want_fres else None, out4.data_ptr(), ws.data_ptr(), wsb,
+                                            fres.data_ptr() if want_fres else None, out4.data_ptr() if out4 is not None else None, ws.data_ptr(), wsb,
                                             _lib.stream_ptr(dev))
         _lib.check(rc, "nis_integrate_steps")
         if train:
@@ -561,7 +561,7 @@ class FlowEngine:
                                                 rng_state.data_ptr() if rng_state is not None else None,
                                                 w_out.data_ptr() if w_out is not None else None,
                                                 planes.data_ptr() if planes is not None else None, N, 1 if keep_planes else 0,
-                                                out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+                                                out4.data_ptr() if out4 is not None else None, ws.data_ptr(), wsb, _lib.stream_ptr(dev))
         _lib.check(rc, "nis_integrate_steps_rng")
         if train:
             self._stats_bump(1)

@@ -439,6 +439,8 @@ class BasicManager(ModelAPI):
 
     minibatches_per_call = 4096  # training: upper bound on the minibatches of one optimizer step carried by one fused call
     batch_iterations = 20      # integrate(): iterations fused into one launch set (independent BN batches)
+    batch_callable = True      # integrate() with a Python callable: the flow part of G iterations as one launch set (False: one
+                               # forward per iteration with a materialised (N, d+1) XJ, the round-1 path kept for A/B tests)
     fused_minibatch = True     # training: forward -> integrand -> loss bookkeeping -> adjoint as library calls only (False: the piecewise
                                # path through torch's autograd graph, kept for A/B tests and for models outside the adjoint kernels' class)
 
@@ -506,6 +508,38 @@ class BasicManager(ModelAPI):
             if not f.check_status(status):                 # the ONE host read of the call
                 return out
             # some sample had x1 == x2: the reference skips the lab boost for that WHOLE batch -- redo batch by batch below
+        if flow and fusable and not planar and self._stock_input() and self.batch_callable:
+            # Any Python callable (the reference's README form, manager.py:397-400): the FLOW part of G iterations is still one launch
+            # set with the draw inside (NIS_F_NONE: X and J stay in the column planes, nothing else is written); f then sees X of
+            # one iteration at a time, as in the reference's loop -- a (neval, d) float64 view of the planes (like the reference's
+            # XJ[:, :-1] it is not contiguous), and one reduction launch pair turns f(X) * J into the moment record.
+            eng = model.engine()
+            d = eng.d
+            G = max(1, min(int(self.batch_iterations), nitn, max(1, (1 << 27) // max(1, neval * (d + 1)))))
+            key = ("callable", G, d, neval, str(dev))
+            if getattr(self, "_planar_key", None) != key:
+                self._planar_key = key
+                self._planar_buf = (None, torch.empty((G, d + 1, neval), dtype=torch.double, device=dev), None)
+            planes = self._planar_buf[1]
+            identity = list(eng.out_col) == list(range(d))
+            cols = None if identity else torch.as_tensor(eng.out_col, device=dev)
+            if in_kernel:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            i = 0
+            with torch.no_grad():
+                while i < nitn:
+                    g = min(G, nitn - i)
+                    if in_kernel:
+                        eng.integrate_steps_rng(g, neval, dev, _lib.NIS_F_NONE, [], None, seed, i, train=model.training,
+                                                planes=planes[:g], keep_planes=True)
+                    else:
+                        w = torch.stack([self._uniform(neval, dev, torch.float32, "integrate") for _ in range(g)])
+                        eng.integrate_steps(w, model.training, _lib.NIS_F_NONE, [], None, planes=planes[:g])
+                    for gi in range(g):
+                        X = planes[gi, :d].t() if identity else planes[gi].index_select(0, cols).t()
+                        out[i + gi] = hip_moments(f(X), planes[gi, d])
+                    i += g
+            return out
         for i in range(nitn):
             w = self._uniform(neval, dev, torch.float32, "integrate")
             if planar:                      # e.g. RAMBO weight: reads the flow's column planes, X is never assembled

@@ -2002,3 +2002,40 @@ def test_bench_topology_flow_into_rambo_moments_at_2e5_vs_oracle(tag, g_wide):
     np.testing.assert_allclose(got[2], ((v - v.mean()) ** 2).sum(), rtol=1e-7)
     np.testing.assert_allclose(got[3], v.max(), rtol=1e-8)
     assert (v > 0).mean() > 0.01                              # the cuts leave a populated sample
+
+
+@pytest.mark.parametrize("shape", [dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3]), dict(kind="pwquad", d=5, n_cells=3, K=6, NN=[8, 8]),
+                                   dict(kind="pwlin", d=4, P=2, n_cells=3, K=16, NN=[16, 16], roll=2)])
+def test_integrate_with_a_python_callable_batched_flow_equals_one_forward_per_iteration(shape):
+    """integrate(f, ...) with an arbitrary callable: the flow part of G iterations as ONE launch set that keeps X / J in the column planes
+    (NIS_F_NONE) against the per-iteration path (one forward + materialised XJ per iteration) on the same draws: moment records,
+    the combined estimate and the running statistics left behind."""
+    import copy
+    torch.manual_seed(21)
+    A = build_manager(shape)
+    A.best_model = A._model
+    A._model.train()
+    B = build_manager(shape)
+    B._model.load_state_dict(copy.deepcopy(A._model.state_dict()))
+    B.best_model = B._model
+    B._model.train()
+    d, N, nitn = shape["d"], 30_011, 7
+
+    def f(x):
+        assert x.dim() == 2 and x.shape[1] == d and x.dtype == torch.double
+        return torch.exp(-((x - 0.45) ** 2).sum(-1) * 4.0) + 0.05 * x[:, 0]
+
+    g = torch.Generator().manual_seed(3)
+    draws = [torch.rand(N, d, generator=g, dtype=torch.float32) * (1 - 2 ** -24) for _ in range(nitn)]
+    A.batch_iterations = 3                      # sets of 3, 3, 1
+    A.sample_hook = Replay([x.numpy() for x in draws])
+    B.batch_callable = False
+    B.sample_hook = Replay([x.numpy() for x in draws])
+    ma = t2n(A.moments_batches(f, nitn, N, dev()))
+    mb = t2n(B.moments_batches(f, nitn, N, dev()))
+    np.testing.assert_allclose(ma, mb, rtol=1e-11)
+    for (ka, va), (kb, vb) in zip(A._model.state_dict().items(), B._model.state_dict().items()):
+        np.testing.assert_allclose(t2n(va), t2n(vb), rtol=1e-12, atol=1e-15, err_msg=ka)
+    A.sample_hook = None                        # and with the draw inside the launch set
+    sig, err = A.integrate(f, 4, 50_000, 0)
+    assert np.isfinite(float(sig)) and float(err) > 0
