@@ -2039,3 +2039,14 @@ def test_integrate_with_a_python_callable_batched_flow_equals_one_forward_per_it
     A.sample_hook = None                        # and with the draw inside the launch set
     sig, err = A.integrate(f, 4, 50_000, 0)
     assert np.isfinite(float(sig)) and float(err) > 0
+
+
+def test_no_access_past_the_end_of_caller_buffers():
+    """tools/guard_check.py: inputs, kept planes and outputs of the main entry points placed at the very end of their own allocator
+    segment, small and ragged batch sizes (a prefetch past a batch of fewer than 64 samples once read off the end of `w`).  A memory
+    fault aborts the process, hence the subprocess."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "guard_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "GUARD_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
