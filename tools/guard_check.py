@@ -1,7 +1,8 @@
 """Over-read / over-write probe: every caller-owned buffer of the main entry points is a view at the very END of its own 16 MiB
 allocation (an exact-size allocator segment), so an access past the buffer's last element leaves the segment -- small and ragged batch
 sizes, where prefetching kernels are most likely to run off the end.  A memory fault aborts the process: tests run this script in a
-subprocess and look for GUARD_OK.   python tools/guard_check.py"""
+subprocess and look for GUARD_OK.   python tools/guard_check.py [1|2]     2: torch.empty itself hands out segment-end views, so the
+buffers the Python layer allocates (workspaces, state planes, history, records, gradient blobs) are covered as well."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,7 +24,7 @@ def tail(shape, dtype, fill=None):
         n *= s
     nbytes = n * torch.empty((), dtype=dtype).element_size()
     pad = (-nbytes) % 16                                   # keep the start 16-byte aligned (the vector-load paths check alignment)
-    big = torch.empty(SEG, dtype=torch.uint8, device=dev)
+    big = _orig_empty(SEG, dtype=torch.uint8, device=dev)
     _keep.append(big)
     t = big[SEG - nbytes - pad:SEG - pad].view(dtype).view(shape) if pad else big[SEG - nbytes:].view(dtype).view(shape)
     if fill == "rand":
@@ -39,8 +40,33 @@ def sync(msg):
     print("ok", msg, flush=True)
 
 
+_orig_empty = torch.empty
+
+
+def guarded_empty(*size, **kw):
+    """torch.empty for CUDA tensors below 4 MiB as a view at the end of its own 16 MiB segment: the library-owned buffers of the
+    Python layer (workspaces, state planes, history, records, gradient blobs) get the same treatment as the caller's."""
+    dev_ = kw.get("device")
+    shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+    dtype = kw.get("dtype") or torch.get_default_dtype()
+    if dev_ is None or torch.device(dev_).type != "cuda" or any(k not in ("device", "dtype") for k in kw):
+        return _orig_empty(*size, **kw)
+    n = 1
+    for s_ in shape:
+        n *= int(s_)
+    nbytes = n * _orig_empty((), dtype=dtype).element_size()
+    if nbytes == 0 or nbytes > (4 << 20):
+        return _orig_empty(*size, **kw)
+    pad = (-nbytes) % 16
+    big = _orig_empty(SEG, dtype=torch.uint8, device=dev_)
+    return big[SEG - nbytes - pad:SEG - pad].view(dtype).view(shape)
+
+
+PASS = 1 if len(sys.argv) < 2 else int(sys.argv[1])
+if PASS == 2:
+    torch.empty = guarded_empty
 torch.manual_seed(0)
-sizes = (2, 3, 5, 63, 64, 65, 127, 257)
+sizes = (2, 3, 5, 63, 64, 65, 127, 257) if PASS == 1 else (2, 3, 65, 130)
 f = integrands.Camel()
 # 1 + 2: the d = 2 SPEC class, fed draws at a segment end; kept planes at a segment end (caller-side integrand form)
 NF = PWQuadManager(n_flow=2); NF.create_model(2, 4, [3] * 3)
