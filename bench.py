@@ -397,6 +397,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4 / C5 legs")
     args = ap.parse_args()
+    # stdout carries ONE JSON line: file descriptor 1 points at stderr until that line is printed, so that nothing a native library
+    # writes there (gloo's "[Gloo] Rank 0 is connected ..." in rehearsals, RCCL / ROCr notices) can get in front of it
+    sys.stdout.flush()
+    fd_out = os.dup(1)
+    os.dup2(2, 1)
     rank, ws, local = init_from_env("nccl")
     if ws != args.gpus and ws > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}")
@@ -443,9 +448,13 @@ def main():
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
         with contextlib.redirect_stdout(sys.stderr):
             line["cpu_baseline"] = cpu_baseline()
+    sys.stdout.flush()
+    os.dup2(fd_out, 1)
+    os.close(fd_out)
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if ws > 1:
+        os.dup2(2, 1)                                      # (teardown messages of the process group: not on stdout either)
         dist.destroy_process_group()
 
 
