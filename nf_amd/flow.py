@@ -591,6 +591,22 @@ class FlowEngine:
             self._plans = cache = (key, IntegratePlan(self, G, N, dev, f_kind, f_params))
         return cache[1]
 
+    def train_plan(self, G, N, dev, f, maxf, preburn, est):
+        """Cached TrainPlan (two captured graphs) for this set size, integrand, loss form and the CURRENT addresses of the model's blobs."""
+        for c in self.cells:
+            ensure_flat(c, dev)
+        key = (int(G), int(N), str(torch.device(dev)), int(f.nis_kind), tuple(float(x) for x in f.nis_params), bool(preburn), bool(est),
+               maxf.data_ptr(), tuple((c._flat.data_ptr(), c._running.data_ptr(), c._tracked.data_ptr()) for c in self.cells))
+        cache = getattr(self, "_train_plans", None)
+        if cache is None:
+            cache = self._train_plans = {}
+        plan = cache.get(key)
+        if plan is None:
+            if len(cache) >= 4:                          # preburn / est / set-size variants of one training run; older ones are dropped
+                cache.clear()
+            plan = cache[key] = TrainPlan(self, G, N, dev, f, maxf, preburn, est)
+        return plan
+
     def resident_status(self, dev):
         """Raise if a hand-off of the persistent kernel timed out (status bit 1; synchronises)."""
         if self._ws is not None and int(self._ws[:4].view(torch.int32)[0].item()) & 2:
@@ -670,6 +686,116 @@ class IntegratePlan:
         else:
             self._call(self.N)
         dst.copy_(self.out)
+
+
+class TrainPlan:
+    """The library calls of ONE optimizer step -- G minibatches of N samples: forward with history + loss bookkeeping, and the adjoint
+    seeded by the losses -- as TWO captured hipGraphs (replayed from `_HipEpochLossFn.forward` / `.backward`).
+
+    In the reference's default regime (five minibatches of 2 000) the step is launch-bound: ~13 + ~16 dependent launches per narrow
+    model (hundreds for a matrix-core one), each paying a host launch and an idle gap on the device.  A graph submits them whole.
+    The plan OWNS every buffer its graphs point at (draws, history, BatchNorm records, integrand values, loss records, workspaces,
+    gradient blobs); the model's own blobs (parameters, running statistics, counters) are read through their current addresses, which
+    are part of the plan's key.  Parameter VALUES may change between replays: the parameter image is re-packed inside the graph.
+    Built-in integrands only (a Python callable cannot be captured)."""
+
+    def __init__(self, eng, G, N, dev, f, maxf, preburn, est):
+        self.eng, self.G, self.N, self.dev = eng, int(G), int(N), torch.device(dev)
+        L, d, n = eng.L, eng.d, len(eng.cells)
+        self.preburn, self.est = bool(preburn), bool(est)
+        dd, nset = d + 1, n + 1
+        dbl = dict(dtype=torch.double, device=self.dev)
+        self.w = torch.empty((self.G, self.N, d), **dbl)
+        self.hist = torch.empty((self.G, nset, dd, self.N), **dbl)
+        self.bnsave = torch.empty((self.G, L.nis_flow_bnsave_count(eng.handle)), **dbl)
+        self.fv = torch.empty((self.G, self.N), **dbl)
+        self.rec = torch.empty((self.G, 12), **dbl)
+        self.out = torch.empty((self.G, 8), **dbl)
+        self.gloss = torch.ones(1, **dbl)
+        self.maxf = maxf                                   # device scalar owned by the training loop (its address is in the key)
+        self.ws = torch.empty(L.nis_flow_workspace_bytes(eng.handle, self.G), dtype=torch.uint8, device=self.dev)
+        self.lws = torch.empty(max(1, L.nis_loss_workspace_bytes_batched(self.G, self.N)), dtype=torch.uint8, device=self.dev)
+        self.bws = torch.empty(L.nis_flow_backward_workspace_bytes_batched(eng.handle, self.G, self.N), dtype=torch.uint8, device=self.dev)
+        for c in eng.cells:
+            ensure_flat(c, self.dev)
+        self.gflat = [torch.empty_like(c._flat) for c in eng.cells]
+        self._gp = (C.c_void_p * n)(*[g.data_ptr() for g in self.gflat])
+        self._fp = (C.c_double * 4)(*(list(f.nis_params) + [0.0] * 4)[:4])
+        self._oc = (C.c_int32 * d)(*eng.out_col)
+        self._kind = f.nis_kind
+        set_ = dd * self.N
+        self._x_planes = (self.hist.data_ptr() + 8 * (nset - 1) * set_, self.N, 1, nset * set_, self._oc)
+        self._x_rows = (self.w.data_ptr(), 1, d, self.N * d, None)
+        self._jac = (self.hist.data_ptr() + 8 * ((nset - 1) * set_ + d * self.N), 1, nset * set_)
+        keep = [(c._running.clone(), c._tracked.clone()) for c in eng.cells]
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        self.gA = self.gB = None
+        with torch.cuda.stream(side):
+            self.w.uniform_(0.05, 0.95)
+            self._forward_calls()                      # warm-up: code objects, first pack; must leave no trace in the running statistics
+            self._backward_calls()
+            side.synchronize()
+            for c, (r, t) in zip(eng.cells, keep):
+                c._running.copy_(r)
+                c._tracked.copy_(t)
+            try:
+                gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gA, stream=side, capture_error_mode="thread_local"):
+                    self._forward_calls()
+                with torch.cuda.graph(gB, stream=side, capture_error_mode="thread_local"):
+                    self._backward_calls()
+                self.gA, self.gB = gA, gB
+            except Exception as exc:                   # noqa: BLE001 - any capture failure: the same calls run eagerly
+                import sys
+                print(f"nf_amd: training-step capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        self.captured = self.gA is not None
+
+    def _forward_calls(self):
+        eng, L = self.eng, self.eng.L
+        pp, rp, tp = eng._pointers(self.dev)
+        with _lib.on_device(self.dev):
+            st = _lib.stream_ptr(self.dev)
+            rc = L.nis_flow_forward_hist_batched(eng.handle, self.w.data_ptr(), _lib.NIS_F64, self.G, self.N, pp, rp, tp, _lib.NIS_BN_TRAIN,
+                                                 0, self.hist.data_ptr(), self.N, self.bnsave.data_ptr(), None, self.ws.data_ptr(),
+                                                 self.ws.numel(), st)          # pack_token 0: the parameter image is re-packed on every replay
+            _lib.check(rc, "nis_flow_forward_hist_batched")
+            src = self._x_rows if self.preburn else self._x_planes
+            rc = L.nis_loss_terms_batched(None, *src, eng.d, self._kind, self._fp, self.fv.data_ptr(), *self._jac, self.G, self.N,
+                                          self.maxf.data_ptr(), 1 if self.preburn else 0, 1 if self.est else 0, self.rec.data_ptr(),
+                                          self.out.data_ptr(), self.lws.data_ptr(), self.lws.numel(), st)
+            _lib.check(rc, "nis_loss_terms_batched")
+
+    def _backward_calls(self):
+        eng, L = self.eng, self.eng.L
+        pp, _, _ = eng._pointers(self.dev)
+        with _lib.on_device(self.dev):
+            rc = L.nis_flow_backward_loss_batched(eng.handle, self.hist.data_ptr(), self.N, self.G, self.N, pp, self.bnsave.data_ptr(),
+                                                  _lib.NIS_BN_TRAIN, self.fv.data_ptr(), self.maxf.data_ptr(), self.rec.data_ptr(),
+                                                  self.gloss.data_ptr(), 1 if self.est else 0, self._gp, self.bws.data_ptr(),
+                                                  self.bws.numel(), _lib.stream_ptr(self.dev))
+            _lib.check(rc, "nis_flow_backward_loss_batched")
+
+    def forward(self, w):
+        """Draws (G, N, d) -> bookkeeping rows (G, 8) (a fresh tensor; the plan's own copy is overwritten by the next replay)."""
+        self.w.copy_(w)
+        if self.gA is not None:
+            self.gA.replay()
+        else:
+            self._forward_calls()
+        self.eng._stats_bump(1)
+        self.eng._raise_on_status(self.ws[:4].view(torch.int32))
+        return self.out.clone()
+
+    def backward(self, gloss):
+        """Upstream cotangent of the summed losses -> [gradient blob per cell] (fresh tensors)."""
+        self.gloss.copy_(gloss.detach().reshape(1))
+        if self.gB is not None:
+            self.gB.replay()
+        else:
+            self._backward_calls()
+        return [g.clone() for g in self.gflat]
 
 
 def philox_rows(seed, stream0, G, N, d, dev):

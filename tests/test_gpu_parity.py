@@ -2051,3 +2051,45 @@ def test_no_access_past_the_end_of_caller_buffers():
     for which in ("1", "2"):          # 2: the buffers the Python layer allocates sit at segment ends as well
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "guard_check.py"), which], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "GUARD_OK" in r.stdout, which + r.stdout[-1500:] + r.stderr[-2500:]
+
+
+@pytest.mark.parametrize("shape", [dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3]), dict(kind="pwquad", d=5, n_cells=3, K=6, NN=[16, 16])])
+def test_captured_training_step_equals_eager(shape, monkeypatch):
+    """flow.TrainPlan (opt-in, NIS_TRAIN_GRAPH=1): forward + loss bookkeeping and the adjoint of an optimizer step as two hipGraph
+    replays against the same library calls launched eagerly -- loss history, estimator bookkeeping, gradients, parameters and running
+    statistics after a few epochs that cross the preburn switch (two plans), identical draws."""
+    import copy
+    from nf_amd import integrands
+    d = shape["d"]
+    torch.manual_seed(31)
+    base = build_manager(shape)
+    f = integrands.Camel() if d == 2 else integrands.Normal(0.5, 0.3, d)
+    g = torch.Generator().manual_seed(8)
+    draws = [torch.rand(1500, d, dtype=torch.double, generator=g) for _ in range(80)]
+
+    def run(graph):
+        if graph:
+            monkeypatch.setenv("NIS_TRAIN_GRAPH", "1")
+        else:
+            monkeypatch.delenv("NIS_TRAIN_GRAPH", raising=False)
+        NF = build_manager(shape)
+        NF._model = copy.deepcopy(base._model)
+        NF.best_model = NF._model
+        it = iter(draws)
+        NF.sample_hook = lambda n, dd, dtype, stage: next(it)[:n].to(dtype)
+        optim = torch.optim.Adamax(NF._model.parameters(), lr=2e-3, weight_decay=1e-4)
+        res = NF._train_variance_forward_seq(f, optim, False, None, 3000, 8, 0, True, True, mini_batch_size=1000, integrate=True, preburn_time=3)
+        eng = NF._model.engine()
+        assert bool(getattr(eng, "_train_plans", None)) == graph
+        if graph:
+            assert all(p.captured for p in eng._train_plans.values())
+        return res, t2n(torch.stack(NF.history)), [t2n(p.grad) for p in NF._model.parameters()], {k: t2n(v) for k, v in NF._model.state_dict().items()}
+
+    ra, ha, ga, sa = run(True)
+    rb, hb, gb, sb = run(False)
+    np.testing.assert_allclose(ha, hb, rtol=1e-12)
+    np.testing.assert_allclose(ra, rb, rtol=1e-9)
+    for x, y in zip(ga, gb):
+        np.testing.assert_allclose(x, y, rtol=1e-11, atol=1e-16)
+    for k in sa:
+        np.testing.assert_allclose(sa[k], sb[k], rtol=1e-11, atol=1e-15, err_msg=k)
