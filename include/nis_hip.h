@@ -190,9 +190,9 @@ int nis_flow_forward_sync(nis_flow* f, const void* w, int32_t w_dtype, int32_t w
                           int32_t world, int32_t rank);
 
 /* Training forward + hand-written adjoint (replaces loss.backward() through the flow, manager.py:275-278, for the
- * cell class the adjoint kernels cover: conditioner widths and pass-through size <= 64 -- <= 8: fp64 VALU kernels (PWQuad and
- * PWLin up to NIS_MAX_BINS bins); wider: v_mfma_f64_16x16x4_f64 kernels (PWQuad n_bins <= 32, PWLin any n_bins whose LDS image
- * fits) --, any number of transformed columns; nis_flow_backward_supported tells).
+ * cell class the adjoint kernels cover: every model nis_flow_create accepts -- conditioner widths and pass-through size <= 64
+ * (<= 8: fp64 VALU kernels; wider: v_mfma_f64_16x16x4_f64 kernels), up to NIS_MAX_BINS bins, any number of transformed columns;
+ * nis_flow_backward_supported tells).
  *   nis_flow_forward_train: train-mode forward that keeps every cell's input: planes_hist holds n_cells+1 plane
  *     sets of (d+1, ld) doubles (set c = input of cell c, last set = model output); bnsave
  *     (nis_flow_bnsave_count doubles) receives scale | shift | batch mean | rstd of every BN layer.

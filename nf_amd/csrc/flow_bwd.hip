@@ -630,7 +630,7 @@ bool nis_bwd_cell_supported(const nis_cell_desc& cd, int wm) {
   if (wm == 32) return bwd_wide_supported<32>(cd);
   if (wm == 64) return bwd_wide_supported<64>(cd);
   if (wm != 4 && wm != 8) return false;
-  return cd.K <= NIS_MAX_BINS;                        // PWQuad with more than 32 bins: scratch-array variant of the head (narrow conditioners only)
+  return cd.K <= NIS_MAX_BINS;                        // PWQuad with more than 32 bins: scratch-array variant of the head
 }
 
 static size_t bwd_chunks(int R) { return (size_t)(R + BRC - 1) / BRC; }

@@ -189,7 +189,7 @@ __device__ __forceinline__ void bww_stage(const BwdK& k, double* lds_bn, int* ld
 // kernels (the C5 head goes from 52 to 85 spilled dwords, +13 % on a 2e5 minibatch), so a single minibatch runs the BATCH = false build.
 template <int KIND, int KM, bool KEXACT, bool BATCH>
 __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, BwdW w) {
-  extern __shared__ double mf_dyn[];                 // per wave: [NCB*out rows][16 samples] of exp(Z)
+  extern __shared__ double mf_dyn[];                 // per wave: [ncb*out rows][16 samples] of exp(Z); ncb = CellK::mf_ncb columns per batch
   __shared__ double lds_bn[BNLDS];
   __shared__ int lds_plane[NIS_MAX_DIM];
   __shared__ double etab[NIS_EXP_N];
@@ -202,7 +202,10 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
   __syncthreads();
   const int L = c.L, K = KEXACT ? KM : c.K, out = c.out;
   const long ld = k.ld, N = k.N;
-  double* ring = mf_dyn + (size_t)wave * NCB * out * 16;
+  // columns per bijector batch: four (one per lane group) unless the ring of four does not fit the LDS -- then two or one, the other
+  // lane groups run on dummy data with zero gradients (heads with many rows per column: PWLin with > 70 bins, PWQuad with > 32)
+  const int ncb = c.mf_ncb;
+  double* ring = mf_dyn + (size_t)wave * ncb * out * 16;
   const double* bnL = lds_bn + (size_t)L * 4 * WM;
   // BN_L sums live in LDS (sm[wave]: sum dy | sum dy*xhat), updated once per tile: 32 registers less in the bijector phase
   if (lane < SREC / 2) sm[wave][lane] = 0.0, sm[wave][SREC / 2 + lane] = 0.0;
@@ -248,9 +251,9 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
       const double gJ = iv ? k.g[(size_t)c.jplane * ld + i] : 0.0;
       const double Jout = iv ? k.xo[(size_t)c.jplane * ld + i] : 1.0;
 #pragma unroll 1
-      for (int cb = 0; cb * NCB < c.T; ++cb) {
-        const int r0 = cb * NCB * out;
-        const int r1 = min(c.R, r0 + NCB * out);
+      for (int cb = 0; cb * ncb < c.T; ++cb) {
+        const int r0 = cb * ncb * out;
+        const int r1 = min(c.R, r0 + ncb * out);
         double fa[KQ];                                  // fragments of the row tile being multiplied (prefetched one tile ahead)
 #pragma unroll
         for (int q = 0; q < KQ; ++q) fa[q] = w.wm_last[((size_t)(r0 / 16) * KQ + q) * 64 + lane];
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int j = 16 * jt + gq + 4 * r - r0;
-            if (j >= 0 && j < NCB * out && 16 * jt + gq + 4 * r < c.R)
+            if (j >= 0 && j < ncb * out && 16 * jt + gq + 4 * r < c.R)
               ring[j * 16 + s] = (KIND == NIS_AFFINE && (j & 1)) ? z[r] : nis_exp(z[r], etab);   // affine: odd rows = raw shift
           }
 #pragma unroll
@@ -276,18 +279,84 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
         __builtin_amdgcn_wave_barrier();
         // (sample s, column slot gq) per lane.  Lanes without a column / sample run on dummy data with zero incoming
         // gradients, so that the MFMAs below stay in wave-uniform control flow and receive dZ = 0 from them.
-        const int t = cb * NCB + gq;
-        const bool valid = t < c.T && iv;
+        const int t = cb * ncb + gq;
+        const bool valid = gq < ncb && t < c.T && iv;
         const int tc = min(t, c.T - 1);
         const size_t colp = (size_t)lds_plane[c.P + tc] * ld;
         const int row0 = tc * out;
         const double xraw = valid ? k.x[colp + i] : 0.5;
         const double gy = valid ? k.g[colp + i] : 0.0;
         const double gJv = valid ? gJ : 0.0;
-        const double* zr = ring + (size_t)gq * out * 16 + s;
+        const double* zr = ring + (size_t)(gq < ncb ? gq : 0) * out * 16 + s;      // (lane groups without a column read slot 0: in bounds, masked)
         const double* wrow = c.wlast + (size_t)row0 * WM + s;
         double gx = 0.0, jf = 1.0;
-        if (KIND == NIS_PWQUAD) {
+        if constexpr (KIND == NIS_PWQUAD && KM > 32) {
+          // 33 .. NIS_MAX_BINS bins: no register arrays -- the column's raw exponentials stay in its LDS ring (element q of this lane's
+          // column and sample at zr[16 q]: heights 0 .. K, widths K+1 .. 2K), every pass over the bins is a runtime loop, and dZ replaces
+          // the exponentials in place (the ring is rebuilt for the next column batch).  Same arithmetic as the register branch below.
+          const bool clamped = xraw > 1.0 - 1e-6;
+          const double xb = clamped ? 1.0 - 1e-6 : xraw;
+          double* zw = const_cast<double*>(zr);
+          const double* Wr = zr + (size_t)(K + 1) * 16;
+          double wn = 0.0;
+          for (int q = 0; q < K; ++q) wn += valid ? Wr[q * 16] : 1.0;
+          int b = 0;
+          double left = 0.0;
+          if (valid) pwquad_bin_big<16>(xb, K, Wr, wn, &b, &left);
+          left = left / wn;
+          const double iwn = 1.0 / wn;
+          double area = 0.0;
+          for (int q = 0; q < K; ++q) area += valid ? (zr[q * 16] + zr[(q + 1) * 16]) / 2 * (Wr[q * 16] * iwn) : 1.0;
+          const double iarea = 1.0 / area;
+          const double Wb = valid ? Wr[b * 16] * iwn : 1.0;
+          const double Vb = valid ? zr[b * 16] * iarea : 1.0, Vb1 = valid ? zr[(b + 1) * 16] * iarea : 1.0;
+          const double alpha = (xb - left) / Wb;
+          const double D = Vb1 - Vb;
+          jf = lerp_torch(Vb, Vb1, alpha);
+          const double gjf = gJv * Jout / jf;
+          const double galpha = gy * jf * Wb + gjf * D;
+          gx = clamped ? 0.0 : galpha / Wb;
+          const double gleft = -galpha / Wb;
+          const double hgy = gy / 2;
+          const double A0 = gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha);
+          const double A1 = gy * alpha * alpha / 2 * Wb + gjf * alpha;
+          const double B0 = gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb;
+          auto gv = [&](int q, double wm1, double wq) {
+            return ((q >= 1 && q - 1 < b) ? hgy * wm1 : 0.0) + (q < b ? hgy * wq : 0.0) + (q == b ? A0 : 0.0) + (q == b + 1 ? A1 : 0.0);
+          };
+          auto gw0 = [&](int q, double vq, double vq1) { return (q < b ? hgy * (vq + vq1) + gleft : 0.0) + (q == b ? B0 : 0.0); };
+          double S = 0.0, Sw = 0.0;
+          if (valid) {
+            for (int q = 0; q <= K; ++q) {
+              const double wm1 = q >= 1 ? Wr[(q - 1) * 16] * iwn : 0.0;
+              const double wq = q < K ? Wr[q * 16] * iwn : 0.0;
+              S += gv(q, wm1, wq) * (zr[q * 16] * iarea);
+            }
+            for (int q = 0; q < K; ++q) {
+              const double vq = zr[q * 16] * iarea, vq1 = zr[(q + 1) * 16] * iarea;
+              Sw += (gw0(q, vq, vq1) - S * (vq + vq1) / 2) * (Wr[q * 16] * iwn);
+            }
+            // dZ in place, ascending q: v_q and w_{q-1} of the step are carried in registers, v_{q+1} / w_q are still the raw values
+            double wprev = 0.0;
+            for (int q = 0; q <= K; ++q) {
+              const bool hasw = q < K;
+              const double wq = hasw ? Wr[q * 16] * iwn : 0.0;
+              const double vq = zr[q * 16] * iarea;
+              const double vq1 = hasw ? zr[(q + 1) * 16] * iarea : 0.0;
+              const double dzv = gv(q, wprev, wq) * vq - S * vq * (wprev + wq) / 2;
+              if (hasw) zw[(size_t)(K + 1 + q) * 16] = wq * (gw0(q, vq, vq1) - S * (vq + vq1) / 2 - Sw);
+              zw[q * 16] = dzv;
+              wprev = wq;
+            }
+            for (int q = 0; q < 2 * K + 1; ++q) k.dzp[tmx(c.R, row0 + q, i)] = zr[q * 16];
+          }
+          // d a_L += W_rows^T dZ: every lane takes part in the MFMAs (lanes without a column / sample contribute dZ = 0)
+          for (int q = 0; q < 2 * K + 1; ++q) {
+            const double dzq = valid ? zr[q * 16] : 0.0;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) da[jt] = mfma(wrow[(size_t)q * WM + 16 * jt], dzq, da[jt]);
+          }
+        } else if (KIND == NIS_PWQUAD) {
           const bool clamped = xraw > 1.0 - 1e-6;
           const double xb = clamped ? 1.0 - 1e-6 : xraw;
           double V[KM + 1], W[KM];
@@ -747,7 +816,14 @@ int device_cus() {
   return cus;
 }
 
-size_t ring_bytes(int out) { return (size_t)NW * NCB * out * 16 * sizeof(double); }
+size_t ring_bytes(int out, int ncb) { return (size_t)NW * ncb * out * 16 * sizeof(double); }
+constexpr size_t HEAD_FIXED_LDS = (size_t)(BNLDS + NW * SREC + 64) * sizeof(double) + NIS_MAX_DIM * sizeof(int) + 1024;   // static LDS of the head
+// columns per bijector batch of the head: the largest of 4 / 2 / 1 whose ring fits beside the static LDS (0: none does)
+int pick_ncb(int out) {
+  for (int n = NCB; n >= 1; n >>= 1)
+    if (ring_bytes(out, n) + HEAD_FIXED_LDS <= 160 * 1024) return n;
+  return 0;
+}
 long ldw_of(long N) { return (N + 15) / 16 * 16; }
 int groups_of(int rows) { return (rows + RPW * 16 - 1) / (RPW * 16); }
 
@@ -776,9 +852,7 @@ Plan plan_for(int R, long N, int G) {         // the G minibatches of a launch (
 template <>
 bool bwd_wide_supported<NIS_WM>(const nis_cell_desc& cd) {
   const int out = cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K;
-  if (cd.kind == NIS_PWQUAD && cd.K > 32) return false;        // the in-place dZ arrays (2K + 1 doubles) stay in registers
-  const size_t fixed = (size_t)(BNLDS + NW * SREC + 64) * sizeof(double) + NIS_MAX_DIM * sizeof(int) + 1024;   // static LDS of the head
-  return ring_bytes(out) + fixed <= 160 * 1024;
+  return pick_ncb(out) > 0;            // (PWQuad with more than 32 bins: the column's LDS ring doubles as the dZ array)
 }
 
 template <>
@@ -817,7 +891,10 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   double* ghid = glast + (size_t)p.ngl * GREC;
   k.part = part;
   k.sums = nullptr;
-  const size_t ring = ring_bytes(c.out);
+  CellK& cm = k.c;                                  // (k is this function's own copy)
+  cm.mf_ncb = pick_ncb(c.out);
+  if (cm.mf_ncb < 1) return NIS_E_UNSUPPORTED;
+  const size_t ring = ring_bytes(c.out, cm.mf_ncb);
   const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : c.K <= 16 ? 16 : 32;
   const unsigned Gz = (unsigned)G;
 #define NIS_HEAD(KIND, KMV, EX)                                                                                        \
@@ -841,8 +918,10 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
     NIS_HEAD(NIS_PWQUAD, 8, false);
   else if (km == 16)
     NIS_HEAD(NIS_PWQUAD, 16, false);
-  else
+  else if (c.K <= 32)
     NIS_HEAD(NIS_PWQUAD, 32, false);
+  else
+    NIS_HEAD(NIS_PWQUAD, NIS_KM_BIG, false);
 #undef NIS_HEAD
   hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + 3) / 4, 1, Gz), dim3(TPB), 0, s, (const double*)part, p.nb, SREC, sums, (long)p.part, (long)nsum);
   // dW_L = dZ a_L^T, db_L = row sums of dZ

@@ -924,6 +924,8 @@ __device__ __forceinline__ double pwquad_column(double xb, int Krt, const double
 // More than 32 bins (up to NIS_MAX_BINS): the same transform with V (K + 1 raw heights) and W (K raw widths) in per-thread arrays
 // the compiler keeps in scratch memory, every loop over the bins a runtime loop.  Bin selection is pwquad_bin_raw's, statement by
 // statement (guard band, exact re-test with the reference's division when a lane falls inside it, sentinel, clamp).
+// (ST: element stride of W -- 1 for a scratch array, 16 for a column of the matrix-core adjoint's LDS ring)
+template <int ST = 1>
 __device__ __forceinline__ void pwquad_bin_big(double xb, int K, const double* W, double wn, int* idx_out, double* run_out) {
   const double q = xb * wn;
   const double qlo = q * (1.0 - 0x1p-50), qhi = q * (1.0 + 0x1p-50);
@@ -931,7 +933,7 @@ __device__ __forceinline__ void pwquad_bin_big(double xb, int K, const double* W
   int idx = 0;
   bool ambany = false;
   for (int k = 0; k < K; ++k) {
-    run += W[k];
+    run += W[k * ST];
     const bool le = run <= qlo;
     ambany |= (run > qlo) && (run < qhi);
     const bool up = le && (run > bestrun);
@@ -943,7 +945,7 @@ __device__ __forceinline__ void pwquad_bin_big(double xb, int K, const double* W
     bestrun = 0.0;
     idx = 0;
     for (int k = 0; k < K; ++k) {
-      run += W[k];
+      run += W[k * ST];
       const bool le = !((run / wn) > xb);                // the reference's comparison, verbatim
       const bool up = le && (run > bestrun);
       bestrun = up ? run : bestrun;

@@ -4,7 +4,7 @@ Forward values AND gradients come from the HIP kernels.  Gradients are needed on
 (/root/reference/nisrep/normalizing_flows/manager.py:275-280): `nis_flow_forward_train` keeps what the adjoint needs,
 `nis_flow_backward` runs the hand-written adjoint (nf_amd/csrc/flow_bwd.hip: conditioner widths and pass-through size <= 8 on
 the fp64 VALU; flow_bwd_wm.hip: widths 9..64 on the f64 matrix cores; PWQuad n_bins <= 32, PWLin any n_bins whose LDS image
-fits -- on the matrix-core path PWQuad n_bins <= 32 --; AffineCoupling), with train-mode BatchNorm or -- like the reference's autograd, which differentiates a model in any mode --
+fits; AffineCoupling), with train-mode BatchNorm or -- like the reference's autograd, which differentiates a model in any mode --
 eval-mode BatchNorm (running statistics: `nis_flow_forward_hist` / `nis_flow_backward_eval`).  Shapes outside that class RAISE:
 there is no stock-PyTorch fallback in the product (the torch re-evaluation the adjoint kernels are tested against lives in
 tests/torch_adjoint.py).
@@ -187,8 +187,8 @@ def run_flow(engine, modules, x, has_jac, train):
         return engine.forward(x, has_jac, train, want_xj=True)["xj"]
     why = None
     if not engine.backward_supported():
-        why = ("the adjoint kernels do not cover this model (PWQuad n_bins > 32 behind a conditioner wider than 8, or a PWLin head "
-               "whose LDS image does not fit): forward-only on this build")
+        why = ("the adjoint kernels do not cover this model (a matrix-core head whose one-column LDS ring does not fit): forward-only "
+               "on this build")
     if why is not None and train:
         # a TRAINING forward outside the adjoint class: refuse before anything runs -- the forward would advance the BatchNorm
         # running statistics and the failure would surface mid-step, inside loss.backward()

@@ -185,7 +185,13 @@ WIDE_BWD_CASES = [("pwquad", dict(d=16, n_cells=8, K=16, NN=[32, 32, 32])),     
                   ("pwlin", dict(d=7, P=3, n_cells=3, K=21, NN=[64, 48], roll=2)),
                   ("pwquad", dict(d=4, n_cells=2, K=9, NN=[40, 64, 33])),
                   ("pwquad", dict(d=8, n_cells=2, K=32, NN=[32, 32, 32])),            # golden cell shape (8, 4, 32, [32]*3)
-                  ("pwquad", dict(d=5, n_cells=2, K=23, NN=[16]))]
+                  ("pwquad", dict(d=5, n_cells=2, K=23, NN=[16])),
+                  # heads whose four-column LDS ring does not fit: two / one column(s) per batch (CellK::mf_ncb in the adjoint head)
+                  ("pwlin", dict(d=6, P=3, n_cells=2, K=128, NN=[16, 16], roll=2)),
+                  # PWQuad with more than 32 bins behind a wide conditioner: the column's LDS ring doubles as the in-place dZ array
+                  ("pwquad", dict(d=5, n_cells=2, K=40, NN=[16])),
+                  ("pwquad", dict(d=4, n_cells=2, K=128, NN=[32, 32])),
+                  ("pwquad", dict(d=3, n_cells=2, K=64, NN=[40, 64]))]
 
 
 @pytest.mark.parametrize("kind,c", WIDE_BWD_CASES, ids=[f"{k}-d{c['d']}-K{c['K']}-NN{'x'.join(map(str, c['NN']))}" for k, c in WIDE_BWD_CASES])
