@@ -735,24 +735,34 @@ __global__ __launch_bounds__(TPB, 2) void k_bwd_xty_w(const double* __restrict__
   for (int e = tid; e < GREC; e += TPB) rec[e] = sm[e];
 }
 
-// records -> their sum: a workgroup owns 4 elements, 64 slices of the records each; fixed order (bitwise reproducible)
-__global__ __launch_bounds__(TPB) void k_bwd_reduce_w(const double* __restrict__ part, int nparts, int nacc, double* __restrict__ out, long part_gs,
-                                                      long out_gs) {
+// records -> their sum: a workgroup owns 4 elements, 64 slices of the records each; fixed order (bitwise reproducible).
+// Two reductions in ONE launch (rows [0, a.ny) of the grid's y extent run job a, the rest job b): the BatchNorm sums of a chain
+// kernel and the weight-gradient GEMM's records always come in pairs, and a launch costs more than either reduction.
+struct RedJob {
+  const double* part;
+  double* out;
+  int nparts, nacc, ny;
+  long part_gs, out_gs;
+};
+__global__ __launch_bounds__(TPB) void k_bwd_reduce2_w(RedJob a, RedJob b) {
   __shared__ double sm[64][4];
+  const bool second = (int)blockIdx.y >= a.ny;
+  const RedJob& j = second ? b : a;
+  const int y = (int)blockIdx.y - (second ? a.ny : 0);
   const int el = threadIdx.x & 3, slice = threadIdx.x >> 2;
   const int e = blockIdx.x * 4 + el;
-  part += (size_t)blockIdx.z * part_gs + (size_t)blockIdx.y * nparts * nacc;
-  out += (size_t)blockIdx.z * out_gs;
+  const double* part = j.part + (size_t)blockIdx.z * j.part_gs + (size_t)y * j.nparts * j.nacc;
+  double* out = j.out + (size_t)blockIdx.z * j.out_gs;
   double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-  if (e < nacc) {
-    int b = slice;
-    for (; b + 192 < nparts; b += 256) {
-      t0 += part[(size_t)b * nacc + e];
-      t1 += part[(size_t)(b + 64) * nacc + e];
-      t2 += part[(size_t)(b + 128) * nacc + e];
-      t3 += part[(size_t)(b + 192) * nacc + e];
+  if (e < j.nacc) {
+    int b_ = slice;
+    for (; b_ + 192 < j.nparts; b_ += 256) {
+      t0 += part[(size_t)b_ * j.nacc + e];
+      t1 += part[(size_t)(b_ + 64) * j.nacc + e];
+      t2 += part[(size_t)(b_ + 128) * j.nacc + e];
+      t3 += part[(size_t)(b_ + 192) * j.nacc + e];
     }
-    for (; b < nparts; b += 64) t0 += part[(size_t)b * nacc + e];
+    for (; b_ < j.nparts; b_ += 64) t0 += part[(size_t)b_ * j.nacc + e];
   }
   sm[slice][el] = (t0 + t1) + (t2 + t3);
   __syncthreads();
@@ -760,7 +770,7 @@ __global__ __launch_bounds__(TPB) void k_bwd_reduce_w(const double* __restrict__
     if (slice < h) sm[slice][el] += sm[slice + h][el];
     __syncthreads();
   }
-  if (slice == 0 && e < nacc) out[(size_t)blockIdx.y * nacc + e] = sm[0][el];
+  if (slice == 0 && e < j.nacc) out[(size_t)y * j.nacc + e] = sm[0][el];
 }
 
 // Reduced records -> gradient blob in the reference's parameter order (include/nis_hip.h).
@@ -831,7 +841,8 @@ struct Plan {
   int nb;            // workgroups of the head / layer launches
   int ngl, ngh;      // row groups of the last-layer / hidden GEMMs
   int nxl, nxh;      // sample chunks (workgroups in x) of those GEMMs
-  size_t part;       // doubles of the shared record area
+  size_t part;       // doubles of the record area of the chain kernels (BatchNorm sums: nb x SREC)
+  size_t partg;      // doubles of the record area of the weight-gradient GEMMs
 };
 
 Plan plan_for(int R, long N, int G) {         // the G minibatches of a launch (blockIdx.z) share the chip
@@ -844,7 +855,8 @@ Plan plan_for(int R, long N, int G) {         // the G minibatches of a launch (
   const long tiles_wg = ((N + 15) / 16 + NW - 1) / NW;
   p.nxl = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 2 / (p.ngl * G))));      // 2 resident workgroups per CU
   p.nxh = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 2 / (p.ngh * G))));
-  p.part = std::max<size_t>((size_t)p.nb * SREC, std::max((size_t)p.ngl * p.nxl, (size_t)p.ngh * p.nxh) * GREC);
+  p.part = (size_t)p.nb * SREC;
+  p.partg = std::max((size_t)p.ngl * p.nxl, (size_t)p.ngh * p.nxh) * GREC;
   return p;
 }
 }  // namespace
@@ -860,7 +872,8 @@ size_t bwd_wide_workspace_doubles<NIS_WM>(const nis_cell_desc& cd, int64_t N, in
   const int T = cd.d - cd.P;
   const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K);
   const Plan p = plan_for(R, (long)N, G);
-  return (size_t)G * ((size_t)(3 * WM + R) * ldw_of((long)N) + p.part + (size_t)(cd.n_hidden + 2) * SREC + (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC);
+  return (size_t)G * ((size_t)(3 * WM + R) * ldw_of((long)N) + p.part + p.partg + (size_t)(cd.n_hidden + 2) * SREC +
+                      (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC);
 }
 
 template <>
@@ -886,7 +899,8 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   w.dhp = ws + (size_t)2 * WM * ldw;
   k.dzp = ws + (size_t)3 * WM * ldw;
   double* part = ws + (size_t)G * wsp;
-  double* sums = part + (size_t)G * p.part;
+  double* partg = part + (size_t)G * p.part;
+  double* sums = partg + (size_t)G * p.partg;
   double* glast = sums + (size_t)G * nsum;                 // minibatch g: glast + g * ngem, its hidden-layer results ngl * GREC behind
   double* ghid = glast + (size_t)p.ngl * GREC;
   k.part = part;
@@ -923,23 +937,24 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   else
     NIS_HEAD(NIS_PWQUAD, NIS_KM_BIG, false);
 #undef NIS_HEAD
-  hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + 3) / 4, 1, Gz), dim3(TPB), 0, s, (const double*)part, p.nb, SREC, sums, (long)p.part, (long)nsum);
-  // dW_L = dZ a_L^T, db_L = row sums of dZ
-  hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.ngl, Gz), dim3(TPB), 0, s, (const double*)k.dzp, c.R, c.R, (const double*)k.alp, N, part, (long)wsp,
-                     (long)p.part);
-  hipLaunchKernelGGL(k_bwd_reduce_w, dim3((GREC + 3) / 4, p.ngl, Gz), dim3(TPB), 0, s, (const double*)part, p.nxl, GREC, glast, (long)p.part, (long)ngem);
+  auto reduce_pair = [&](double* sums_out, int ngroups, int nx, double* gemm_out) {
+    RedJob a = {part, sums_out, p.nb, SREC, 1, (long)p.part, (long)nsum};
+    RedJob b = {partg, gemm_out, nx, GREC, ngroups, (long)p.partg, (long)ngem};
+    hipLaunchKernelGGL(k_bwd_reduce2_w, dim3((GREC + 3) / 4, 1 + ngroups, Gz), dim3(TPB), 0, s, a, b);
+  };
+  // dW_L = dZ a_L^T, db_L = row sums of dZ; then ONE launch reduces the head's BatchNorm sums and the GEMM's records
+  hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.ngl, Gz), dim3(TPB), 0, s, (const double*)k.dzp, c.R, c.R, (const double*)k.alp, N, partg, (long)wsp,
+                     (long)p.partg);
+  reduce_pair(sums, p.ngl, p.nxl, glast);
   for (int l = L; l >= 1; --l) {
     const int pass = L - l + 1;
     k.sums = sums + (size_t)(pass - 1) * SREC;
     if (G > 1) hipLaunchKernelGGL(k_bwd_layer_w<true>, dim3(p.nb, 1, Gz), dim3(TPB), 0, s, k, w, l);
     else hipLaunchKernelGGL(k_bwd_layer_w<false>, dim3(p.nb, 1, 1), dim3(TPB), 0, s, k, w, l);
-    hipLaunchKernelGGL(k_bwd_reduce_w, dim3((SREC + 3) / 4, 1, Gz), dim3(TPB), 0, s, (const double*)part, p.nb, SREC, sums + (size_t)pass * SREC,
-                       (long)p.part, (long)nsum);
     // dW_{l-1} = d h_l a_{l-1}^T
-    hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxh, p.ngh, Gz), dim3(TPB), 0, s, (const double*)w.dhp, WM, c.width[l - 1], (const double*)k.alp, N, part,
-                       (long)wsp, (long)p.part);
-    hipLaunchKernelGGL(k_bwd_reduce_w, dim3((GREC + 3) / 4, p.ngh, Gz), dim3(TPB), 0, s, (const double*)part, p.nxh, GREC,
-                       ghid + (size_t)(l - 1) * p.ngh * GREC, (long)p.part, (long)ngem);
+    hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxh, p.ngh, Gz), dim3(TPB), 0, s, (const double*)w.dhp, WM, c.width[l - 1], (const double*)k.alp, N, partg,
+                       (long)wsp, (long)p.partg);
+    reduce_pair(sums + (size_t)pass * SREC, p.ngh, p.nxh, ghid + (size_t)(l - 1) * p.ngh * GREC);
   }
   k.sums = sums + (size_t)L * SREC;
   {
