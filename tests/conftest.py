@@ -17,6 +17,17 @@ def pytest_configure(config):
         _guard_allocations()
 
 
+def pytest_collection_modifyitems(config, items):
+    """NIS_TEST_ORDER=reverse | shuffle:<seed>: another execution order (an out-of-bounds read once depended on which test had used the
+    allocator before)."""
+    order = os.environ.get("NIS_TEST_ORDER", "")
+    if order == "reverse":
+        items.reverse()
+    elif order.startswith("shuffle"):
+        import random
+        random.Random(int(order.split(":")[1]) if ":" in order else 0).shuffle(items)
+
+
 def _guard_allocations():
     """NIS_TEST_GUARD_ALLOC=1 (GPU box, occasional sweep): torch.empty / zeros / empty_like hand out CUDA tensors below 4 MiB as views
     at the very end of their own 16 MiB allocator segment, so a kernel that reads or writes past ANY buffer the Python layer or a test
