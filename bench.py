@@ -271,6 +271,8 @@ TRAIN_CASES = {
     "C2": ("C2", 1_000_000, 1, 360.0),        # (model, minibatch size, minibatches per optimizer step, forward flop per sample: 2 cells x 180)
     "C5": ("C5", 200_000, 1, 1.9e5),
     "C1_epoch": ("C2", 2_000, 5, 360.0),
+    # the C2 step is host-bound at 1e6 (~0.9 ms of Python / autograd / optimizer against ~0.5 ms of kernels); at 4e6 the kernels decide
+    "C2_mbs4e6": ("C2", 4_000_000, 1, 360.0),
 }
 
 
