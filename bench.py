@@ -276,9 +276,9 @@ TRAIN_CASES = {
 }
 
 
-def bench_train_step(name, rank, ws, dev, steps=5):
+def bench_train_step(name, rank, ws, dev, steps=20):
     """One training minibatch (reference manager.py:219-280 with n_minibatches = 1): draw w, train-mode forward with history, integrand,
-    loss bookkeeping (nis_loss_terms), hand-written adjoint seeded by the loss, optimizer step.  `steps` timed after 2 warm-up steps."""
+    loss bookkeeping (nis_loss_terms), hand-written adjoint seeded by the loss, optimizer step.  `steps` timed after 5 warm-up steps."""
     from nf_amd.normalizing_flows._autograd import flow_loss_batched
     cfg, mbs, G, fwd_flop = TRAIN_CASES[name]
     if G > 1:
@@ -307,7 +307,7 @@ def bench_train_step(name, rank, ws, dev, steps=5):
         optim.step()
         return loss
 
-    for _ in range(2):
+    for _ in range(5):               # allocator growth, code-object loads and the optimizer's lazy state are behind these
         step()
     barrier_sync(ws)
     t0 = time.perf_counter()
