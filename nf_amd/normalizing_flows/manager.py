@@ -437,7 +437,8 @@ class BasicManager(ModelAPI):
         per = (n_cells + 1) * (self.n_flow + 1) * int(mini_batch_size) * 8
         return int(max(1, min(self.minibatches_per_call, (2 << 30) // max(per, 1))))
 
-    minibatches_per_call = 4096  # training: upper bound on the minibatches of one optimizer step carried by one fused call
+    minibatches_per_call = 256   # training: upper bound on the minibatches of one optimizer step carried by one fused call (the launch
+                                 # cost is amortised long before; the record workspace grows with the count)
     batch_iterations = 20      # integrate(): iterations fused into one launch set (independent BN batches)
     batch_callable = True      # integrate() with a Python callable: the flow part of G iterations as one launch set (False: one
                                # forward per iteration with a materialised (N, d+1) XJ, the round-1 path kept for A/B tests)

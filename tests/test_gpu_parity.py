@@ -1958,6 +1958,41 @@ def test_batched_minibatches_equal_single_minibatch_calls(mk, mode):
         np.testing.assert_allclose(t2n(b), t2n(a), rtol=1e-9, atol=1e-12 * max(scale, 1.0), err_msg=f"cell {ci}")
 
 
+@pytest.mark.parametrize("which", ["c2-class", "wide-d6"])
+def test_many_small_minibatches_in_one_call(which):
+    """70 minibatches of 130 samples as the y / z extent of the training launches (every minibatch gets ONE workgroup per launch) against
+    one call per minibatch: bookkeeping rows and the summed gradients."""
+    from nf_amd import integrands
+    import copy
+    mk = [p.values[0] for p in _batched_models() if p.id == which][0]
+    torch.manual_seed(2)
+    NF = mk()
+    model = NF._model.to(dev()).train()
+    d = NF.n_flow
+    G, N = 70, 130
+    w = torch.rand(G, N, d, dtype=torch.double, device=dev()) * (1 - 1e-9)
+    f = integrands.Camel() if d == 2 else integrands.Normal(0.5, 0.35, d)
+    maxf = torch.tensor(1.3, dtype=torch.double, device=dev())
+    gloss = torch.tensor(1.0 / G, dtype=torch.double, device=dev())
+    model_b = copy.deepcopy(model)
+    ea, eb = model.engine(), model_b.engine()
+    out_a, g_a = [], None
+    for g in range(G):
+        xj, saved = ea.forward_train(w[g], False)
+        fv, rec, out = ea.loss_terms(xj, maxf, False, False, f=f, w=w[g])
+        gf = ea.backward_loss(saved, fv, maxf, rec, gloss, False)
+        out_a.append(out)
+        g_a = [x.clone() for x in gf] if g_a is None else [a + x for a, x in zip(g_a, gf)]
+    _, saved = eb.forward_train_batched(w, True)
+    fv, rec, out = eb.loss_terms_batched(saved, maxf, False, False, f=f, w=w)
+    g_b = eb.backward_loss_batched(saved, fv, maxf, rec, gloss, False)
+    np.testing.assert_allclose(t2n(out)[:, :6], t2n(torch.stack(out_a))[:, :6], rtol=1e-11, atol=1e-14)
+    for ci, (a, b) in enumerate(zip(g_a, g_b)):
+        np.testing.assert_allclose(t2n(b), t2n(a), rtol=1e-9, atol=1e-12 * max(float(a.abs().max()), 1.0), err_msg=f"cell {ci}")
+    for (ka, va), (kb, vb) in zip(model.state_dict().items(), model_b.state_dict().items()):
+        np.testing.assert_allclose(t2n(vb), t2n(va), rtol=1e-12, atol=1e-14, err_msg=ka)
+
+
 def test_batched_minibatches_with_a_callable_integrand_and_xj():
     """The callable-integrand form of the fused epoch: xj (G, N, d+1) of the batched forward equals the per-minibatch outputs."""
     from nf_amd.normalizing_flows.manager import PWQuadManager
