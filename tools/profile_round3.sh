@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 profile set, on the GPU box:   bash tools/profile_round3.sh [what]     what: all | bench | kernels | train | c2 | rambo | wide
+# Round-3 profile set, on the GPU box:   bash tools/profile_round3.sh [what]     what: all | bench | kernels | train | trainpmc | c2 | rambo | wide
 # Writes gpurun_out/r03_*; copy what should be judged into profiles/.  Counters run in their own passes, without tracing
 # (rocprofv3 --pmc only).  `kernels`: ONE config per rocprofv3 --kernel-trace --stats run, so that per-config kernel timings
 # (apply / statistics / ingest / tail split) are artefacts: r03_kernels_<cfg>.csv.
@@ -41,6 +41,13 @@ if [ $WHAT = all ] || [ $WHAT = train ]; then
   python3 tools/train_probe.py C5 2000 5 20 both 2>&1 | grep "^C" >> $OUT/r03_train_probe.txt
   python3 tools/host_sections.py 2000 5 2>&1 | grep -v "Warn\|amdgpu" >> $OUT/r03_train_probe.txt
   tools/probe/rambo_traffic 1000000 40 > $OUT/r03_rambo_traffic_probe.txt 2>&1 || true
+fi
+if [ $WHAT = all ] || [ $WHAT = trainpmc ]; then
+  # counters of the narrow training kernels at a kernel-bound minibatch (C2 model, one minibatch of 4e6): instructions and HBM bytes
+  pmc train_valu "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" python3 tools/train_probe.py C2 4e6 1 3 batched
+  pmc train_fetch FETCH_SIZE python3 tools/train_probe.py C2 4e6 1 3 batched
+  pmc train_write WRITE_SIZE python3 tools/train_probe.py C2 4e6 1 3 batched
+  python3 tools/pmc_json.py $OUT/r03_pmc_train_c2.json 1 sets=6 valu=$OUT/r03_pmc_train_valu/p_counter_collection.csv fetch=$OUT/r03_pmc_train_fetch/p_counter_collection.csv write=$OUT/r03_pmc_train_write/p_counter_collection.csv > $OUT/r03_pmc_train_c2.txt
 fi
 if [ $WHAT = all ] || [ $WHAT = c2 ]; then
   pmc c2_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" python3 tools/run_c2_set.py 20 4
