@@ -141,9 +141,36 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
 #pragma unroll
   for (int a = 0; a < NW; ++a) accw[a] = 0.0;
   const long stride = (long)gridDim.x * NIS_TPB;
-  for (long i = (long)blockIdx.x * NIS_TPB + threadIdx.x; i < k.N; i += stride) {
+  // FUSEW (one transformed column): the five values a sample needs from memory are requested one sample AHEAD -- at its two waves
+  // per SIMD the kernel sat out a full HBM round trip per sample otherwise (PMC: 47 % of the fp64 issue rate).  The last round re-reads
+  // its own sample; the in-place stores of sample i never touch what was requested for sample i + stride.
+  const long i_first = (long)blockIdx.x * NIS_TPB + threadIdx.x;
+  const size_t pl_j = (size_t)c.jplane * k.ld, pl_t = (size_t)c.in_plane[c.P] * k.ld;
+  double xq[WM], xrq = 0.0, gyq = 0.0, gJq = 0.0, Joq = 0.0;
+#pragma unroll
+  for (int p = 0; p < WM; ++p) xq[p] = 0.0;
+  if (FUSEW && i_first < k.N) {
+    bw_load_x<WM>(k, x, i_first, xq);
+    xrq = x[pl_t + i_first];
+    gyq = gp[pl_t + i_first];
+    gJq = gp[pl_j + i_first];
+    Joq = xo[pl_j + i_first];
+  }
+  for (long i = i_first; i < k.N; i += stride) {
     double h[WM], a_in[WM], o_in[WM], xh_in[WM], xin[WM];
-    bw_load_x<WM>(k, x, i, xin);
+    const double xrc = xrq, gyc = gyq, gJc = gJq, Joc = Joq;
+    if (FUSEW) {
+#pragma unroll
+      for (int p = 0; p < WM; ++p) xin[p] = xq[p];
+      const long ic = i + stride < k.N ? i + stride : i;
+      bw_load_x<WM>(k, x, ic, xq);
+      xrq = x[pl_t + ic];
+      gyq = gp[pl_t + ic];
+      gJq = gp[pl_j + ic];
+      Joq = xo[pl_j + ic];
+    } else {
+      bw_load_x<WM>(k, x, i, xin);
+    }
     bw_forward<WM, WX>(k, xin, lbn, L, h, a_in, o_in, xh_in);
     double aL[WM], oL[WM], xhL[WM], da[WM];
 #pragma unroll
@@ -154,14 +181,14 @@ __global__ __launch_bounds__(NIS_TPB) void k_cell_bwd_head(BwdK k) {
       if (!FUSEW) alp[(size_t)j * k.ldw + i] = aL[j];
       da[j] = 0.0;
     }
-    const double gJ = gp[(size_t)c.jplane * k.ld + i];
-    const double Jout = xo[(size_t)c.jplane * k.ld + i];
+    const double gJ = FUSEW ? gJc : gp[(size_t)c.jplane * k.ld + i];
+    const double Jout = FUSEW ? Joc : xo[(size_t)c.jplane * k.ld + i];
     double jfprod = 1.0;
     for (int t = 0; t < c.T; ++t) {
       const int colp = c.in_plane[c.P + t];
       const int row0 = t * c.out;
-      const double xraw = x[(size_t)colp * k.ld + i];
-      const double gy = gp[(size_t)colp * k.ld + i];
+      const double xraw = FUSEW ? xrc : x[(size_t)colp * k.ld + i];
+      const double gy = FUSEW ? gyc : gp[(size_t)colp * k.ld + i];
       double gx = 0.0, jf = 1.0;
 #define NIS_GV(q, wm1, wq) (((q) >= 1 && (q) - 1 < b ? hgy * (wm1) : 0.0) + ((q) < b ? hgy * (wq) : 0.0) + ((q) == b ? A0 : 0.0) + ((q) == b + 1 ? A1 : 0.0))
 #define NIS_GW0(q) (((q) < b ? hgy * (V[q] + V[(q) + 1]) + gleft : 0.0) + ((q) == b ? B0 : 0.0))
