@@ -2134,3 +2134,70 @@ def test_captured_training_step_equals_eager(shape, monkeypatch):
         np.testing.assert_allclose(x, y, rtol=1e-11, atol=1e-16)
     for k in sa:
         np.testing.assert_allclose(sa[k], sb[k], rtol=1e-11, atol=1e-15, err_msg=k)
+
+
+def _random_cell_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        kind = "pwquad" if rng.random() < 0.6 else "pwlin"
+        d = int(rng.integers(2, 13))
+        P = int(rng.integers(1, d))
+        K = int(rng.choice([2, 3, 4, 5, 8, 13, 16, 31, 32, 33, 47, 64, 100, 128]))
+        depth = int(rng.integers(1, 4))
+        wmax = int(rng.choice([3, 8, 16, 32, 64]))
+        NN = [int(rng.integers(1, wmax + 1)) for _ in range(depth)]
+        N = int(rng.integers(17, 700))
+        out.append(pytest.param(kind, d, P, K, NN, N, id=f"{i}-{kind}-d{d}-P{P}-K{K}-NN{'x'.join(map(str, NN))}-N{N}"))
+    return out
+
+
+@pytest.mark.parametrize("kind,d,P,K,NN,N", _random_cell_shapes(28, 20261004))
+def test_random_cell_shapes_forward_and_adjoint(kind, d, P, K, NN, N):
+    """A seeded sweep over cell shapes nobody picked by hand (bin counts 2 .. 128, widths 1 .. 64, depths 1 .. 3, every pass-through /
+    transformed split of d <= 12, ragged N): train- and eval-mode forward against the oracle (bins bit-exact, values 1e-9), and the
+    adjoint against autograd through the stock-PyTorch re-evaluation of the same cell."""
+    from nf_amd.normalizing_flows.layers.coupling_cells import PWLin, PWQuad
+    torch.manual_seed(1000 * d + K)
+    cell = (PWQuad if kind == "pwquad" else PWLin)(d, P, K, list(NN)).double()
+    with torch.no_grad():
+        for p in cell.parameters():
+            p.add_(0.25 * torch.randn_like(p))
+        for mod in cell.NN:
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.uniform_(0, 0.5)
+                mod.running_var.uniform_(0.1, 1.0)
+    params = {"c." + k: t2n(v) for k, v in cell.state_dict().items()}
+    x = torch.rand(N, d + 1, dtype=torch.double)
+    x[:, -1] += 0.5
+    x[:, :d] *= (1 - 1e-12)
+    cell = cell.to(dev())
+    for train in (True, False):
+        want, upd = {}, {}
+        y_ref = oflow.cell_forward(x.numpy(), params, "c", kind, P, K, train, upd, want)
+        cell.load_state_dict({k[2:]: torch.as_tensor(v) for k, v in params.items()})
+        cell.train(train)
+        res = cell._own_engine().forward(x.to(dev()), True, train, want_xj=True, want_bins=True)
+        np.testing.assert_array_equal(t2n(res["bins"]).T, want["bins"])
+        np.testing.assert_allclose(t2n(res["xj"]), y_ref, rtol=RTOL, atol=ATOL)
+    # adjoint (train mode), same cell through the model-level autograd function
+    cell.load_state_dict({k[2:]: torch.as_tensor(v) for k, v in params.items()})
+    cell.train(True)
+    model = torch.nn.Sequential(cell)
+    R = torch.randn(N, d + 1, dtype=torch.double, device=dev())
+
+    def grads(force_torch):
+        for p in cell.parameters():
+            p.grad = None
+        xx = x.to(dev()).clone().requires_grad_(True)
+        out = model_torch(model, xx) if force_torch else cell(xx)
+        (out * R).sum().backward()
+        return xx.grad.clone(), [p.grad.clone() for p in cell.parameters()]
+
+    sd = {k: v.clone() for k, v in cell.state_dict().items()}
+    gx_h, gp_h = grads(False)
+    cell.load_state_dict(sd)
+    gx_t, gp_t = grads(True)
+    np.testing.assert_allclose(t2n(gx_h), t2n(gx_t), rtol=1e-6, atol=1e-9 * max(1.0, float(gx_t.abs().max())))
+    for (name, _), a, b in zip(cell.named_parameters(), gp_h, gp_t):
+        np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-6, atol=1e-9 * max(1.0, float(b.abs().max())), err_msg=name)
