@@ -247,7 +247,13 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
   // in flight while the current one is computed.  PDF columns only exist in the PDF modes.
   constexpr int NIN = HAS_PDF ? NPS + 2 : NPS;
   // row-major rows of exactly NIN doubles (NIN even): 16-byte vector loads, NIN / 2 per sample instead of NIN 8-byte ones
-  const bool vec_rows = !col_major && (NIN % 2 == 0) && k.r_ld == NIN && k.ncol == NIN && ((unsigned long long)r & 15ull) == 0;
+  // ... for maps of at most six final-state legs ONLY: the pipelined loads land in registers the compiler believes idle, which is sound
+  // exactly as long as it never spills or re-allocates them between issue and wait.  The larger instantiations do spill (n >= 7 with
+  // cuts, n = 10 in every mode: 66 .. 264 spilled registers) and then read stale inputs -- found by the random 2 -> n sweep of round 3
+  // (2 -> 10 with cuts: 1-4 % of the weights differed from run to run).  tests/test_host_logic.py checks the built object: no spills
+  // in any instantiation that takes this path.
+  constexpr bool PIPE_OK = NF <= 6;
+  const bool vec_rows = PIPE_OK && !col_major && (NIN % 2 == 0) && k.r_ld == NIN && k.ncol == NIN && ((unsigned long long)r & 15ull) == 0;
   // vec_rows: SOFTWARE-PIPELINED inputs.  The 16-byte loads of the NEXT tile are issued by inline asm (rb_issue16) into registers the
   // compiler regards as ready, and the one wait that guards them is written by hand at the top of the next iteration:
   // s_waitcnt vmcnt(<number of stores a whole tile issues after its loads>).  vmcnt counts loads and stores in issue order on
@@ -558,14 +564,16 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
   };
   const std::integral_constant<bool, true> yes;
   const std::integral_constant<bool, false> no;
-  if (vec_rows) {
-    if ((long)blockIdx.x >= ntiles) return;
-    issue(blockIdx.x, rawn);
-    rb_wait_loads<0>(rawn);                            // first tile of the workgroup: nothing is behind its loads yet
-    const long nfull = N / RB_TPB;
-    long tile = blockIdx.x;
-    for (; tile < nfull; tile += gridDim.x) process(tile, yes, yes);
-    if (tile < ntiles) process(tile, no, yes);         // the ragged last tile, if it is this workgroup's
+  if (PIPE_OK && vec_rows) {                           // (not even instantiated for the larger maps)
+    if constexpr (PIPE_OK) {
+      if ((long)blockIdx.x >= ntiles) return;
+      issue(blockIdx.x, rawn);
+      rb_wait_loads<0>(rawn);                          // first tile of the workgroup: nothing is behind its loads yet
+      const long nfull = N / RB_TPB;
+      long tile = blockIdx.x;
+      for (; tile < nfull; tile += gridDim.x) process(tile, yes, yes);
+      if (tile < ntiles) process(tile, no, yes);       // the ragged last tile, if it is this workgroup's
+    }
   } else {
 #ifndef RB_VEC_ONLY                                    // (register-pressure experiments: the pipelined path alone)
     if ((long)blockIdx.x < ntiles) fetch(blockIdx.x, rvn);

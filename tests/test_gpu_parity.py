@@ -2201,3 +2201,42 @@ def test_random_cell_shapes_forward_and_adjoint(kind, d, P, K, NN, N):
     np.testing.assert_allclose(t2n(gx_h), t2n(gx_t), rtol=1e-6, atol=1e-9 * max(1.0, float(gx_t.abs().max())))
     for (name, _), a, b in zip(cell.named_parameters(), gp_h, gp_t):
         np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-6, atol=1e-9 * max(1.0, float(b.abs().max())), err_msg=name)
+
+
+def _random_rambo_shapes(n_cases, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n_cases):
+        n = int(rng.integers(2, 11))
+        style = int(rng.integers(0, 3))            # 0 massless, 1 massive, 2 mixed
+        final = [0.0 if style == 0 or (style == 2 and rng.random() < 0.5) else float(rng.uniform(1, 150)) for _ in range(n)]
+        pdf = bool(rng.random() < 0.5)
+        tau = bool(rng.random() < 0.7)
+        init = [0., 0.] if pdf or rng.random() < 0.5 else [float(rng.uniform(1, 50)), float(rng.uniform(1, 50))]
+        cuts = (-1, -1, -1) if rng.random() < 0.4 else (float(rng.uniform(1, 30)), float(rng.uniform(0.1, 0.6)), float(rng.uniform(2, 5)))
+        E = float(rng.uniform(2000, 13000))
+        N = int(rng.integers(100, 9000))
+        out.append(pytest.param(init, final, E, cuts, pdf, tau, N, id=f"{i}-n{n}-{'mass0 massive mixed'.split()[style]}-pdf{int(pdf)}-tau{int(tau)}-cuts{int(cuts[0] > 0)}-N{N}"))
+    return out
+
+
+@pytest.mark.parametrize("init,final,E,cuts,pdf,tau,N", _random_rambo_shapes(16, 77))
+def test_random_rambo_configurations_vs_oracle(init, final, E, cuts, pdf, tau, N):
+    """A seeded sweep over 2 -> n maps nobody picked by hand (n = 2 .. 10, massless / massive / mixed legs, massive or massless beams, tau-y or
+    x1-x2 sampling, with and without cuts): momenta and weights against the oracle, row input and column-plane input bit-identical."""
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    n = len(final)
+    rng = np.random.default_rng(N)
+    r = rng.random((N, 3 * n - 4 + (2 if pdf else 0)))
+    ref_m, ref_w = orambo.generate_kinematics(init, final, E, r, *cuts, pdf_active=pdf, tau=tau)
+    gen = FlatInvertiblePhasespace(init, final, pdf=None, pdf_active=pdf, tau=tau)
+    rt = torch.as_tensor(r).to(dev())
+    mom, wgt = gen.generateKinematics_batch(E, rt, *cuts)
+    differ = (t2n(wgt) == 0) != (ref_w == 0)          # a point within rounding of a cut threshold may fall on either side
+    assert differ.sum() <= 2
+    ok = ~differ
+    np.testing.assert_allclose(t2n(mom), ref_m, rtol=1e-8, atol=1e-9 * E)
+    np.testing.assert_allclose(t2n(wgt)[ok], ref_w[ok], rtol=1e-8)
+    planes = rt.t().contiguous()
+    wp, _ = gen.weights_from_planes(E, planes, list(range(r.shape[1])), N, *cuts)
+    np.testing.assert_array_equal(t2n(wp), t2n(wgt))

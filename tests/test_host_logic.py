@@ -198,3 +198,36 @@ def test_reference_checkpoints_load_and_training_state_round_trips(tmp_path, g_m
     assert NF3.best_epoch == 17 and NF3.best_var == 0.25 and len(NF3.history) == 2
     with pytest.raises(AttributeError, match="No model was instantiated"):
         type(NF)(n_flow=2).load_checkpoint(str(tmp_path / "torch"))
+
+
+def test_pipelined_rambo_instantiations_do_not_spill():
+    """k_rambo's hand-pipelined row loads (inline-asm issue, hand-written s_waitcnt) are sound only while the compiler never spills the
+    registers they land in: the path is compiled for maps of at most six final-state legs (rambo.hip: PIPE_OK), and none of those
+    instantiations may report a spilled register in the built object's metadata."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    obj = os.path.join(ROOT, "nf_amd", "csrc", "build", "rambo.o")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(llvm, "llvm-readelf")):
+        pytest.skip("no built rambo.o / llvm tools here")
+    td = tempfile.mkdtemp()
+    try:
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", f".hip_fatbin={td}/fat.bin", obj], check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={td}/fat.bin",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={td}/dev.co"], check=True)
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", f"{td}/dev.co"], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    seen = 0
+    for blk in notes.split(".agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        spill = re.search(r"\.vgpr_spill_count:\s+(\d+)", blk)
+        if not name or not spill:
+            continue
+        m = re.match(r"_Z7k_ramboILi(\d+)ELi(\d+)E", name.group(1))
+        if m and int(m.group(1)) <= 6:
+            seen += 1
+            assert int(spill.group(1)) == 0, f"k_rambo<{m.group(1)}, {m.group(2)}> spills {spill.group(1)} registers"
+    assert seen >= 20, seen          # n = 2 .. 6, four modes each
