@@ -509,11 +509,13 @@ class BasicManager(ModelAPI):
             if not f.check_status(status):                 # the ONE host read of the call
                 return out
             # some sample had x1 == x2: the reference skips the lab boost for that WHOLE batch -- redo batch by batch below
-        if flow and fusable and not planar and self._stock_input() and self.batch_callable:
+        if flow and not planar and self._stock_input() and self.batch_callable:
             # Any Python callable (the reference's README form, manager.py:397-400): the FLOW part of G iterations is still one launch
             # set with the draw inside (NIS_F_NONE: X and J stay in the column planes, nothing else is written); f then sees X of
             # one iteration at a time, as in the reference's loop -- a (neval, d) float64 view of the planes (like the reference's
-            # XJ[:, :-1] it is not contiguous), and one reduction launch pair turns f(X) * J into the moment record.
+            # XJ[:, :-1] it is not contiguous), and one reduction launch pair turns f(X) * J into the moment record.  Also the way of a
+            # built-in integrand on a model whose last cell has no fused rider (matrix-core PWQuad with a bin count other than
+            # 4 / 8 / 16 / 32): the integrand is then evaluated from the kept planes.
             eng = model.engine()
             d = eng.d
             G = max(1, min(int(self.batch_iterations), nitn, max(1, (1 << 27) // max(1, neval * (d + 1)))))
@@ -537,6 +539,9 @@ class BasicManager(ModelAPI):
                         w = torch.stack([self._uniform(neval, dev, torch.float32, "integrate") for _ in range(g)])
                         eng.integrate_steps(w, model.training, _lib.NIS_F_NONE, [], None, planes=planes[:g])
                     for gi in range(g):
+                        if hasattr(f, "nis_kind"):
+                            out[i + gi] = moments_of(planes[gi], d, eng.out_col, f.nis_kind, f.nis_params)[0]
+                            continue
                         X = planes[gi, :d].t() if identity else planes[gi].index_select(0, cols).t()
                         out[i + gi] = hip_moments(f(X), planes[gi, d])
                     i += g

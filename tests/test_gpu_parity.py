@@ -2240,3 +2240,94 @@ def test_random_rambo_configurations_vs_oracle(init, final, E, cuts, pdf, tau, N
     planes = rt.t().contiguous()
     wp, _ = gen.weights_from_planes(E, planes, list(range(r.shape[1])), N, *cuts)
     np.testing.assert_array_equal(t2n(wp), t2n(wgt))
+
+
+def _random_models(n_cases, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n_cases):
+        which = rng.choice(["pwquad", "pwquad", "pwlin", "affine"])
+        depth = int(rng.integers(1, 4))
+        wmax = int(rng.choice([3, 3, 8, 16, 32]))
+        NN = [int(rng.integers(2, wmax + 1)) for _ in range(depth)]
+        if which == "pwquad":
+            d = int(rng.integers(2, 11))
+            cfg = dict(kind="pwquad", d=d, n_cells=int(rng.integers(1, 5)), K=int(rng.choice([2, 4, 5, 8, 16, 21, 40])), NN=NN)
+        else:
+            d = int(rng.integers(2, 9))
+            cfg = dict(kind=which, d=d, P=int(rng.integers(1, d)), n_cells=int(rng.integers(1, 5)), K=int(rng.choice([3, 8, 32, 70])), NN=NN,
+                       roll=int(rng.integers(1, d)))
+        N = int(rng.integers(40, 2500))
+        G = int(rng.choice([1, 2, 5]))
+        out.append(pytest.param(cfg, N, G, id=f"{i}-{which}-d{cfg['d']}-c{cfg['n_cells']}-K{cfg['K']}-NN{'x'.join(map(str, NN))}-N{N}-G{G}"))
+    return out
+
+
+@pytest.mark.parametrize("cfg,N,G", _random_models(20, 4242))
+def test_random_models_batched_integrate_step_vs_oracle(cfg, N, G):
+    """A seeded sweep over whole models nobody picked by hand (the three managers, d = 2 .. 10, 1 .. 4 requested cells, bins 2 .. 70, widths
+    2 .. 32, ragged N, G batches per launch set): integrate()'s loop body with the fused integrand -- train-mode BatchNorm, G batches as
+    grid.y, running statistics applied in batch order -- against the oracle's forward + integrand on the same draws; then the same
+    minibatches through the training step (grid.y minibatches) against one call per minibatch."""
+    from nf_amd import integrands
+    from nf_amd.normalizing_flows.manager import AffineManager
+    torch.manual_seed(7 * N + G)
+    d = cfg["d"]
+    if cfg["kind"] == "affine":
+        NF = AffineManager(n_flow=d)
+        NF.create_model(cfg["P"], cfg["n_cells"], list(cfg["NN"]), cfg["roll"])
+        steps = oflow.plan_affine(d, cfg["P"], cfg["n_cells"], cfg["roll"])
+    else:
+        NF = build_manager(cfg)
+        steps = plan_from_meta(cfg)
+    with torch.no_grad():
+        for p in NF._model.parameters():
+            p.add_(0.15 * torch.randn_like(p))
+    model = NF.best_model
+    model.train()
+    eng = model.engine()
+    f = integrands.Normal(0.45, 0.3, d)
+    cur = {k: t2n(v) for k, v in model.state_dict().items()}
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    w = (torch.rand(G, N, d, device=dev()) * (1 - 2 ** -23)).to(torch.float32)
+    if eng.fusable():
+        out = torch.zeros(G, 4, dtype=torch.double, device=dev())
+        eng.integrate_steps(w, True, f.nis_kind, f.nis_params, out)
+    else:           # no fused rider in the last cell (matrix-core PWQuad, bin count not 4 / 8 / 16 / 32): kept planes + integrand from the planes
+        NF.batch_iterations = G
+        NF.sample_hook = Replay([t2n(w[g]) for g in range(G)])
+        out = NF.moments_batches(f, G, N, dev())
+        NF.sample_hook = None
+    got = t2n(out)
+    for g in range(G):
+        upd = {}
+        XJ = oflow.model_forward(t2n(w[g]).astype(np.float64), cur, steps, True, upd)
+        cur.update(upd)
+        v = oflow.normal(XJ[:, :d], 0.45, 0.3, d) * XJ[:, d]
+        ref = np.array([N, v.mean(), ((v - v.mean()) ** 2).sum(), v.max()])
+        np.testing.assert_allclose(got[g], ref, rtol=5e-9, atol=1e-300, err_msg=f"g={g}")
+    sd1 = model.state_dict()
+    for k_, v_ in cur.items():
+        if "running" in k_:
+            np.testing.assert_allclose(t2n(sd1[k_]), v_, rtol=1e-9, atol=1e-13, err_msg=k_)
+    # the same batches as the minibatches of one optimizer step
+    if not eng.backward_supported():
+        return
+    import copy
+    model.load_state_dict(sd0)
+    model_b = copy.deepcopy(model)
+    wd = w.double()
+    maxf = torch.tensor(0.9, dtype=torch.double, device=dev())
+    gloss = torch.tensor(1.0 / G, dtype=torch.double, device=dev())
+    g_a = None
+    for g in range(G):
+        xj, saved = eng.forward_train(wd[g], False)
+        fv, rec, o8 = eng.loss_terms(xj, maxf, False, False, f=f, w=wd[g])
+        gf = eng.backward_loss(saved, fv, maxf, rec, gloss, False)
+        g_a = [x.clone() for x in gf] if g_a is None else [a + x for a, x in zip(g_a, gf)]
+    eb = model_b.engine()
+    _, saved = eb.forward_train_batched(wd, True)
+    fv, rec, o8 = eb.loss_terms_batched(saved, maxf, False, False, f=f, w=wd)
+    g_b = eb.backward_loss_batched(saved, fv, maxf, rec, gloss, False)
+    for ci, (a, b) in enumerate(zip(g_a, g_b)):
+        np.testing.assert_allclose(t2n(b), t2n(a), rtol=1e-8, atol=1e-12 * max(float(a.abs().max()), 1e-30), err_msg=f"cell {ci}")
