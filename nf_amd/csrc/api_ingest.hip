@@ -313,12 +313,19 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest_rng(unsigned long long seed,
 #pragma unroll
     for (int f = 0; f < NF; ++f) v[f] = 0.5;                    // padding features: exactly the shift
     for (int q = 0; q < Q; ++q) {
-      const unsigned long long ctr = (unsigned long long)i * (unsigned long long)Q + (unsigned long long)q;
+      // d == 2: the pair mapping of the direct-row chain and of nis_philox_rows (one call = two samples: counter n >> 1, words
+      // 2 (n & 1) + c), so that EVERY d = 2 model draws the numbers nis_philox_rows materialises -- not only the SPEC class
+      const bool pair = d == 2;
+      const unsigned long long ctr = pair ? (unsigned long long)(i >> 1) : (unsigned long long)i * (unsigned long long)Q + (unsigned long long)q;
       unsigned r[4];
       nis_philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), (unsigned)sid, (unsigned)(sid >> 32), (unsigned)seed, (unsigned)(seed >> 32), r);
       float u[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) u[j] = (float)(r[j] >> 8) * 0x1p-24f;
+      if (pair && (i & 1)) {
+        u[0] = u[2];
+        u[1] = u[3];
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (4 * q + j < d) {

@@ -2331,3 +2331,44 @@ def test_random_models_batched_integrate_step_vs_oracle(cfg, N, G):
     g_b = eb.backward_loss_batched(saved, fv, maxf, rec, gloss, False)
     for ci, (a, b) in enumerate(zip(g_a, g_b)):
         np.testing.assert_allclose(t2n(b), t2n(a), rtol=1e-8, atol=1e-12 * max(float(a.abs().max()), 1e-30), err_msg=f"cell {ci}")
+
+
+@pytest.mark.parametrize("cfg,N,G", _random_models(14, 99))
+@pytest.mark.parametrize("train", [True, False])
+def test_random_models_in_kernel_draws_equal_the_fed_path(cfg, N, G, train):
+    """The same seeded model sweep through the draw-inside form of the launch set (`nis_integrate_steps_rng`) against the fed form on the
+    materialised Philox rows (`nis_philox_rows`), train and eval mode, with the fused integrand where the model has the rider and with
+    kept planes (NIS_F_NONE) everywhere: moment records, kept X / J planes and running statistics."""
+    import copy
+    from nf_amd import _lib, integrands
+    from nf_amd.flow import philox_rows
+    from nf_amd.normalizing_flows.manager import AffineManager
+    torch.manual_seed(3 * N + G)
+    d = cfg["d"]
+    if cfg["kind"] == "affine":
+        NF = AffineManager(n_flow=d)
+        NF.create_model(cfg["P"], cfg["n_cells"], list(cfg["NN"]), cfg["roll"])
+    else:
+        NF = build_manager(cfg)
+    with torch.no_grad():
+        for p in NF._model.parameters():
+            p.add_(0.15 * torch.randn_like(p))
+    A = NF.best_model.train(train)
+    B = copy.deepcopy(A)
+    ea, eb = A.engine(), B.engine()
+    f = integrands.Normal(0.45, 0.3, d)
+    seed, s0 = 1234567 + N, 11
+    rows = philox_rows(seed, s0, G, N, d, dev())
+    pa = torch.zeros(G, d + 1, N, dtype=torch.double, device=dev())
+    pb = torch.zeros(G, d + 1, N, dtype=torch.double, device=dev())
+    ea.integrate_steps_rng(G, N, dev(), _lib.NIS_F_NONE, [], None, seed, s0, train=train, planes=pa, keep_planes=True)
+    eb.integrate_steps(rows, train, _lib.NIS_F_NONE, [], None, planes=pb)
+    np.testing.assert_allclose(t2n(pa), t2n(pb), rtol=1e-10 if train else 1e-13, atol=1e-300)      # train: BN_0 records summed about 1/2 vs about the wave's first value
+    if ea.fusable():
+        oa = torch.zeros(G, 4, dtype=torch.double, device=dev())
+        ob = torch.zeros(G, 4, dtype=torch.double, device=dev())
+        ea.integrate_steps_rng(G, N, dev(), f.nis_kind, f.nis_params, oa, seed, s0 + G, train=train)
+        eb.integrate_steps(philox_rows(seed, s0 + G, G, N, d, dev()), train, f.nis_kind, f.nis_params, ob)
+        np.testing.assert_allclose(t2n(oa), t2n(ob), rtol=1e-10)
+    for (ka, va), (kb, vb) in zip(A.state_dict().items(), B.state_dict().items()):
+        np.testing.assert_allclose(t2n(va), t2n(vb), rtol=1e-11, atol=1e-15, err_msg=ka)
