@@ -2195,12 +2195,16 @@ def test_random_cell_shapes_forward_and_adjoint(kind, d, P, K, NN, N):
         return xx.grad.clone(), [p.grad.clone() for p in cell.parameters()]
 
     sd = {k: v.clone() for k, v in cell.state_dict().items()}
-    gx_h, gp_h = grads(False)
-    cell.load_state_dict(sd)
-    gx_t, gp_t = grads(True)
-    np.testing.assert_allclose(t2n(gx_h), t2n(gx_t), rtol=1e-6, atol=1e-9 * max(1.0, float(gx_t.abs().max())))
-    for (name, _), a, b in zip(cell.named_parameters(), gp_h, gp_t):
-        np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-6, atol=1e-9 * max(1.0, float(b.abs().max())), err_msg=name)
+    for train in (True, False):                       # the reference's autograd differentiates a model in any mode
+        cell.load_state_dict(sd)
+        cell.train(train)
+        model.train(train)
+        gx_h, gp_h = grads(False)
+        cell.load_state_dict(sd)
+        gx_t, gp_t = grads(True)
+        np.testing.assert_allclose(t2n(gx_h), t2n(gx_t), rtol=1e-6, atol=1e-9 * max(1.0, float(gx_t.abs().max())), err_msg=f"train={train}")
+        for (name, _), a, b in zip(cell.named_parameters(), gp_h, gp_t):
+            np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-6, atol=1e-9 * max(1.0, float(b.abs().max())), err_msg=f"{name} train={train}")
 
 
 def _random_rambo_shapes(n_cases, seed):
@@ -2372,3 +2376,86 @@ def test_random_models_in_kernel_draws_equal_the_fed_path(cfg, N, G, train):
         np.testing.assert_allclose(t2n(oa), t2n(ob), rtol=1e-10)
     for (ka, va), (kb, vb) in zip(A.state_dict().items(), B.state_dict().items()):
         np.testing.assert_allclose(t2n(va), t2n(vb), rtol=1e-11, atol=1e-15, err_msg=ka)
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_random_flow_into_rambo_fused_equals_materialised(case):
+    """A seeded sweep over flow -> RAMBO pipelines (2 -> n with n = 2 .. 7, massless / massive legs, with and without cuts, narrow and
+    matrix-core flows, G iterations per launch set): the fused form (kept planes -> `nis_rambo_moments`, nothing materialised) against
+    the materialised form (X emitted, weights from `generateKinematics_batch`, `nis_moments`) on identical draws."""
+    from nf_amd import integrands
+    from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
+    rng = np.random.default_rng(500 + case)
+    n = int(rng.integers(2, 8))
+    pdf = bool(rng.random() < 0.6) or n == 2          # d = 3n - 4 (+ 2): at least 2 flow dimensions
+    d = 3 * n - 4 + (2 if pdf else 0)
+    massive = bool(rng.random() < 0.5)
+    final = [float(rng.uniform(5, 120)) if massive else 0.0 for _ in range(n)]
+    cuts = (-1, -1, -1) if rng.random() < 0.4 else (float(rng.uniform(5, 25)), float(rng.uniform(0.2, 0.5)), float(rng.uniform(2.5, 5)))
+    E = float(rng.uniform(3000, 13000))
+    NN = [int(rng.choice([3, 8, 16, 32]))] * int(rng.integers(1, 4))
+    K = int(rng.choice([4, 6, 16]))
+    N, G = int(rng.integers(300, 5000)), int(rng.choice([1, 3]))
+    torch.manual_seed(case)
+    cfg = dict(kind="pwquad", d=d, n_cells=2, K=K, NN=NN)
+    NF = build_manager(cfg)
+    params = {k: v.clone() for k, v in NF._model.state_dict().items()}
+    gen = FlatInvertiblePhasespace([0., 0.], final, pdf=None, pdf_active=pdf, tau=True)
+    f = integrands.RamboWeight(gen, E, *cuts)
+    draws = [(torch.rand(N, d) * (1 - 2 ** -23)).to(torch.float32).numpy() for _ in range(G)]
+    NF.batch_iterations = G
+    NF.sample_hook = Replay(draws)
+    fused = t2n(NF.moments_batches(f, G, N, dev()))
+    NF2 = build_manager(cfg)
+    NF2._model.load_state_dict(params)
+    NF2.batch_callable = False
+    NF2.sample_hook = Replay(draws)
+    plain = t2n(NF2.moments_batches(lambda x: f(x), G, N, dev()))
+    assert (fused[:, 0] == N).all()
+    np.testing.assert_allclose(fused[:, 1], plain[:, 1], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(fused[:, 2], plain[:, 2], rtol=1e-8, atol=1e-300)
+    np.testing.assert_allclose(fused[:, 3], plain[:, 3], rtol=1e-9, atol=1e-300)
+
+
+@pytest.mark.parametrize("cfg,N,G", _random_models(8, 31337))
+@pytest.mark.parametrize("loss_mode", ["var", "est"])
+def test_random_models_training_loop_fused_equals_piecewise(cfg, N, G, loss_mode):
+    """The seeded model sweep through `_train_variance_forward_seq` itself: the fused epoch (grid.y minibatches, library-side loss and
+    adjoint) against the piecewise path through torch's autograd graph -- loss history, returned estimate, gradients -- for a few
+    epochs that cross the preburn switch."""
+    import copy
+    from nf_amd import integrands
+    from nf_amd.normalizing_flows.manager import AffineManager
+    d = cfg["d"]
+    torch.manual_seed(N + 17 * G)
+    if cfg["kind"] == "affine":
+        base = AffineManager(n_flow=d)
+        base.create_model(cfg["P"], cfg["n_cells"], list(cfg["NN"]), cfg["roll"])
+    else:
+        base = build_manager(cfg)
+    if not base._model.engine().backward_supported():
+        pytest.skip("no adjoint for this shape")
+    f = integrands.Normal(0.5, 0.3, d)
+    mbs = max(64, N // 2)
+    n_mb = max(1, G)
+    gen = torch.Generator().manual_seed(N)
+    draws = [torch.rand(2 * mbs, d, dtype=torch.double, generator=gen) * (1 - 1e-9) for _ in range(d + 6 * n_mb + 8)]
+
+    def run(fused):
+        NF = copy.copy(base)
+        NF._model = copy.deepcopy(base._model)
+        NF.best_model = NF._model
+        NF.fused_minibatch = fused
+        it = iter(draws)
+        NF.sample_hook = lambda n, dd, dtype, stage: next(it)[:n].to(dtype)
+        optim = torch.optim.Adamax(NF._model.parameters(), lr=2e-3, weight_decay=1e-4)
+        res = NF._train_variance_forward_seq(f, optim, False, None, mbs * n_mb, 5, 0, True, True, mini_batch_size=mbs, integrate=True,
+                                             preburn_time=2, loss_mode=loss_mode)
+        return res, t2n(torch.stack(NF.history)), [t2n(p.grad) for p in NF._model.parameters()]
+
+    ra, ha, ga = run(True)
+    rb, hb, gb = run(False)
+    np.testing.assert_allclose(ha, hb, rtol=1e-8)
+    np.testing.assert_allclose(ra, rb, rtol=1e-5)
+    for x, y in zip(ga, gb):
+        np.testing.assert_allclose(x, y, rtol=1e-6, atol=1e-9 * max(1e-30, float(np.abs(y).max())) + 1e-14)
