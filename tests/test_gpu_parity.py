@@ -2486,3 +2486,78 @@ def test_random_rambo_with_pdf_grid_vs_oracle(case):
     planes = torch.as_tensor(r.T.copy()).to(dev())
     f = integrands.RamboWeight(gen, E, *cuts, pdgs=pdgs)
     np.testing.assert_array_equal(t2n(f.from_planes(planes, list(range(3 * n - 2)), N)), w)
+
+
+@pytest.mark.parametrize("kind,d,P,K", [("pwquad", 3, 1, 5), ("pwlin", 4, 2, 9), ("pwquad", 6, 3, 8)])
+@pytest.mark.parametrize("train", [True, False])
+def test_conditioner_without_hidden_layers(kind, d, P, K, train):
+    """NN_layers = []: the reference's layer list then holds ONE hidden layer as wide as the head (sizes = [T * out]: BatchNorm -> Linear ->
+    BatchNorm -> ReLU -> Linear, coupling_cells.py:236-254) -- a matrix-core conditioner for all but the smallest cells; forward against
+    the oracle, adjoint against autograd."""
+    from nf_amd.normalizing_flows.layers.coupling_cells import PWLin, PWQuad
+    torch.manual_seed(d + K)
+    cell = (PWQuad if kind == "pwquad" else PWLin)(d, P, K, []).double()
+    with torch.no_grad():
+        for p in cell.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    params = {"c." + k: t2n(v) for k, v in cell.state_dict().items()}
+    N = 777
+    x = torch.rand(N, d + 1, dtype=torch.double) * (1 - 1e-12)
+    x[:, -1] += 0.5
+    want, upd = {}, {}
+    y_ref = oflow.cell_forward(x.numpy(), params, "c", kind, P, K, train, upd, want)
+    cell = cell.to(dev()).train(train)
+    res = cell._own_engine().forward(x.to(dev()), True, train, want_xj=True, want_bins=True)
+    np.testing.assert_array_equal(t2n(res["bins"]).T, want["bins"])
+    np.testing.assert_allclose(t2n(res["xj"]), y_ref, rtol=RTOL, atol=ATOL)
+    cell.load_state_dict({k[2:]: torch.as_tensor(v) for k, v in params.items()})
+    model = torch.nn.Sequential(cell).train(train)
+    R = torch.randn(N, d + 1, dtype=torch.double, device=dev())
+
+    def grads(force_torch):
+        for p in cell.parameters():
+            p.grad = None
+        xx = x.to(dev()).clone().requires_grad_(True)
+        out = model_torch(model, xx) if force_torch else cell(xx)
+        (out * R).sum().backward()
+        return xx.grad.clone(), [p.grad.clone() for p in cell.parameters()]
+
+    sd = {k: v.clone() for k, v in cell.state_dict().items()}
+    gx_h, gp_h = grads(False)
+    cell.load_state_dict(sd)
+    gx_t, gp_t = grads(True)
+    np.testing.assert_allclose(t2n(gx_h), t2n(gx_t), rtol=1e-6, atol=1e-9 * max(1.0, float(gx_t.abs().max())))
+    for (name, _), a, b in zip(cell.named_parameters(), gp_h, gp_t):
+        np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-6, atol=1e-9 * max(1.0, float(b.abs().max())), err_msg=name)
+
+
+@pytest.mark.parametrize("cfg,N,G", _random_models(8, 555))
+def test_random_models_integrate_builtin_equals_callable(cfg, N, G):
+    """`integrate()` end to end on the seeded model sweep: the built-in integrand (fused rider, or kept planes + plane integrand where the
+    model has no rider) against the same function as a Python callable (kept planes + torch expression), identical draws."""
+    from nf_amd import integrands
+    from nf_amd.normalizing_flows.manager import AffineManager
+    d = cfg["d"]
+    torch.manual_seed(N)
+    if cfg["kind"] == "affine":
+        NF = AffineManager(n_flow=d)
+        NF.create_model(cfg["P"], cfg["n_cells"], list(cfg["NN"]), cfg["roll"])
+    else:
+        NF = build_manager(cfg)
+    sd0 = {k: v.clone() for k, v in NF._model.state_dict().items()}
+    nitn = G + 2
+    f = integrands.Normal(0.5, 0.35, d)
+
+    def f_py(x):
+        return torch.exp(-((x - 0.5) ** 2).sum(-1) / (2 * 0.35 ** 2)) / (0.35 * np.sqrt((2 * np.pi) ** d))
+
+    gen = torch.Generator().manual_seed(N)
+    draws = [(torch.rand(N, d, generator=gen) * (1 - 2 ** -23)).to(torch.float32).numpy() for _ in range(nitn)]
+    NF.batch_iterations = G
+    NF.sample_hook = Replay(draws)
+    a = NF.integrate(f, nitn, N, 0)
+    NF._model.load_state_dict(sd0)
+    NF.sample_hook = Replay(draws)
+    b = NF.integrate(f_py, nitn, N, 0)
+    np.testing.assert_allclose(float(a[0]), float(b[0]), rtol=2e-6)
+    np.testing.assert_allclose(float(a[1]), float(b[1]), rtol=2e-5)
