@@ -273,14 +273,19 @@ TRAIN_CASES = {
     "C1_epoch": ("C2", 2_000, 5, 360.0),
     # the C2 step is host-bound at 1e6 (~0.9 ms of Python / autograd / optimizer against ~0.5 ms of kernels); at 4e6 the kernels decide
     "C2_mbs4e6": ("C2", 4_000_000, 1, 360.0),
+    # opt-in captured step (NIS_TRAIN_GRAPH=1, flow.TrainPlan: the step's library calls as two hipGraph replays; capture ~0.2 s, untimed)
+    "C2_graph": ("C2", 1_000_000, 1, 360.0),
+    "C1_epoch_graph": ("C2", 2_000, 5, 360.0),
 }
 
 
 def bench_train_step(name, rank, ws, dev, steps=20):
     """One training minibatch (reference manager.py:219-280 with n_minibatches = 1): draw w, train-mode forward with history, integrand,
     loss bookkeeping (nis_loss_terms), hand-written adjoint seeded by the loss, optimizer step.  `steps` timed after 5 warm-up steps."""
+    from nf_amd.normalizing_flows import _autograd
     from nf_amd.normalizing_flows._autograd import flow_loss_batched
     cfg, mbs, G, fwd_flop = TRAIN_CASES[name]
+    _autograd.TRAIN_GRAPH = name.endswith("_graph")
     if G > 1:
         steps = 50
     torch.manual_seed(20 + rank)
@@ -315,6 +320,7 @@ def bench_train_step(name, rank, ws, dev, steps=20):
         loss = step()
     barrier_sync(ws)
     dt = max_over_ranks(time.perf_counter() - t0, ws, dev)
+    _autograd.TRAIN_GRAPH = False
     rate = G * mbs * steps * ws / dt
     tf = 3.0 * fwd_flop * rate / ws / 1e12          # forward + adjoint ~ 3x the forward's algorithmic flop (dX and dW products per layer)
     return {"workload": f"{cfg} optimizer step: draw, forward with history, f(X)*J, loss + bookkeeping, adjoint, Adamax step "

@@ -30,7 +30,7 @@ if [ $WHAT = all ] || [ $WHAT = kernels ]; then
 fi
 if [ $WHAT = all ] || [ $WHAT = train ]; then
   # training legs of bench.py (one optimizer step each): C2 at mbs 1e6, C5 at 2e5, the reference's default regime (5 x 2000 as grid.y)
-  for c in C2 C5 C1_epoch C2_mbs4e6; do
+  for c in C2 C5 C1_epoch C2_mbs4e6 C2_graph; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r03_kt_train_$c -o k -- python3 tools/run_train_leg.py $c 5 > $OUT/r03_kt_train_$c.log 2>&1
     cp $OUT/r03_kt_train_$c/k_kernel_stats.csv $OUT/r03_kernels_train_$c.csv
   done
