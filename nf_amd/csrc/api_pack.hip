@@ -189,7 +189,8 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double*
 // W[16 jt + (l & 15)][4 q + (l >> 4)]  (the A operand of v_mfma_f64_16x16x4_f64).
 // affT > 0 (NIS_AFFINE with T transformed columns): the last layer's rows [scale | shift][T] are interleaved to
 // [t][scale, shift], so that a column's outputs are contiguous like those of the piecewise cells.
-// regmode != 0 (diagnostics build, flow_mfma_reg.h): the last layer's rows are permuted so that a lane's four accumulator registers
+// regmode == NIS_PACK_REL: the relative image of a PWQuad last layer (nis_common.h, nis_rel_row).
+// other regmode != 0 (diagnostics build, flow_mfma_reg.h): the last layer's rows are permuted so that a lane's four accumulator registers
 // hold four consecutive bins of one column (mf_reg_row); T, K: transformed columns and bins of the cell.
 #ifndef NIS_DIAG
 __host__ __device__ inline int mf_reg_row(int, int, int, int tile, int rho) { return 16 * tile + rho; }
@@ -216,18 +217,20 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int
     const int q = (int)(frag % KQ), jt = (int)(frag / KQ);
     const int j = 16 * jt + (lane & 15), k = 4 * q + (lane >> 4);
     int jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;                // packed row j <- blob row jo
-    if (regmode) jo = mf_reg_row(regmode, T, K, jt, lane & 15);
+    int js = -1;
+    if (regmode == NIS_PACK_REL) jo = nis_rel_row(T, K, j, &js);
+    else if (regmode) jo = mf_reg_row(regmode, T, K, jt, lane & 15), js = mf_reg_row_sub(regmode, T, K, jt, lane & 15);
     double v = (regmode ? jo >= 0 && jo < R : j < R) ? wlast[(size_t)jo * WM + k] : 0.0;
-    const int js = regmode ? mf_reg_row_sub(regmode, T, K, jt, lane & 15) : -1;
     if (js >= 0) v -= wlast[(size_t)js * WM + k];
     wm_last[e] = v;
   }
   for (size_t e = tid; e < (size_t)RT * 16; e += nth) {
     const int j = (int)e;
     int jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;
-    if (regmode) jo = mf_reg_row(regmode, T, K, j >> 4, j & 15);
+    int js = -1;
+    if (regmode == NIS_PACK_REL) jo = nis_rel_row(T, K, j, &js);
+    else if (regmode) jo = mf_reg_row(regmode, T, K, j >> 4, j & 15), js = mf_reg_row_sub(regmode, T, K, j >> 4, j & 15);
     double v = (regmode ? jo >= 0 && jo < R : e < (size_t)R) ? bias[jo] : 0.0;
-    const int js = regmode ? mf_reg_row_sub(regmode, T, K, j >> 4, j & 15) : -1;
     if (js >= 0) v -= bias[js];
     bias_pad[e] = v;
   }

@@ -984,15 +984,18 @@ __device__ __forceinline__ double pwquad_column_big(double xb, int K, const doub
 // Same transform with the raw heights / widths in an LDS image (element k of the column at zr[k * ZS]: rows 0..K heights,
 // K+1..2K widths), as the matrix-core kernels keep them: the widths are streamed for the bin search, the trapezoid sums
 // stream the heights, and V_b, V_{b+1}, W_b are read BY INDEX instead of through K-long select chains.
-template <int KM, bool KEXACT, int ZS>
+// REL: the relative image (nis_common.h, NIS_PACK_REL): rows 0..K-1 = V[k] / V[K], rows K..2K-2 = W[k] / W[K-1]; V[K] = W[K-1] = 1.
+template <int KM, bool KEXACT, int ZS, bool REL = false>
 __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const double* zr, double* jf, int* bin) {
+  static_assert(!REL || KEXACT, "the relative image exists for K == KM only");
   const int K = KEXACT ? KM : Krt;
+  const int WO = REL ? K : K + 1;                                 // first width row
   xb = (xb > 1.0 - 1e-6) ? 1.0 - 1e-6 : xb;                       // :167
   double W[KM];
   double wn = 0.0;
 #pragma unroll
   for (int k = 0; k < KM; ++k) {
-    W[k] = (KEXACT || k < K) ? zr[(K + 1 + k) * ZS] : 0.0;
+    W[k] = (REL && k == KM - 1) ? 1.0 : (KEXACT || k < K) ? zr[(WO + k) * ZS] : 0.0;
     if (KEXACT || k < K) wn += W[k];                              // Wsum[-1]  :180-182
   }
   int idx;
@@ -1002,12 +1005,22 @@ __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const do
 #pragma unroll
   for (int k = 0; k < KM; ++k)
     if (KEXACT || k < K) {
-      const double vn = zr[(k + 1) * ZS];
+      const double vn = (REL && k == KM - 1) ? 1.0 : zr[(k + 1) * ZS];
       pre = (k == idx) ? A : pre;                                 // VW[idx] A  :209-211
       A = fma(vk + vn, W[k], A);                                  // :194
       vk = vn;
     }
-  const double Vb = zr[idx * ZS], Vb1 = zr[(idx + 1) * ZS], Wb = zr[(K + 1 + idx) * ZS];
+  double Vb = zr[idx * ZS], Vb1, Wb;
+  if (REL) {                                                      // the two constant rows are not in the image
+    const bool lastb = idx == K - 1;
+    Vb1 = zr[(lastb ? idx : idx + 1) * ZS];
+    Wb = zr[(WO + (lastb ? 0 : idx)) * ZS];
+    Vb1 = lastb ? 1.0 : Vb1;
+    Wb = lastb ? 1.0 : Wb;
+  } else {
+    Vb1 = zr[(idx + 1) * ZS];
+    Wb = zr[(WO + idx) * ZS];
+  }
   const double r = nis_rcp(Wb * A);                               // one reciprocal for both divisions (see pwquad_column)
   const double iA = r * Wb;
   const double alpha = (xb * wn - run) * (r * A);                 // :206-207
@@ -1342,12 +1355,17 @@ static inline bool nis_mfma_fusable(int kind, int km) { return kind != NIS_PWQUA
 static inline int nis_mf_regmode(int kind, int K, int T, int wm) {
 #ifdef NIS_DIAG
   const char* e = getenv("NIS_REGBIJ");
-  if (!e || atoi(e) == 0 || wm < 16) return 0;
-  if (kind == NIS_PWQUAD && K == 16 && T >= 1 && T <= 16) return 1;
-  if (kind == NIS_PWLIN && K >= 16 && K % 16 == 0) return 2;
+  if (e && atoi(e) != 0 && wm >= 16) {
+    if (kind == NIS_PWQUAD && K == 16 && T >= 1 && T <= 16) return 1;
+    if (kind == NIS_PWLIN && K >= 16 && K % 16 == 0) return 2;
+  }
 #endif
+  // PWQuad with K == KM on the matrix cores: the relative image (nis_common.h); NIS_NO_REL=1 keeps the reference rows (A/B runs)
+  static const bool no_rel = getenv("NIS_NO_REL") && atoi(getenv("NIS_NO_REL")) != 0;
+  if (NIS_MF_REL && !no_rel && wm >= 16 && kind == NIS_PWQUAD && (K == 4 || K == 8 || K == 16 || K == 32)) return NIS_PACK_REL;
   return 0;
 }
+static inline bool nis_mf_regbij(int regmode) { return regmode != 0 && regmode != NIS_PACK_REL; }
 #define NIS_DECL_WM(W)                                                                                                      \
   template <>                                                                                                               \
   int stats_blocks_per_cu<W>(int wx, bool folded);                                                                                          \

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(NIS_MF_TPB, WM <= 32 ? NIS_MF_STATS_WAVES : 1) void
 // lanes that share a sample each hold the contributions of their columns (transformed: the y they just computed;
 // pass-through: column p of lane group p % 4) and combine them with two shuffles, like the Jacobian product -- and with
 // fz.write_planes == 0 neither the transformed columns nor the Jacobian are stored (nothing reads them).
-template <int KIND, int WM, int KM, bool KEXACT, bool FUSE = false>
+// REL (PWQuad, K == KM): the last layer is the relative image (nis_common.h, NIS_PACK_REL): c.out = 2K - 1, c.R = T c.out at launch.
+template <int KIND, int WM, int KM, bool KEXACT, bool FUSE = false, bool REL = false>
 __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN) ? NIS_MF_WAVES_LIN : KM <= 16 ? NIS_MF_WAVES : 1) void k_cell_apply_mfma(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                                 int* __restrict__ bins_out, const double* __restrict__ wm_all,
                                                                 const double* __restrict__ wm_last, const double* __restrict__ bias_pad,
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
           double y, jf;
           int bin;
           if (KIND == NIS_PWQUAD) {
-            y = pwquad_column_lds<KM, KEXACT, 16>(xb, c.K, zr, &jf, &bin);
+            y = pwquad_column_lds<KM, KEXACT, 16, REL>(xb, c.K, zr, &jf, &bin);
           } else if (KIND == NIS_AFFINE) {
             // rows interleaved at pack time: [exp(z0), z1] per column (coupling_cells.py:56-68)
             const double s0 = 20.0 * zr[0], z1 = zr[16];

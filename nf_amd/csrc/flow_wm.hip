@@ -312,6 +312,15 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
 #include "flow_mfma_pc.h"           // producer / consumer wave roles: diagnostics build only (measured slower)
 #endif
 
+// the cell as the apply kernel sees it: with the relative image (NIS_PACK_REL) a column has 2K - 1 rows
+static CellK mf_view(const CellK& c_in) {
+  CellK c = c_in;
+  if (c.regmode == NIS_PACK_REL) {
+    c.out = 2 * c.K - 1;
+    c.R = c.T * c.out;
+  }
+  return c;
+}
 // per wave: the whole row tiles of one column batch (flow_mfma.h, mf_cb_tiles); at least the prologue's reduction scratch
 static size_t mf_ring_bytes_n(const CellK& c, int ncb) {
   const size_t ring = (size_t)(NIS_MF_TPB / 64) * mf_cb_tiles(c.T, c.out, c.R, ncb) * 256 * sizeof(double);
@@ -356,19 +365,21 @@ static bool mf_use_pc(const CellK&) { return false; }
 #endif
 
 template <>
-bool mfma_supported<NIS_WM>(const CellK& c) {
+bool mfma_supported<NIS_WM>(const CellK& c_in) {
+  const CellK c = mf_view(c_in);
   if (mf_use_pc(c)) return true;
 #ifdef NIS_DIAG
-  if (c.regmode) return true;                      // register-resident bijector: no LDS image
+  if (nis_mf_regbij(c.regmode)) return true;       // register-resident bijector: no LDS image
 #endif
   return mf_ring_bytes(c) + 24 * 1024 <= 160 * 1024 && (c.kind == NIS_PWLIN || c.K <= 32);
 }
 
 template <>
-int mfma_blocks_per_cu<NIS_WM>(const CellK& c) {
+int mfma_blocks_per_cu<NIS_WM>(const CellK& c_in) {
+  const CellK c = mf_view(c_in);
   if (mf_use_pc(c)) return 1;                      // one 512-thread workgroup per CU: a producer and a consumer wave per SIMD
 #ifdef NIS_DIAG
-  if (c.regmode) {                                 // registers decide: one 256-thread workgroup = one wave per SIMD
+  if (nis_mf_regbij(c.regmode)) {                             // registers decide: one 256-thread workgroup = one wave per SIMD
     static const int bpc = getenv("NIS_MFR_BPC") ? atoi(getenv("NIS_MFR_BPC")) : NIS_MFR_WAVES;
     return bpc;
   }
@@ -392,13 +403,24 @@ hipError_t launch_stats_mfma<NIS_WM>(const CellK& c, const MfmaW& w, const doubl
 #define NIS_APPLY_MFF(KIND, KMV)                                                                                                  \
   hipLaunchKernelGGL((k_cell_apply_mfma<KIND, NIS_WM, KMV, true, true>), dim3(grid, c.Gy), dim3(NIS_MF_TPB), mf_ring_bytes(c), s, c, planes, \
                      ld, N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad, fz)
+// PWQuad with K == KM: the relative image when the packer made one (c.regmode, nis_mf_regmode)
+#define NIS_APPLY_MFQ(KMV, FU)                                                                                                    \
+  do {                                                                                                                            \
+    if (rel)                                                                                                                      \
+      hipLaunchKernelGGL((k_cell_apply_mfma<NIS_PWQUAD, NIS_WM, KMV, true, FU, true>), dim3(grid, c.Gy), dim3(NIS_MF_TPB), mf_ring_bytes(c), \
+                         s, c, planes, ld, N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad, fz);                                 \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((k_cell_apply_mfma<NIS_PWQUAD, NIS_WM, KMV, true, FU, false>), dim3(grid, c.Gy), dim3(NIS_MF_TPB),         \
+                         mf_ring_bytes(c), s, c, planes, ld, N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad, fz);               \
+  } while (0)
 
 template <>
 hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* planes, long ld, long N, int bn_train, int km, int* bins,
                                      const FuseF& fz, int grid, hipStream_t s) {
-  CellK c = c_in;
+  CellK c = mf_view(c_in);
+  const bool rel = c.regmode == NIS_PACK_REL;
 #ifdef NIS_DIAG
-  if (c.regmode) {                       // PWQuad K = 16 / PWLin K = 16 m: bijector on the accumulator registers (flow_mfma_reg.h)
+  if (nis_mf_regbij(c.regmode)) {        // PWQuad K = 16 / PWLin K = 16 m: bijector on the accumulator registers (flow_mfma_reg.h)
     const bool fuse = fz.kind >= 0;
     if (fuse && (bins || fz.fres)) return hipErrorInvalidValue;
 #define NIS_APPLY_MFR(KIND, FU)                                                                                               \
@@ -417,7 +439,7 @@ hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* 
 #endif
 #ifdef NIS_DIAG
   if (mf_use_pc(c)) {                    // wave-specialised producer / consumer kernel (flow_mfma_pc.h)
-    c.mf_ncb = mfpc_pick_ncb(c_in);
+    c.mf_ncb = mfpc_pick_ncb(c);
     const size_t ring = mfpc_ring_bytes_n(c, c.mf_ncb);
     const bool fuse = fz.kind >= 0;
     if (fuse && (!nis_mfma_fusable(c.kind, km) || bins || fz.fres)) return hipErrorInvalidValue;
@@ -450,7 +472,8 @@ hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* 
     return hipGetLastError();
   }
 #endif
-  c.mf_ncb = mf_pick_ncb(c_in);
+  c.mf_ncb = mf_pick_ncb(c);
+  if (rel && (c.kind != NIS_PWQUAD || km >= 0)) return hipErrorInvalidValue;
   if (fz.kind >= 0) {                      // last cell of an integrate step: integrand * J + moment records fused (FUSE instantiations)
     if (!nis_mfma_fusable(c.kind, km) || bins || fz.fres) return hipErrorInvalidValue;
     if (c.kind == NIS_PWLIN) {
@@ -459,10 +482,10 @@ hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* 
       NIS_APPLY_MFF(NIS_AFFINE, 4);
     } else {
       switch (km) {
-        case -4: NIS_APPLY_MFF(NIS_PWQUAD, 4); break;
-        case -8: NIS_APPLY_MFF(NIS_PWQUAD, 8); break;
-        case -16: NIS_APPLY_MFF(NIS_PWQUAD, 16); break;
-        case -32: NIS_APPLY_MFF(NIS_PWQUAD, 32); break;
+        case -4: NIS_APPLY_MFQ(4, true); break;
+        case -8: NIS_APPLY_MFQ(8, true); break;
+        case -16: NIS_APPLY_MFQ(16, true); break;
+        case -32: NIS_APPLY_MFQ(32, true); break;
         default: return hipErrorInvalidValue;
       }
     }
@@ -478,10 +501,10 @@ hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* 
       case 8: NIS_APPLY_MF(NIS_PWQUAD, 8, false); break;
       case 16: NIS_APPLY_MF(NIS_PWQUAD, 16, false); break;
       case 32: NIS_APPLY_MF(NIS_PWQUAD, 32, false); break;
-      case -4: NIS_APPLY_MF(NIS_PWQUAD, 4, true); break;
-      case -8: NIS_APPLY_MF(NIS_PWQUAD, 8, true); break;
-      case -16: NIS_APPLY_MF(NIS_PWQUAD, 16, true); break;
-      case -32: NIS_APPLY_MF(NIS_PWQUAD, 32, true); break;
+      case -4: NIS_APPLY_MFQ(4, false); break;
+      case -8: NIS_APPLY_MFQ(8, false); break;
+      case -16: NIS_APPLY_MFQ(16, false); break;
+      case -32: NIS_APPLY_MFQ(32, false); break;
       default: return hipErrorInvalidValue;
     }
   }

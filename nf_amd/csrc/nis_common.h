@@ -181,12 +181,30 @@ struct FuseF {
   double* fres;           // optional per-sample f*J
 };
 
+// Relative image of a PWQuad last Linear (matrix-core apply kernel).  The bijector is invariant under a common factor of a column's
+// K + 1 heights and under a common factor of its K widths (coupling_cells.py:176-225: the widths are normalised by their sum, the
+// heights by the trapezoid integral), so exp(z_k - z_ref) serves as well as exp(z_k): the packer subtracts the row of V[K] from the other
+// height rows and the row of W[K-1] from the other width rows, the two reference rows become the constant 1 and are not computed --
+// 2K - 1 rows per column instead of 2K + 1 (C4: 155 rows = 10 tiles instead of 165 = 11; C5: 248 = 16 tiles instead of 264 = 17).
+#ifndef NIS_MF_REL
+#define NIS_MF_REL 1
+#endif
+#define NIS_PACK_REL 3
+// packed row j -> row of the reference-order last Linear (-1: zero padding); *js = the row subtracted from it
+__host__ __device__ inline int nis_rel_row(int T, int K, int j, int* js) {
+  const int o = 2 * K - 1, t = j / o, q = j % o, b = t * (2 * K + 1);
+  *js = -1;
+  if (t >= T) return -1;
+  *js = q < K ? b + K : b + 2 * K;
+  return q < K ? b + q : b + q + 1;
+}
+
 // Per-launch view of one coupling cell (passed by value in the kernarg segment: every field is
 // wave-uniform, so plane indices / sizes live in SGPRs).
 struct CellK {
   int kind, d, P, T, K, L, out, R;       // out = conditioner outputs per transformed column, R = T*out
   int mf_ncb;                            // matrix-core apply kernel: transformed columns per bijector batch (4, 2 or 1; set at launch)
-  int regmode;                           // != 0: the last Linear is packed for the register-resident bijector (flow_mfma_reg.h: MF_REG_*)
+  int regmode;                           // row order of the last Linear's matrix-core image: 0 reference order, NIS_PACK_REL, or (diagnostics build) MF_REG_* of flow_mfma_reg.h
   int width[NIS_MAX_HIDDEN];
   int in_plane[NIS_MAX_DIM];             // local column j -> state plane
   int jplane;                            // plane of the running Jacobian
