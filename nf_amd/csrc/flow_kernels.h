@@ -984,7 +984,7 @@ __device__ __forceinline__ double pwquad_column_big(double xb, int K, const doub
 // Same transform with the raw heights / widths in an LDS image (element k of the column at zr[k * ZS]: rows 0..K heights,
 // K+1..2K widths), as the matrix-core kernels keep them: the widths are streamed for the bin search, the trapezoid sums
 // stream the heights, and V_b, V_{b+1}, W_b are read BY INDEX instead of through K-long select chains.
-// REL: the relative image (nis_common.h, NIS_PACK_REL): rows 0..K-1 = V[k] / V[K], rows K..2K-2 = W[k] / W[K-1]; V[K] = W[K-1] = 1.
+// REL: the relative image (nis_common.h, NIS_PACK_REL): rows 0..K-1 = V[k] / V[K], rows K..2K-2 = W[k] / W[K-1], row 2K-1 unused; V[K] = W[K-1] = 1.
 template <int KM, bool KEXACT, int ZS, bool REL = false>
 __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const double* zr, double* jf, int* bin) {
   static_assert(!REL || KEXACT, "the relative image exists for K == KM only");
@@ -1360,9 +1360,8 @@ static inline int nis_mf_regmode(int kind, int K, int T, int wm) {
     if (kind == NIS_PWLIN && K >= 16 && K % 16 == 0) return 2;
   }
 #endif
-  // PWQuad with K == KM on the matrix cores: the relative image (nis_common.h); NIS_NO_REL=1 keeps the reference rows (A/B runs)
-  static const bool no_rel = getenv("NIS_NO_REL") && atoi(getenv("NIS_NO_REL")) != 0;
-  if (NIS_MF_REL && !no_rel && wm >= 16 && kind == NIS_PWQUAD && (K == 4 || K == 8 || K == 16 || K == 32)) return NIS_PACK_REL;
+  // PWQuad with K == KM on the matrix cores: the relative image (nis_common.h; -DNIS_MF_REL=0 builds the reference rows for A/B runs)
+  if (NIS_MF_REL && wm >= 16 && kind == NIS_PWQUAD && (K == 4 || K == 8 || K == 16 || K == 32)) return NIS_PACK_REL;
   return 0;
 }
 static inline bool nis_mf_regbij(int regmode) { return regmode != 0 && regmode != NIS_PACK_REL; }

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, WM <= 32 ? NIS_MF_STATS_WAVES : 1) void
 // lanes that share a sample each hold the contributions of their columns (transformed: the y they just computed;
 // pass-through: column p of lane group p % 4) and combine them with two shuffles, like the Jacobian product -- and with
 // fz.write_planes == 0 neither the transformed columns nor the Jacobian are stored (nothing reads them).
-// REL (PWQuad, K == KM): the last layer is the relative image (nis_common.h, NIS_PACK_REL): c.out = 2K - 1, c.R = T c.out at launch.
+// REL (PWQuad, K == KM): the last layer is the relative image (nis_common.h, NIS_PACK_REL): c.out = 2K, c.R = T c.out at launch.
 template <int KIND, int WM, int KM, bool KEXACT, bool FUSE = false, bool REL = false>
 __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN) ? NIS_MF_WAVES_LIN : KM <= 16 ? NIS_MF_WAVES : 1) void k_cell_apply_mfma(CellK c, double* __restrict__ planes, long ld, long N, int bn_train,
                                                                 int* __restrict__ bins_out, const double* __restrict__ wm_all,

@@ -312,11 +312,11 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
 #include "flow_mfma_pc.h"           // producer / consumer wave roles: diagnostics build only (measured slower)
 #endif
 
-// the cell as the apply kernel sees it: with the relative image (NIS_PACK_REL) a column has 2K - 1 rows
+// the cell as the apply kernel sees it: with the relative image (NIS_PACK_REL) a column has 2K rows (2K - 1 computed, one zero row)
 static CellK mf_view(const CellK& c_in) {
   CellK c = c_in;
   if (c.regmode == NIS_PACK_REL) {
-    c.out = 2 * c.K - 1;
+    c.out = nis_rel_out(c.K);
     c.R = c.T * c.out;
   }
   return c;
@@ -403,16 +403,10 @@ hipError_t launch_stats_mfma<NIS_WM>(const CellK& c, const MfmaW& w, const doubl
 #define NIS_APPLY_MFF(KIND, KMV)                                                                                                  \
   hipLaunchKernelGGL((k_cell_apply_mfma<KIND, NIS_WM, KMV, true, true>), dim3(grid, c.Gy), dim3(NIS_MF_TPB), mf_ring_bytes(c), s, c, planes, \
                      ld, N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad, fz)
-// PWQuad with K == KM: the relative image when the packer made one (c.regmode, nis_mf_regmode)
+// PWQuad with K == KM: the relative image (nis_common.h: NIS_MF_REL is a build-time choice, one instantiation per shape)
 #define NIS_APPLY_MFQ(KMV, FU)                                                                                                    \
-  do {                                                                                                                            \
-    if (rel)                                                                                                                      \
-      hipLaunchKernelGGL((k_cell_apply_mfma<NIS_PWQUAD, NIS_WM, KMV, true, FU, true>), dim3(grid, c.Gy), dim3(NIS_MF_TPB), mf_ring_bytes(c), \
-                         s, c, planes, ld, N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad, fz);                                 \
-    else                                                                                                                          \
-      hipLaunchKernelGGL((k_cell_apply_mfma<NIS_PWQUAD, NIS_WM, KMV, true, FU, false>), dim3(grid, c.Gy), dim3(NIS_MF_TPB),         \
-                         mf_ring_bytes(c), s, c, planes, ld, N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad, fz);               \
-  } while (0)
+  hipLaunchKernelGGL((k_cell_apply_mfma<NIS_PWQUAD, NIS_WM, KMV, true, FU, NIS_MF_REL != 0>), dim3(grid, c.Gy), dim3(NIS_MF_TPB),    \
+                     mf_ring_bytes(c), s, c, planes, ld, N, bn_train, bins, w.wm_all, w.wm_last, w.bias_pad, fz)
 
 template <>
 hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* planes, long ld, long N, int bn_train, int km, int* bins,
@@ -473,7 +467,7 @@ hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* 
   }
 #endif
   c.mf_ncb = mf_pick_ncb(c);
-  if (rel && (c.kind != NIS_PWQUAD || km >= 0)) return hipErrorInvalidValue;
+  if (rel != (NIS_MF_REL != 0 && c.kind == NIS_PWQUAD && km < 0)) return hipErrorInvalidValue;      // packer and launcher disagree
   if (fz.kind >= 0) {                      // last cell of an integrate step: integrand * J + moment records fused (FUSE instantiations)
     if (!nis_mfma_fusable(c.kind, km) || bins || fz.fres) return hipErrorInvalidValue;
     if (c.kind == NIS_PWLIN) {

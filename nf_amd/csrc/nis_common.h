@@ -184,17 +184,20 @@ struct FuseF {
 // Relative image of a PWQuad last Linear (matrix-core apply kernel).  The bijector is invariant under a common factor of a column's
 // K + 1 heights and under a common factor of its K widths (coupling_cells.py:176-225: the widths are normalised by their sum, the
 // heights by the trapezoid integral), so exp(z_k - z_ref) serves as well as exp(z_k): the packer subtracts the row of V[K] from the other
-// height rows and the row of W[K-1] from the other width rows, the two reference rows become the constant 1 and are not computed --
-// 2K - 1 rows per column instead of 2K + 1 (C4: 155 rows = 10 tiles instead of 165 = 11; C5: 248 = 16 tiles instead of 264 = 17).
+// height rows and the row of W[K-1] from the other width rows, the two reference rows become the constant 1 and are not computed.
+// A column then has 2K - 1 rows; the image gives it 2K (one zero row at the end), so that a batch of columns is a whole number of
+// 16-row tiles for every K the image exists for (4, 8, 16, 32) and no tile is computed for two batches: C4's cells with T = 5 take
+// 10 tile products per 16 samples instead of 9 + 3 (reference rows: 33 per column, batches of 4 columns = 132 rows), C5's 16 instead of 9 + 9.
 #ifndef NIS_MF_REL
 #define NIS_MF_REL 1
 #endif
 #define NIS_PACK_REL 3
-// packed row j -> row of the reference-order last Linear (-1: zero padding); *js = the row subtracted from it
+__host__ __device__ inline int nis_rel_out(int K) { return 2 * K; }          // rows per column in the relative image
+// packed row j -> row of the reference-order last Linear (-1: zero row); *js = the row subtracted from it
 __host__ __device__ inline int nis_rel_row(int T, int K, int j, int* js) {
-  const int o = 2 * K - 1, t = j / o, q = j % o, b = t * (2 * K + 1);
+  const int o = nis_rel_out(K), t = j / o, q = j % o, b = t * (2 * K + 1);
   *js = -1;
-  if (t >= T) return -1;
+  if (t >= T || q == o - 1) return -1;
   *js = q < K ? b + K : b + 2 * K;
   return q < K ? b + q : b + q + 1;
 }

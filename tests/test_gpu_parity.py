@@ -83,7 +83,11 @@ def test_cell_vs_reference_golden(case, g_cells):
                                              # PWQuad with more than 32 bins: heights / widths in per-thread scratch arrays (pwquad_column_big);
                                              # wide conditioners take the fp64 VALU kernel there (the matrix-core image kernel stops at 32)
                                              ("pwquad", 3, 1, 33, [4, 4], 2000), ("pwquad", 5, 2, 100, [8, 6], 1200),
-                                             ("pwquad", 4, 2, 128, [3], 900), ("pwquad", 6, 3, 64, [32, 32], 700)])
+                                             ("pwquad", 4, 2, 128, [3], 900), ("pwquad", 6, 3, 64, [32, 32], 700),
+                                             # matrix-core PWQuad heads with K == KM: the relative last-layer image (NIS_PACK_REL), 2K - 1 rows per
+                                             # column -- column batches that start inside a row tile, one column, every K the image exists for
+                                             ("pwquad", 7, 3, 4, [16, 16], 1100), ("pwquad", 9, 2, 8, [40, 40], 900),
+                                             ("pwquad", 5, 4, 16, [24], 1300), ("pwquad", 11, 2, 16, [64, 64], 650)])
 @pytest.mark.parametrize("train", [True, False])
 def test_cell_vs_oracle_seeded(kind, d, P, K, NN, N, train):
     from nf_amd.normalizing_flows.layers.coupling_cells import PWLin, PWQuad
