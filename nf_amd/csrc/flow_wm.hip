@@ -357,7 +357,8 @@ static int mfpc_pick_ncb(const CellK& c) {           // 0: no batch size fits
 }
 static bool mf_use_pc(const CellK& c) {
   const char* e = getenv("NIS_MF_PC");
-  // PWQuad with more than 16 bins keeps the one-wave-per-SIMD kernel (its bin arrays need > 256 registers)
+  // PWQuad with more than 16 bins keeps the one-wave-per-SIMD kernel (its bin arrays need > 256 registers); cells packed as the relative
+  // image (regmode NIS_PACK_REL: PWQuad with K == KM) keep the product kernel too -- build with -DNIS_MF_REL=0 to A/B this variant on them
   return e && atoi(e) != 0 && !c.regmode && (c.kind != NIS_PWQUAD || c.K <= 16) && mfpc_pick_ncb(c) > 0;
 }
 #else
