@@ -548,24 +548,39 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
             const double alpha = (ak - bf) / c.K;
             bin = (int)bf;
             // heights streamed from the image EIGHT reads at a time (one read per trip left the LDS round trip, ~130 cycles, in
-            // front of every height: at K = 64 that loop was as long as the MFMA phase and pure latency); the bin's own height
-            // is read back by index.  Same sequential sums as before.
+            // front of every height: at K = 64 that loop was as long as the MFMA phase and pure latency).  Whole blocks of eight are
+            // summed as a tree and only the running total in front of the bin's block is kept (11 instead of 32 vector instructions
+            // per block); the heights of that one block left of the bin are added in a second pass over its eight values, read by
+            // index.  Blocked instead of sequential sums: <= 1-2 ulp of the total, the bin index does not depend on them.
             double tot = 0.0, below = 0.0;
+            const int binc = bin < 0 ? 0 : bin >= c.K ? c.K - 1 : bin;
+            const int kblk = c.K & ~7;                                                    // heights in whole blocks
+            const bool inblk = binc < kblk;
+            const int jb8 = inblk ? (binc & ~7) : 0;                                      // first height of the bin's block
             int k0 = 0;
-            for (; k0 + 8 <= c.K; k0 += 8) {
+            for (; k0 < kblk; k0 += 8) {
               double e[8];
 #pragma unroll
               for (int u = 0; u < 8; ++u) e[u] = zr[(k0 + u) * 16];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                below = (k0 + u == bin) ? tot : below;
-                tot += e[u];                                                              // :117
-              }
+              const double b = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+              below = (k0 == jb8 && inblk) ? tot : below;
+              tot += b;                                                                   // :117
             }
-            for (; k0 < c.K; ++k0) {
+            for (; k0 < c.K; ++k0) {                                                      // K % 8 trailing heights, one by one
               const double e = zr[k0 * 16];
               below = (k0 == bin) ? tot : below;
               tot += e;
+            }
+            if (kblk > 0) {
+              const double* zb = zr + (size_t)jb8 * 16;
+              const int rb = inblk ? binc - jb8 : 0;
+              double part = 0.0;
+#pragma unroll
+              for (int u = 0; u < 7; ++u) {
+                const double e = zb[u * 16];
+                part += (u < rb) ? e : 0.0;
+              }
+              below += part;
             }
             double qb = zr[(bin < 0 ? 0 : bin >= c.K ? c.K - 1 : bin) * 16];
             if (bin < 0 || bin >= c.K) {
