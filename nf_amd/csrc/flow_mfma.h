@@ -414,6 +414,12 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
     for (int r = 0; r < 4; ++r) bnx[r] = bias_pad[16 * jt + gq + 4 * r];
   };
   const int ncb = (c.T + NCB - 1) / NCB;
+  // PWLin with fewer than four columns per batch: the lane groups without a column of their own take a share of the heights of
+  // another group's column (nsp lanes per column and sample, each sums K / nsp heights -- whole blocks of eight -- and the partial
+  // sums meet in one or two exchanges); lane group `part` 0 of a column owns its outputs.  Other cells: one lane per column.
+  const int nsp = (KIND == NIS_PWLIN && NCB < 4 && c.K % (32 / NCB) == 0) ? 4 / NCB : 1;
+  const int slot = nsp > 1 ? (gq & (NCB - 1)) : gq, part = nsp > 1 ? gq / NCB : 0;
+  const bool colane = nsp > 1 || gq < NCB;
   load_tile(0);
   // the pass-through block of the NEXT pair of sample tiles is requested one iteration ahead (cells with P <= 8: two k-steps)
   constexpr int PQ = 2;
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
       // requests of this sample tile that nothing below has to wait for: first column batch's xb, incoming Jacobian
       double xbn = 0.0, jinq = 1.0;
       if (NIS_MF_PREFETCH) {
-        if (gq < NCB && gq < c.T && i < N) xbn = planes[(size_t)lds_plane[c.P + gq] * ld + i];
+        if (colane && slot < c.T && i < N) xbn = planes[(size_t)lds_plane[c.P + slot] * ld + i];
         if (!c.first && gq == 0 && i < N) jinq = planes[(size_t)c.jplane * ld + i];
       }
       if (FUSE) {
@@ -485,11 +491,11 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
       for (int cb = 0; cb < ncb; ++cb) {
         const int r0 = cb * NCB * out;
         const int r1 = min(c.R, r0 + NCB * out);
-        const int t = cb * NCB + gq;
+        const int t = cb * NCB + slot;
         const double xbq = xbn;                        // requested one column batch ago
         if (NIS_MF_PREFETCH) {
           const int tn = t + NCB;
-          xbn = (gq < NCB && tn < c.T && i < N) ? planes[(size_t)lds_plane[c.P + (tn < c.T ? tn : 0)] * ld + i] : 0.0;
+          xbn = (colane && tn < c.T && i < N) ? planes[(size_t)lds_plane[c.P + (tn < c.T ? tn : 0)] * ld + i] : 0.0;
         }
         const int jt_first_next = (cb + 1 < ncb) ? ((cb + 1) * NCB * out) / 16 : 0;      // cyclic: the next sample tile starts at row tile 0
         const int jt0 = r0 / 16;
@@ -527,10 +533,10 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
         // the image written above is complete; the wave barriers only pin the compiler's schedule.
         __builtin_amdgcn_wave_barrier();
         MF_STAMP(st_tiles);
-        if (gq < NCB && t < c.T && i < N) {
+        if (colane && t < c.T && i < N) {
           double* col = planes + (size_t)lds_plane[c.P + t] * ld;
           const double xb = NIS_MF_PREFETCH ? xbq : col[i];
-          const double* zr = ring + (size_t)((r0 & 15) + gq * out) * 16 + s;
+          const double* zr = ring + (size_t)((r0 & 15) + slot * out) * 16 + s;
           double y, jf;
           int bin;
           if (KIND == NIS_PWQUAD) {
@@ -554,11 +560,12 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
             // index.  Blocked instead of sequential sums: <= 1-2 ulp of the total, the bin index does not depend on them.
             double tot = 0.0, below = 0.0;
             const int binc = bin < 0 ? 0 : bin >= c.K ? c.K - 1 : bin;
-            const int kblk = c.K & ~7;                                                    // heights in whole blocks
-            const bool inblk = binc < kblk;
+            const int kbeg = nsp > 1 ? part * (c.K / nsp) : 0;                            // this lane's heights [kbeg, kend): whole blocks
+            const int kend = nsp > 1 ? kbeg + c.K / nsp : (c.K & ~7);
+            const bool inblk = binc < (c.K & ~7);
             const int jb8 = inblk ? (binc & ~7) : 0;                                      // first height of the bin's block
-            int k0 = 0;
-            for (; k0 < kblk; k0 += 8) {
+            int k0 = kbeg;
+            for (; k0 < kend; k0 += 8) {
               double e[8];
 #pragma unroll
               for (int u = 0; u < 8; ++u) e[u] = zr[(k0 + u) * 16];
@@ -566,25 +573,37 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
               below = (k0 == jb8 && inblk) ? tot : below;
               tot += b;                                                                   // :117
             }
-            for (; k0 < c.K; ++k0) {                                                      // K % 8 trailing heights, one by one
-              const double e = zr[k0 * 16];
-              below = (k0 == bin) ? tot : below;
-              tot += e;
+            if (nsp > 1) {
+              below = (inblk && jb8 >= kend) ? tot : below;                               // the bin lies in a later lane's share: all of this one is below it
+            } else {
+              for (; k0 < c.K; ++k0) {                                                    // K % 8 trailing heights, one by one
+                const double e = zr[k0 * 16];
+                below = (k0 == bin) ? tot : below;
+                tot += e;
+              }
             }
-            if (kblk > 0) {
+            if (kend > kbeg) {
               const double* zb = zr + (size_t)jb8 * 16;
-              const int rb = inblk ? binc - jb8 : 0;
-              double part = 0.0;
+              const int rb = (inblk && jb8 >= kbeg && jb8 < kend) ? binc - jb8 : 0;       // (the lane whose share holds the bin's block)
+              double bpart = 0.0;
 #pragma unroll
               for (int u = 0; u < 7; ++u) {
                 const double e = zb[u * 16];
-                part += (u < rb) ? e : 0.0;
+                bpart += (u < rb) ? e : 0.0;
               }
-              below += part;
+              below += bpart;
+            }
+            if (nsp > 1) {                                                                // partner lanes: same sample, same column (all active together)
+              tot += __shfl_xor(tot, 32, 64);
+              below += __shfl_xor(below, 32, 64);
+              if (nsp == 4) {
+                tot += __shfl_xor(tot, 16, 64);
+                below += __shfl_xor(below, 16, 64);
+              }
             }
             double qb = zr[(bin < 0 ? 0 : bin >= c.K ? c.K - 1 : bin) * 16];
             if (bin < 0 || bin >= c.K) {
-              if (c.status) atomicOr(c.status, 1);
+              if (c.status && part == 0) atomicOr(c.status, 1);
               qb = __builtin_nan("");
             }
             const double itot = nis_rcp(tot);                                             // one Newton-refined reciprocal for both
@@ -592,16 +611,18 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
             y = qn * alpha + below * itot;                                                // :123,136-139
             jf = qn;                                                                      // :141
           }
-          if (wplanes) col[c.out_off + i] = y;
-          jprod *= jf;
-          if (FUSE) {
-            if (fz.kind == NIS_F_NORMAL) facc = fma((y - fz.p[0]) * (y - fz.p[0]), f_i2s, facc);
-            if (fz.kind == NIS_F_CAMEL) {
-              fc0 = (c.P + t == fz.loc0) ? y : fc0;
-              fc1 = (c.P + t == fz.loc1) ? y : fc1;
+          if (part == 0) {                                                                // (every lane of a shared column holds the same y, jf)
+            if (wplanes) col[c.out_off + i] = y;
+            jprod *= jf;
+            if (FUSE) {
+              if (fz.kind == NIS_F_NORMAL) facc = fma((y - fz.p[0]) * (y - fz.p[0]), f_i2s, facc);
+              if (fz.kind == NIS_F_CAMEL) {
+                fc0 = (c.P + t == fz.loc0) ? y : fc0;
+                fc1 = (c.P + t == fz.loc1) ? y : fc1;
+              }
             }
+            if (KIND != NIS_AFFINE && bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
           }
-          if (KIND != NIS_AFFINE && bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
         }
         __builtin_amdgcn_wave_barrier();
         MF_STAMP(st_bij);
