@@ -806,6 +806,26 @@ __device__ __forceinline__ double lerp_torch(double a, double b, double w) {
 // band around fl(x * wn) (then the correctly rounded quotient provably falls on the same side of x); inside the band
 // -- probability ~1e-15 per bin -- the true division decides.  One division yields the selected left edge.
 // Ties (equal Wsum for consecutive bins, i.e. widths that vanish in the cumsum) resolve to the first bin, as argmax does.
+// the search with the reference's own comparison (one division per bin), for the columns the multiplied-out tests cannot decide
+template <int KM>
+__device__ __forceinline__ void pwquad_bin_divide(double xb, int K, const double (&W)[KM], double wn, int* idx_out, double* run_out) {
+  double run = 0.0, bestrun = 0.0;
+  int idx = 0;
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    double wk = W[0];
+#pragma unroll
+    for (int u = 1; u < KM; ++u) wk = (u == k) ? W[u] : wk;
+    run += wk;
+    const bool le = !((run / wn) > xb);                  // the reference's comparison, verbatim
+    const bool up = le && (run > bestrun);
+    bestrun = up ? run : bestrun;
+    idx = up ? k + 1 : idx;
+  }
+  *idx_out = idx;
+  *run_out = bestrun;
+}
+
 template <int KM, bool KEXACT>
 __device__ __forceinline__ void pwquad_bin_raw(double xb, int Krt, const double (&W)[KM], double wn, int* idx_out, double* run_out) {
   const int K = KEXACT ? KM : Krt;
@@ -824,22 +844,7 @@ __device__ __forceinline__ void pwquad_bin_raw(double xb, int Krt, const double 
       bestrun = up ? run : bestrun;
       idx = up ? k + 1 : idx;
     }
-  if (__any(ambany)) {                                   // one wave-uniform test per column; practically never taken
-    run = 0.0;
-    bestrun = 0.0;
-    idx = 0;
-#pragma unroll 1
-    for (int k = 0; k < K; ++k) {
-      double wk = W[0];
-#pragma unroll
-      for (int u = 1; u < KM; ++u) wk = (u == k) ? W[u] : wk;
-      run += wk;
-      const bool le = !((run / wn) > xb);                // the reference's comparison, verbatim
-      const bool up = le && (run > bestrun);
-      bestrun = up ? run : bestrun;
-      idx = up ? k + 1 : idx;
-    }
-  }
+  if (__any(ambany)) pwquad_bin_divide<KM>(xb, K, W, wn, &idx, &bestrun);      // one wave-uniform test per column; practically never taken
   // Wsum2[idx] = bestrun / wn (:186, :198) must exceed the 1e-30 sentinel, else bin 0 with left edge 0 wins; tested on
   // the raw sum (equivalent unless the quotient is within an ulp of 1e-30)
   const bool none = !(bestrun > 1e-30 * wn);
@@ -998,9 +1003,36 @@ __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const do
     W[k] = (REL && k == KM - 1) ? 1.0 : (KEXACT || k < K) ? zr[(WO + k) * ZS] : 0.0;
     if (KEXACT || k < K) wn += W[k];                              // Wsum[-1]  :180-182
   }
-  int idx;
-  double run;
-  pwquad_bin_raw<KM, KEXACT>(xb, Krt, W, wn, &idx, &run);
+  // Bin search.  The cumulative widths never decrease, so the bin is the NUMBER of edges at or below the lower end of the band around
+  // x * wn (pwquad_bin_raw: 2^-50 relative), and only the two edges next to it can make the multiplied-out test differ from the
+  // reference's divisions: the bin's right edge inside the band, or a width that vanished in the sum right below it (the reference's argmax
+  // takes the FIRST of equal edges).  Both are checked on W[idx], W[idx - 1] read back by index; a wave with such a column -- probability
+  // ~1e-15 per bin -- runs the search with the divisions.  5 vector instructions per bin instead of 11.
+  int idx = 0;
+  double run = 0.0;
+  {
+    const double q = xb * wn;
+    const double qlo = q * (1.0 - 0x1p-50), qhi = q * (1.0 + 0x1p-50);
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+      if (KEXACT || k < K) {
+        acc += W[k];
+        const bool le = acc <= qlo;
+        run = le ? acc : run;
+        idx += le ? 1 : 0;
+      }
+    const int ir = idx > K - 1 ? K - 1 : idx, il = idx > 0 ? idx - 1 : 0;
+    const double wr = (REL && ir == K - 1) ? 1.0 : zr[(WO + (REL && ir == K - 1 ? 0 : ir)) * ZS];
+    const double wl = (REL && il == K - 1) ? 1.0 : zr[(WO + (REL && il == K - 1 ? 0 : il)) * ZS];
+    const bool amb = idx < K && run + wr < qhi;                    // (run + W[idx] IS the next edge of the loop above, bit for bit)
+    const bool tie = idx > 0 && !(wl > run * 0x1p-52);             // W[idx - 1] may have vanished in the sum: equal edges
+    if (__any(amb || tie)) pwquad_bin_divide<KM>(xb, K, W, wn, &idx, &run);
+    const bool none = !(run > 1e-30 * wn);                         // :186, :198 (see pwquad_bin_raw)
+    idx = none ? 0 : idx;
+    run = none ? 0.0 : run;
+    idx = (idx > K - 1) ? K - 1 : idx;
+  }
   double A = 0.0, pre = 0.0, vk = zr[0];
 #pragma unroll
   for (int k = 0; k < KM; ++k)
