@@ -117,6 +117,44 @@ def test_cell_vs_oracle_seeded(kind, d, P, K, NN, N, train):
             np.testing.assert_allclose(t2n(sd[k[2:]]), v, rtol=1e-11, atol=1e-14, err_msg=k)
 
 
+@pytest.mark.parametrize("d,P,K,NN", [(3, 1, 8, [4, 4]), (6, 3, 16, [32, 32]), (5, 2, 4, [16, 16]), (4, 2, 20, [24])],
+                         ids=["narrow-K8", "matrixcore-K16-relative-image", "matrixcore-K4-relative-image", "matrixcore-K20-reference-rows"])
+def test_pwquad_vanishing_width_takes_the_reference_search(d, P, K, NN):
+    """A width that vanishes in the cumulative sum (exp(z) 1e-35 of its neighbours) leaves two EQUAL bin edges; the reference's argmax
+    (coupling_cells.py:198-202) takes the first of them, so samples right of the pair land in the zero-width bin.  The kernels' fast
+    searches (multiplied-out comparisons; in the matrix-core image kernel a COUNT of the edges below x) cannot see that and must hand the
+    wave to the search with the reference's own divisions (pwquad_bin_divide): bins bit-identical to the oracle, values wherever the
+    selected bin has a width."""
+    from nf_amd.normalizing_flows.layers.coupling_cells import PWQuad
+    torch.manual_seed(K)
+    cell = PWQuad(d, P, K, list(NN)).double()
+    T, k0 = d - P, K // 2
+    with torch.no_grad():
+        for p in cell.parameters():
+            p.add_(0.2 * torch.randn_like(p))
+        last = [m for m in cell.NN if isinstance(m, torch.nn.Linear)][-1]
+        for t in range(T):                                       # width row k0 of every column: exp(-80) relative
+            last.weight[t * (2 * K + 1) + K + 1 + k0].zero_()
+            last.bias[t * (2 * K + 1) + K + 1 + k0] = -80.0
+    params = {"c." + k: t2n(v) for k, v in cell.state_dict().items()}
+    N = 4000
+    x = torch.rand(N, d + 1, dtype=torch.double)
+    x[:, -1] += 0.5
+    for train in (True, False):
+        want, upd = {}, {}
+        y_ref = oflow.cell_forward(x.numpy(), params, "c", "pwquad", P, K, train, upd, want)
+        m = PWQuad(d, P, K, list(NN)).double()
+        m.load_state_dict(cell.state_dict())
+        m = m.to(dev()).train(train)
+        res = m._own_engine().forward(x.to(dev()), True, train, want_xj=True, want_bins=True)
+        bins = t2n(res["bins"]).T
+        np.testing.assert_array_equal(bins, want["bins"])
+        assert (bins == k0).any(), "no sample reached the zero-width bin: the case is not exercised"
+        ok = (bins != k0).all(axis=1)                            # rows whose every column sits in a bin with a width
+        assert ok.sum() > N // 4
+        np.testing.assert_allclose(t2n(res["xj"])[ok], y_ref[ok], rtol=RTOL, atol=ATOL)
+
+
 def test_cell_module_call_is_differentiable():
     """cell(x) is the reference's nn.Module surface: forward values from HIP, gradients available."""
     from nf_amd.normalizing_flows.layers.coupling_cells import PWQuad
