@@ -67,4 +67,4 @@ for name, fn in (("single", step_single), ("batched", step_batched)):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     print(f"{cfg} {name:8s} G={G} mbs={mbs}: {dt * 1e3:8.3f} ms/step wall, {e0.elapsed_time(e1) / steps:8.3f} ms/step stream, "
-          f"{G * mbs / dt / 1e6:9.1f} Msamples/s  loss={float(loss):.6e}", flush=True)
+          f"{G * mbs / dt / 1e6:9.1f} Msamples/s  loss={float(loss.detach()):.6e}", flush=True)
