@@ -834,9 +834,11 @@ __device__ __forceinline__ void pwquad_bin_raw(double xb, int Krt, const double 
   double run = 0.0, bestrun = 0.0;
   int idx = 0;
   bool ambany = false;
+  // the last edge is wn itself (same additions in the same order as the caller's sum): with x <= 1 - 1e-6 (every caller clamps, :167) it is
+  // neither at or below q (1 - 2^-50) nor inside the band, so K - 1 edges are examined
 #pragma unroll
-  for (int k = 0; k < KM; ++k)
-    if (KEXACT || k < K) {
+  for (int k = 0; k < KM - 1; ++k)
+    if (KEXACT || k < K - 1) {
       run += W[k];
       const bool le = run <= qlo;
       ambany |= (run > qlo) && (run < qhi);
@@ -1015,8 +1017,8 @@ __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const do
     const double qlo = q * (1.0 - 0x1p-50), qhi = q * (1.0 + 0x1p-50);
     double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < KM; ++k)
-      if (KEXACT || k < K) {
+    for (int k = 0; k < KM - 1; ++k)                                // (the last edge is wn: never at or below q, see pwquad_bin_raw)
+      if (KEXACT || k < K - 1) {
         acc += W[k];
         const bool le = acc <= qlo;
         run = le ? acc : run;
