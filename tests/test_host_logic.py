@@ -231,3 +231,51 @@ def test_pipelined_rambo_instantiations_do_not_spill():
             seen += 1
             assert int(spill.group(1)) == 0, f"k_rambo<{m.group(1)}, {m.group(2)}> spills {spill.group(1)} registers"
     assert seen >= 20, seen          # n = 2 .. 6, four modes each
+
+
+def test_relative_image_row_map_covers_every_row_once(tmp_path):
+    """nis_rel_row (nf_amd/csrc/nis_common.h): the relative last-layer image of a PWQuad cell gives a column 2K rows -- K heights minus the
+    row of V[K], K - 1 widths minus the row of W[K-1], one zero row.  Host-compiled check of the map the packer uses: every reference row
+    except the two subtracted ones appears exactly once, with the right row subtracted; padding rows map to -1."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    src = tmp_path / "relmap.cpp"
+    src.write_text(r'''
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "nis_common.h"
+int main() {
+  for (int K : {4, 8, 16, 32})
+    for (int T = 1; T <= 9; ++T) {
+      const int o = nis_rel_out(K), R = T * (2 * K + 1);
+      int seen[9 * 65] = {0};
+      for (int j = 0; j < 16 * ((T * o + 15) / 16); ++j) {
+        int js = -2;
+        const int jo = nis_rel_row(T, K, j, &js);
+        const int t = j / o, q = j % o;
+        if (t >= T || q == o - 1) { if (jo != -1 || js != -1) { printf("pad K=%d T=%d j=%d\n", K, T, j); return 1; } continue; }
+        if (jo < 0 || jo >= R || js < 0 || js >= R) { printf("range K=%d T=%d j=%d\n", K, T, j); return 1; }
+        const int b = t * (2 * K + 1);
+        const bool height = q < K;
+        if (js != (height ? b + K : b + 2 * K) || jo != (height ? b + q : b + K + 1 + (q - K))) { printf("map K=%d T=%d j=%d\n", K, T, j); return 1; }
+        ++seen[jo];
+      }
+      for (int r = 0; r < R; ++r) {
+        const int q = r % (2 * K + 1);
+        const int want = (q == K || q == 2 * K) ? 0 : 1;
+        if (seen[r] != want) { printf("cover K=%d T=%d r=%d seen=%d\n", K, T, r, seen[r]); return 1; }
+      }
+    }
+  printf("ok\n");
+  return 0;
+}
+''')
+    exe = tmp_path / "relmap"
+    r = subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "nf_amd", "csrc"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
