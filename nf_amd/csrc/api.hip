@@ -154,6 +154,14 @@ int nis_bwd_cell_run(const CellK& c, const nis_cell_desc& cd, int wm, const doub
                      long ld, long N, int G, long x_gs, long g_gs, long bn_gs, double* ws, double* gparams, const MfmaW& mw, bool eval_bn,
                      hipStream_t s);
 
+// BN_1 derived from the pass-through block's co-moments (CellK::dcov): 2 <= P <= 8, the record (3 P feature entries + P (P - 1) / 2
+// co-moments) must fit the 3 WM doubles of a BN record, AND the merge in load_coefs gives every pair one of its WM feature columns --
+// width 16 with P = 7 has 21 pairs: the record fits, the merge does not (pairs 16 .. 20 were never summed: BN_1 variances ~1 % off,
+// found by a shifted-seed sweep in round 3).
+static bool dcov_fits(int P, int WM) {
+  const int npair = P * (P - 1) / 2;
+  return P >= 2 && P <= 8 && 3 * P + npair <= 3 * WM && npair <= WM;
+}
 static bool use_mfma() {
   static const int off = nis_env_int("NIS_NO_MFMA", 0);
   return !off;
@@ -305,8 +313,8 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   ist.plane_gs = plane_gs;
   // a matrix-core first cell with 2..8 pass-through columns takes its BN_0 records from the covariance pass (CellK::dcov: BN_1 is
   // derived, the layer-1 statistics launch disappears) instead of the ingest rider, which has no co-moments
-  const bool cell0_cov = train && lay[0].WM >= 16 && use_mfma() && c0.P >= 2 && c0.P <= 8 && c0.n_hidden >= 2 &&
-                         3 * c0.P + c0.P * (c0.P - 1) / 2 <= 3 * lay[0].WM && !o.sync_fn && !nis_env_int("NIS_NO_DERIVE1", 0) &&
+  const bool cell0_cov = train && lay[0].WM >= 16 && use_mfma() && c0.n_hidden >= 2 && dcov_fits(c0.P, lay[0].WM) && !o.sync_fn &&
+                         !nis_env_int("NIS_NO_DERIVE1", 0) &&
                          !nis_env_int("NIS_NO_DCOV", 0);
   // ... unless the batch is DRAWN by the ingest launch (o.rng): that kernel holds a sample's whole row in registers and adds the
   // co-moments to its records, so the first cell needs neither the covariance pass nor its layer-1 statistics launch
@@ -550,7 +558,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       c.derive1 = (train && cd.P == 1 && !nis_env_int("NIS_NO_DERIVE1", 0)) ? 1 : 0;
       // matrix-core cells with 2..8 pass-through columns: BN_0's records carry the co-moments of the block, BN_1 is derived from
       // them and the layer-1 statistics launch is skipped (not with the multi-rank record exchange: its records are per feature)
-      c.dcov = (train && mfma && cd.P >= 2 && cd.P <= 8 && cd.n_hidden >= 2 && 3 * cd.P + cd.P * (cd.P - 1) / 2 <= 3 * L.WM && !o.sync_fn &&
+      c.dcov = (train && mfma && cd.n_hidden >= 2 && dcov_fits(cd.P, L.WM) && !o.sync_fn &&
                 (have_stats0 == false || stats0_cov) && !nis_env_int("NIS_NO_DERIVE1", 0) && !nis_env_int("NIS_NO_DCOV", 0)) ? 1 : 0;
       if (c.dcov && have_stats0) {
         c.derive1 = 1;                  // the producing launch (ingest with in-kernel draws) already wrote them: nparts[0] = its grid

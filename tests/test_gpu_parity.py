@@ -87,7 +87,10 @@ def test_cell_vs_reference_golden(case, g_cells):
                                              # matrix-core PWQuad heads with K == KM: the relative last-layer image (NIS_PACK_REL), 2K - 1 rows per
                                              # column -- column batches that start inside a row tile, one column, every K the image exists for
                                              ("pwquad", 7, 3, 4, [16, 16], 1100), ("pwquad", 9, 2, 8, [40, 40], 900),
-                                             ("pwquad", 5, 4, 16, [24], 1300), ("pwquad", 11, 2, 16, [64, 64], 650)])
+                                             ("pwquad", 5, 4, 16, [24], 1300), ("pwquad", 11, 2, 16, [64, 64], 650),
+                                             # width 16 with seven pass-through columns: 21 co-moments fit the BN record but not the 16 columns of
+                                             # the merge -- BN_1 must NOT be derived from them there (found by NIS_TEST_SWEEP_SEED=5: values 1 % off)
+                                             ("pwlin", 8, 7, 4, [3, 11], 477), ("pwquad", 11, 7, 16, [16, 2], 385), ("pwquad", 9, 6, 8, [16, 16], 500)])
 @pytest.mark.parametrize("train", [True, False])
 def test_cell_vs_oracle_seeded(kind, d, P, K, NN, N, train):
     from nf_amd.normalizing_flows.layers.coupling_cells import PWLin, PWQuad
@@ -2178,8 +2181,15 @@ def test_captured_training_step_equals_eager(shape, monkeypatch):
         np.testing.assert_allclose(sa[k], sb[k], rtol=1e-11, atol=1e-15, err_msg=k)
 
 
+# NIS_TEST_SWEEP_SEED=<int> shifts the seed of every random sweep below (other shapes, same tests); NIS_TEST_SWEEP_SCALE=<k> multiplies the
+# number of cases.  The default run is the committed, fixed set.
+_SWEEP_SEED = int(os.environ.get("NIS_TEST_SWEEP_SEED", "0"))
+_SWEEP_SCALE = max(1, int(os.environ.get("NIS_TEST_SWEEP_SCALE", "1")))
+
+
 def _random_cell_shapes(n, seed):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + _SWEEP_SEED)
+    n *= _SWEEP_SCALE
     out = []
     for i in range(n):
         kind = "pwquad" if rng.random() < 0.6 else "pwlin"
@@ -2244,13 +2254,24 @@ def test_random_cell_shapes_forward_and_adjoint(kind, d, P, K, NN, N):
         gx_h, gp_h = grads(False)
         cell.load_state_dict(sd)
         gx_t, gp_t = grads(True)
-        np.testing.assert_allclose(t2n(gx_h), t2n(gx_t), rtol=1e-6, atol=1e-9 * max(1.0, float(gx_t.abs().max())), err_msg=f"train={train}")
+        # A sample that lands in a bin of (nearly) vanishing width has derivative terms of 1e15 .. 1e25 that cancel to O(1): the two
+        # evaluation orders then differ by cond * eps.  Rows are independent samples, so the input gradient is compared per row against
+        # that row's own scale; such a cell's parameter gradients (sums over the rows) get the looser factor as a whole.
+        ght, gtt = t2n(gx_h), t2n(gx_t)
+        fac = 1e-7 if float(np.abs(gtt).max()) > 1e8 else 1e-9
+        rowscale = np.maximum(1.0, np.abs(gtt).max(axis=1, keepdims=True))
+        atol = 1e-7 * rowscale if fac == 1e-7 else 1e-9 * max(1.0, float(np.abs(gtt).max()))
+        bad = np.abs(ght - gtt) > 1e-6 * np.abs(gtt) + atol
+        assert not bad.any(), f"train={train}: {int(bad.sum())} input-gradient entries differ, max |diff| {float(np.abs(ght - gtt)[bad].max()):.3e}"
+        gpmax = max(1.0, max(float(b.abs().max()) for b in gp_t))
         for (name, _), a, b in zip(cell.named_parameters(), gp_h, gp_t):
-            np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-6, atol=1e-9 * max(1.0, float(b.abs().max())), err_msg=f"{name} train={train}")
+            np.testing.assert_allclose(t2n(a), t2n(b), rtol=1e-6, atol=fac * (gpmax if fac == 1e-7 else max(1.0, float(b.abs().max()))),
+                                       err_msg=f"{name} train={train}")
 
 
 def _random_rambo_shapes(n_cases, seed):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + _SWEEP_SEED)
+    n_cases *= _SWEEP_SCALE
     out = []
     for i in range(n_cases):
         n = int(rng.integers(2, 11))
@@ -2289,7 +2310,8 @@ def test_random_rambo_configurations_vs_oracle(init, final, E, cuts, pdf, tau, N
 
 
 def _random_models(n_cases, seed):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + _SWEEP_SEED)
+    n_cases *= _SWEEP_SCALE
     out = []
     for i in range(n_cases):
         which = rng.choice(["pwquad", "pwquad", "pwlin", "affine"])
@@ -2499,8 +2521,9 @@ def test_random_models_training_loop_fused_equals_piecewise(cfg, N, G, loss_mode
     rb, hb, gb = run(False)
     np.testing.assert_allclose(ha, hb, rtol=1e-8)
     np.testing.assert_allclose(ra, rb, rtol=1e-5)
-    for x, y in zip(ga, gb):
-        np.testing.assert_allclose(x, y, rtol=1e-6, atol=1e-9 * max(1e-30, float(np.abs(y).max())) + 1e-14)
+    gscale = max(float(np.abs(y).max()) for y in gb)         # (a Linear bias in front of a train-mode BatchNorm has gradient 0: what both
+    for x, y in zip(ga, gb):                                  # paths return there is rounding noise relative to the OTHER gradients)
+        np.testing.assert_allclose(x, y, rtol=1e-6, atol=1e-9 * max(1e-30, gscale) + 1e-14)
 
 
 @pytest.mark.parametrize("case", range(8))
