@@ -2238,19 +2238,33 @@ def test_random_cell_shapes_forward_and_adjoint(kind, d, P, K, NN, N):
     model = torch.nn.Sequential(cell)
     R = torch.randn(N, d + 1, dtype=torch.double, device=dev())
 
+    keep = None
+
     def grads(force_torch):
         for p in cell.parameters():
             p.grad = None
         xx = x.to(dev()).clone().requires_grad_(True)
         out = model_torch(model, xx) if force_torch else cell(xx)
+        out = torch.where(keep[:, None], out, torch.zeros_like(out))
         (out * R).sum().backward()
         return xx.grad.clone(), [p.grad.clone() for p in cell.parameters()]
 
     sd = {k: v.clone() for k, v in cell.state_dict().items()}
     for train in (True, False):                       # the reference's autograd differentiates a model in any mode
-        cell.load_state_dict(sd)
         cell.train(train)
         model.train(train)
+        # The stock-PyTorch re-evaluation runs on the GPU, where torch.cumsum is a parallel scan: its bin edges differ from the sequential
+        # sums of the reference on the CPU (= the oracle = the kernels, asserted above) in the last bits, and where widths vanish in the sum
+        # (many bins, wide random nets) a sample can sit on an edge and take ANOTHER bin there.  The adjoint is compared on the samples whose
+        # forward values agree, i.e. where both differentiate the same branch; the others are masked out of the loss on both sides.
+        with torch.no_grad():
+            cell.load_state_dict(sd)
+            o_h = cell(x.to(dev()))
+            cell.load_state_dict(sd)
+            o_t = model_torch(model, x.to(dev()))
+        keep = ((o_h - o_t).abs() <= 1e-8 * o_t.abs() + 1e-12).all(dim=1)
+        assert float(keep.double().mean()) > 0.9, f"train={train}: only {int(keep.sum())} of {N} samples agree in the forward pass"
+        cell.load_state_dict(sd)
         gx_h, gp_h = grads(False)
         cell.load_state_dict(sd)
         gx_t, gp_t = grads(True)
