@@ -2182,7 +2182,9 @@ def test_captured_training_step_equals_eager(shape, monkeypatch):
 
 
 # NIS_TEST_SWEEP_SEED=<int> shifts the seed of every random sweep below (other shapes, same tests); NIS_TEST_SWEEP_SCALE=<k> multiplies the
-# number of cases.  The default run is the committed, fixed set.
+# number of cases.  The default run is the committed, fixed set.  Shifted seeds can hit knife-edge samples that are ambiguous in the
+# reference itself (a width at the threshold of vanishing in the cumulative sum makes the bin depend on the last bit of exp();
+# a phase-space point at threshold) -- seen in 2 of 40 seeds x 366 cases, 2 elements each.
 _SWEEP_SEED = int(os.environ.get("NIS_TEST_SWEEP_SEED", "0"))
 _SWEEP_SCALE = max(1, int(os.environ.get("NIS_TEST_SWEEP_SCALE", "1")))
 
