@@ -154,9 +154,7 @@ int nis_integrate_steps(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_b
  * materialises the same numbers).  planes / keep_planes as for nis_integrate_steps.
  * rng_state (optional, device): {seed, next stream} as two uint64 -- when given it overrides seed / stream0, is read by the
  * drawing launch and advanced by n_batches in the set's last launch, so a launch set captured into a hipGraph draws fresh
- * numbers on every replay.
- * nis_integrate_resident: 1 when the calls run the persistent whole-step kernel of the DIAGNOSTICS build (libnis_hip_diag.so,
- * NIS_MEGA=1, flow_mega.hip); always 0 in the product library.  nis_diag_build: 1 in the diagnostics build. */
+ * numbers on every replay. */
 int nis_integrate_steps_rng(nis_flow* f, int32_t n_batches, int64_t N,
                             const double* const* params, double* const* running, long long* const* tracked,
                             int32_t bn_mode, int64_t pack_token, int32_t f_kind, const double* f_params_host,
@@ -174,9 +172,7 @@ int nis_integrate_steps_bins(nis_flow* f, const void* w, int32_t w_dtype, int64_
                              void* workspace, size_t workspace_bytes, void* stream);
 /* 1 when the built-in integrand of nis_integrate_steps is fused into the last cell's kernel for this model. */
 int nis_flow_fusable(const nis_flow* f);
-int nis_integrate_resident(const nis_flow* f, int32_t n_batches, int64_t N, int32_t bn_mode, int32_t f_kind);
 int nis_philox_rows(uint64_t seed, uint64_t stream0, int32_t n_batches, int64_t N, int32_t d, float* out /* (n_batches, N, d) */, void* stream);
-int nis_diag_build(void);
 
 /* Train-mode forward whose BatchNorm statistics are those of the batch that is SHARDED over `world` ranks (SURVEY.md 8(e)
  * option 1, "SyncBN-exact": every rank passes its N rows; results equal the reference's single-batch forward of the

@@ -27,7 +27,7 @@ LIB_PATH = os.environ.get("NIS_LIB") or os.path.join(os.path.dirname(os.path.abs
 
 EXPORTS = ["nis_cell_param_count", "nis_cell_running_count", "nis_flow_create", "nis_flow_destroy",
            "nis_flow_workspace_bytes", "nis_flow_forward", "nis_flow_forward_sync", "nis_integrate_steps", "nis_integrate_steps_rng",
-           "nis_integrate_resident", "nis_integrate_rng_mode", "nis_diag_build", "nis_philox_rows", "nis_integrate_steps_bins", "nis_flow_fusable", "nis_flow_backward_supported",
+           "nis_integrate_rng_mode", "nis_philox_rows", "nis_integrate_steps_bins", "nis_flow_fusable", "nis_flow_backward_supported",
            "nis_flow_bnsave_count", "nis_flow_forward_train", "nis_flow_forward_hist", "nis_flow_backward_eval", "nis_flow_backward_workspace_bytes", "nis_flow_backward", "nis_flow_backward_loss", "nis_loss_terms", "nis_loss_workspace_bytes",
            "nis_flow_forward_hist_batched", "nis_loss_workspace_bytes_batched", "nis_loss_terms_batched",
            "nis_flow_backward_workspace_bytes_batched", "nis_flow_backward_loss_batched", "nis_integrand_moments", "nis_integrand_eval",
@@ -89,15 +89,11 @@ def lib():
                                           C.POINTER(C.c_double), u64, u64, vp, vp, vp, i64, i32, vp, vp, sz, vp]
     L.nis_integrate_rng_mode.restype = i32
     L.nis_integrate_rng_mode.argtypes = [vp, i32, i64, i32, i32, i32]
-    L.nis_diag_build.restype = i32
-    L.nis_diag_build.argtypes = []
     L.nis_integrate_steps_bins.restype = i32
     L.nis_integrate_steps_bins.argtypes = [vp, vp, i32, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64, i32,
                                            C.POINTER(C.c_double), vp, i64, vp, vp, vp, sz, vp]
     L.nis_flow_fusable.restype = i32
     L.nis_flow_fusable.argtypes = [vp]
-    L.nis_integrate_resident.restype = i32
-    L.nis_integrate_resident.argtypes = [vp, i32, i64, i32, i32]
     L.nis_philox_rows.restype = i32
     L.nis_philox_rows.argtypes = [u64, u64, i32, i64, i32, vp, vp]
     L.nis_flow_backward_supported.restype = i32

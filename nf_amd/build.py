@@ -1,12 +1,9 @@
-"""Build libnis_hip.so (gfx950) in-tree with hipcc.  `python -m nf_amd.build [--force] [--diag]`.
+"""Build libnis_hip.so (gfx950) in-tree with hipcc.  `python -m nf_amd.build [--force]`.
 
 The per-conditioner-width translation units (forward: 5, wide adjoint: 3) compile in parallel; objects go to nf_amd/csrc/build/,
-the shared library to nf_amd/lib/libnis_hip.so (git-ignored, travels to the GPU box with the snapshot).
-
-`--diag` additionally builds nf_amd/lib/libnis_hip_diag.so: the same library with -DNIS_DIAG, i.e. plus the measured dead ends kept for
-A/B measurements only -- the persistent LDS-resident C2 kernel (flow_mega.hip, NIS_MEGA=1), the multi-chain launch sets
-(NIS_STREAMS=n) and the register-resident bijector of the matrix-core apply kernel (flow_mfma_reg.h, NIS_REGBIJ=1).  Select it
-with NIS_LIB=<path>; the product library contains none of them.
+the shared library to nf_amd/lib/libnis_hip.so (git-ignored, travels to the GPU box with the snapshot).  ONE library: the measured
+dead ends of rounds 2-3 (persistent LDS-resident step, multi-chain launch sets, register-resident bijector, producer / consumer
+waves) were deleted in round 4; their A/B numbers are in profiles/r03_*_ab.txt and DESIGN.md, their code in the git history.
 """
 import os
 import subprocess
@@ -21,12 +18,9 @@ LIB = os.path.join(LIBDIR, "libnis_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"] + \
-        os.environ.get("NIS_EXTRA_FLAGS", "").split()          # diagnostics only (e.g. -DNIS_MEGA_STAMPS), never for the shipped library
+        os.environ.get("NIS_EXTRA_FLAGS", "").split()          # A/B builds only (e.g. -DNIS_MF_REL=0), never for the shipped library
 
-LIB_DIAG = os.path.join(LIBDIR, "libnis_hip_diag.so")
 API_UNITS = [("api", "api.hip", []), ("api_pack", "api_pack.hip", []), ("api_ingest", "api_ingest.hip", []), ("api_moments", "api_moments.hip", [])]
-DIAG_UNITS = [("diag_api", "api.hip", ["-DNIS_DIAG"]), ("diag_api_pack", "api_pack.hip", ["-DNIS_DIAG"]), ("diag_flow_mega", "flow_mega.hip", ["-DNIS_DIAG"])] + \
-             [(f"diag_flow_wm{w}", "flow_wm.hip", [f"-DNIS_WM={w}", "-DNIS_DIAG"]) for w in (16, 32, 64)]
 UNITS = API_UNITS + [("rambo", "rambo.hip", []), ("flow_bwd", "flow_bwd.hip", [])] + \
         [(f"flow_wm{w}", "flow_wm.hip", [f"-DNIS_WM={w}"]) for w in (4, 8, 16, 32, 64)] + \
         [(f"flow_bwd_wm{w}", "flow_bwd_wm.hip", [f"-DNIS_WM={w}"]) for w in (16, 32, 64)]
@@ -73,7 +67,7 @@ def _link(lib, objs):
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
 
 
-def build(force=False, verbose=False, diag=False):
+def build(force=False, verbose=False):
     global _FORCE
     _FORCE = bool(force)
     os.makedirs(OBJ, exist_ok=True)
@@ -87,16 +81,9 @@ def build(force=False, verbose=False, diag=False):
                 if err.strip():
                     print(err, file=sys.stderr)
         _link(LIB, [o for o, _ in results])
-    diag = diag or os.path.exists(LIB_DIAG)          # once built, the diagnostics library is kept in step with the product library
-    if diag and (force or _stale(LIB_DIAG, deps + [LIB])):
-        with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
-            dres = list(ex.map(_compile, DIAG_UNITS))
-        swapped = {"api.o", "api_pack.o", "flow_wm16.o", "flow_wm32.o", "flow_wm64.o"}
-        objs = [os.path.join(OBJ, n + ".o") for n, _, _ in UNITS if n + ".o" not in swapped] + [o for o, _ in dres]
-        _link(LIB_DIAG, objs)
     return LIB
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv)
+    path = build(force="--force" in sys.argv, verbose=True)
     print(path)

@@ -2,9 +2,6 @@
 // iterations (flow_run), the entry points, the adjoint driver and the per-launch timing hooks.  The kernels it launches live in
 // flow_wm.hip (cells), api_pack.hip, api_ingest.hip, api_moments.hip, rambo.hip and flow_bwd*.hip (see api_internal.h).
 #include "api_internal.h"
-#ifdef NIS_DIAG
-#include "flow_mega.h"
-#endif
 
 static thread_local std::string g_err;
 int nis_fail_hip(hipError_t e, const char* what) {
@@ -175,33 +172,6 @@ static int sync_records(const RunOpts& o, const double* records, int nparts, int
   return NIS_OK;
 }
 
-#ifdef NIS_DIAG
-// Side streams of the multi-chain mode (flow_run; diagnostics build only: measured no gain): created once per device,
-// non-blocking; fork / join events without timing.
-struct SidePool {
-  std::vector<hipStream_t> stream;
-  std::vector<hipEvent_t> join, stag;
-  hipEvent_t fork = nullptr;
-};
-static SidePool* side_pool(int n) {
-  static SidePool pools[16];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  SidePool& p = pools[dev];
-  if (!p.fork && hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-  while ((int)p.stream.size() < n) {
-    hipStream_t st;
-    hipEvent_t ev, ev2;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&ev2, hipEventDisableTiming) != hipSuccess) return nullptr;
-    p.stream.push_back(st);
-    p.join.push_back(ev);
-    p.stag.push_back(ev2);
-  }
-  return &p;
-}
-#endif
 
 template <int WM>
 static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, long ld, long N, int bn_mode, int km, int* bins,
@@ -288,8 +258,8 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   if (G > 1 && (o.bins_out || o.w_has_jac || (o.xj_out && !o.hist))) return NIS_E_UNSUPPORTED;
   if (!workspace || workspace_bytes < nis_flow_workspace_bytes(f, G)) return NIS_E_WORKSPACE;
   std::vector<CellLayout> lay;
-  size_t off_fpart = 0, off_mega = 0;
-  nis_flow_layout(f, G, &lay, &off_fpart, &off_mega);
+  size_t off_fpart = 0;
+  nis_flow_layout(f, G, &lay, &off_fpart);
   int* status = (int*)workspace;
   double* body = (double*)((char*)workspace + WS_HEADER);
   const int d = f->d;
@@ -412,55 +382,6 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     return NIS_OK;
   };
 
-#ifdef NIS_DIAG
-  // ---- persistent whole-step kernel (flow_mega.hip: diagnostics build only, opt-in with NIS_MEGA=1): the README / C1 / C2 model with everything the
-  //      direct-row mode requires (float32 rows or in-kernel draws, train-mode BN, camel fused, nothing materialised),
-  //      batch resident in LDS.  24-32 B/sample of HBM traffic instead of 88, but slower than the launch-per-phase path
-  //      (one wave per SIMD and team issues fp64 at half rate; 6 hand-offs of ~9 us per batch).
-  {
-    int NT = 0, teams = 0;
-    const bool mega = direct && nis_mega_model(f) && nis_env_int("NIS_MEGA", 0) && G <= NIS_MEGA_MAX_G && nis_mega_geometry(&NT, &teams) &&
-                      ((N + NT - 1) / NT + 1) / 2 * 2 <= NIS_MEGA_CAP;
-    if (mega) {
-      MegaArgs a;
-      memset(&a, 0, sizeof(a));
-      for (int ci = 0; ci < 2; ++ci) {
-        const CellLayout& L = lay[ci];
-        a.cell[ci].wp = body + L.off_wp;
-        a.cell[ci].wlast = body + L.off_wlast;
-        a.cell[ci].bias = body + L.off_bias;
-        a.cell[ci].gb = body + L.off_gb;
-        a.cell[ci].gstat = body + L.off_gstat;
-      }
-      a.w = o.rng ? nullptr : (const float*)w;
-      a.w_out = o.rng ? o.w_out : nullptr;
-      a.N = (long)N;
-      a.G = G;
-      a.NT = NT;
-      a.teams = std::min(teams, G);
-      a.n_loc = (int)(((N + NT - 1) / NT + 1) / 2 * 2);
-      a.col0 = f->cells[0].in_col[0];
-      a.seed = o.seed;
-      a.stream0 = o.stream0;
-      a.rng_state = o.rng ? o.rng_state : nullptr;
-      a.status = status;
-      for (int k = 0; k < 3; ++k) a.fp[k] = o.f_params ? o.f_params[k] : 0.0;
-      a.fp[3] = 1.0 / (a.fp[2] * a.fp[2]);
-      a.fpart = body + off_fpart;
-      a.maxb = NIS_MAXB;
-      {
-        NisProfScope ps(NIS_K_APPLY, s);
-        HIP_OK(nis_mega_launch(a, body + off_mega, f->mega_ws != workspace, s));
-      }
-      f->mega_ws = workspace;
-      epi_add(0);
-      epi_add(1);
-      if (int rc2 = epi_flush(body + off_fpart, NT)) return rc2;
-      packed_done();
-      return NIS_OK;
-    }
-  }
-#endif
   if (!planes) return NIS_E_ARG;
   if (o.rng && (o.w_has_jac || o.hist || o.sync_fn)) return NIS_E_UNSUPPORTED;      // the draw belongs to integrate()'s loop body
   // In-kernel draws of the d = 2 direct-row chain: the record pass GENERATES the float32 rows (same Philox mapping as
@@ -669,41 +590,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     return NIS_OK;
   };
 
-#ifdef NIS_DIAG
-  // Independent batches on several streams: one chain's HBM-bound statistics passes run beside another's fp64-issue-bound
-  // apply kernels (C2 at G = 10: 33.3 -> 28.8 us per step).  The chains share nothing but read-only parameters (records,
-  // coefficients, planes and moment records are indexed by batch); they fork from and join the caller's stream through
-  // events, so the call stays capturable into a hipGraph, and the one epilogue launch behind the join applies the
-  // running-statistics updates of ALL batches in batch order.
-  int n_chains = 1;
-  if (G >= 2 && !o.sync_fn && !o.hist && train && f->n_cells <= NIS_EPI_CELLS) n_chains = std::min(G, std::max(1, nis_env_int("NIS_STREAMS", 1)));   // default 1: started together or staggered, the chains of ONE call gained nothing; free-running sets on separate streams do
-  SidePool* pool = n_chains > 1 ? side_pool(n_chains - 1) : nullptr;
-  if (n_chains > 1 && !pool) n_chains = 1;
-  if (n_chains == 1) {
-    if (int rc = chain(s, 0, G, G, true, nullptr)) return rc;
-  } else {
-    // Chains start STAGGERED: chain k + 1 waits until chain k reaches its first apply launch, so that the memory-bound
-    // head of one chain (record pass, statistics) runs beside the fp64-bound apply kernel of its predecessor; started
-    // together the chains would run the same kernel class in lockstep and overlap nothing.
-    const int Gg = (G + n_chains - 1) / n_chains;
-    static const bool stagger_on = nis_env_int("NIS_NO_STAGGER", 0) == 0;
-    HIP_OK(hipEventRecord(pool->fork, s));
-    int g0 = 0;
-    for (int k = 0; k < n_chains; ++k) {
-      const int Gy = G / n_chains + (k < G % n_chains ? 1 : 0);
-      hipStream_t cs = k == 0 ? s : pool->stream[k - 1];
-      if (k > 0) HIP_OK(hipStreamWaitEvent(cs, (stagger_on ? pool->stag[k - 1] : pool->fork), 0));
-      if (int rc = chain(cs, g0, Gy, Gg, k == 0, (stagger_on && k + 1 < n_chains) ? pool->stag[k] : nullptr)) return rc;
-      if (k > 0) {
-        HIP_OK(hipEventRecord(pool->join[k - 1], cs));
-        HIP_OK(hipStreamWaitEvent(s, pool->join[k - 1], 0));
-      }
-      g0 += Gy;
-    }
-  }
-#else
   if (int rc = chain(s, 0, G, G, true, nullptr)) return rc;
-#endif
   if (epi_fused) {
     if (int rc2 = epi_flush(body + off_fpart, epi_fparts)) return rc2;
   }
@@ -822,7 +709,7 @@ extern "C" int nis_integrate_steps_bins(nis_flow* f, const void* w, int32_t w_dt
   o.spec_bins = 1;
   std::vector<CellLayout> lay;
   nis_flow_layout(f, 1, &lay, nullptr);
-  if (!direct_rows_ok(f, lay, o, w_dtype, f->d, f->cells[0].P) || nis_env_int("NIS_NO_DIRECT_ROWS", 0) || nis_env_int("NIS_MEGA", 0)) return NIS_E_UNSUPPORTED;
+  if (!direct_rows_ok(f, lay, o, w_dtype, f->d, f->cells[0].P) || nis_env_int("NIS_NO_DIRECT_ROWS", 0)) return NIS_E_UNSUPPORTED;
   return flow_run(f, w, w_dtype, N, params, running, planes, ld, workspace, workspace_bytes, (hipStream_t)stream, o);
 }
 
@@ -852,29 +739,6 @@ extern "C" int nis_flow_fusable(const nis_flow* f) {
     default: break;
   }
   return ok ? 1 : 0;
-}
-
-extern "C" int nis_integrate_resident(const nis_flow* f, int32_t n_batches, int64_t N, int32_t bn_mode, int32_t f_kind) {
-#ifdef NIS_DIAG
-  int NT = 0, teams = 0;
-  return f && nis_mega_model(f) && bn_mode == NIS_BN_TRAIN && f_kind == NIS_F_CAMEL && n_batches >= 1 && n_batches <= NIS_MEGA_MAX_G &&
-                 nis_env_int("NIS_MEGA", 0) && !nis_env_int("NIS_NO_DIRECT_ROWS", 0) && !nis_env_int("NIS_NO_FOLD", 0) && !nis_env_int("NIS_NO_WX", 0) &&
-                 !nis_env_int("NIS_NO_DERIVE1", 0) && !getenv("NIS_NO_STATS_FOLD") && nis_mega_geometry(&NT, &teams) &&
-                 ((N + NT - 1) / NT + 1) / 2 * 2 <= NIS_MEGA_CAP
-             ? 1
-             : 0;
-#else
-  (void)f; (void)n_batches; (void)N; (void)bn_mode; (void)f_kind;
-  return 0;                              // the persistent whole-step kernel lives in the diagnostics build only
-#endif
-}
-
-extern "C" int nis_diag_build(void) {
-#ifdef NIS_DIAG
-  return 1;
-#else
-  return 0;
-#endif
 }
 
 // How nis_integrate_steps_rng would draw for this model / call: 2 = the d = 2 direct-row chain (float32 rows in a spare state

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_ingest2(const TIN* __restrict__ w, 
 }
 
 // In-kernel draws for the direct-row chain: the record pass GENERATES batch g's float32 rows (Philox4x32-10, the mapping of
-// nis_philox_rows / flow_mega.hip: sample n takes words 2 (n & 1), 2 (n & 1) + 1 of the call with counter n >> 1 on stream
+// nis_philox_rows: sample n takes words 2 (n & 1), 2 (n & 1) + 1 of the call with counter n >> 1 on stream
 // stream0 + g) instead of reading them, writes them where the cells will read them, and gathers BN_0's records as k_ingest2
 // does.  One thread = one Philox call = two consecutive samples = one 16-byte store.
 __device__ __forceinline__ void nis_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&r)[4]) {

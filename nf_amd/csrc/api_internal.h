@@ -47,12 +47,10 @@ struct nis_flow {
   int packed_G = 0;
   const void* packed_ws = nullptr;
   std::vector<const double*> packed_params, packed_running;
-  const void* mega_ws = nullptr;     // diagnostics build: workspace whose hand-off granules have been zeroed (flow_mega.hip)
 };
 
 static const size_t WS_HEADER = 256;   // bytes: status word + padding
-bool nis_mega_model(const nis_flow* f);
-size_t nis_flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay, size_t* off_fpart, size_t* off_mega = nullptr);
+size_t nis_flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay, size_t* off_fpart);
 
 int nis_device_cus();
 int nis_grid_for(int blocks_per_cu, int G, int64_t N, int tpb);

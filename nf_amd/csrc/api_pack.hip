@@ -1,9 +1,5 @@
 // Model handle, workspace layout and parameter packing of libnis_hip.so (see api_internal.h for the split).
 #include "api_internal.h"
-#ifdef NIS_DIAG
-#include "flow_mfma_reg.h"
-#include "flow_mega.h"
-#endif
 
 extern "C" size_t nis_cell_param_count(const nis_cell_desc* c) {
   size_t n = 0;
@@ -23,20 +19,7 @@ extern "C" size_t nis_cell_running_count(const nis_cell_desc* c) {
 
 // Workspace body for G batched iterations: per cell the zero-padded parameter image (shared by all batches),
 // then per-batch BN coefficients, partial records and batch statistics; finally the integrand's moment records.
-// The persistent whole-step kernel (flow_mega.hip) covers the README / C1 / C2 model: d = 2, two PWQuad cells with 4 bins,
-// one pass-through column, three hidden layers at most 3 wide.
-bool nis_mega_model(const nis_flow* f) {
-  if (f->d != 2 || f->n_cells != 2) return false;
-  for (int ci = 0; ci < 2; ++ci) {
-    const nis_cell_desc& c = f->cells[ci];
-    if (c.kind != NIS_PWQUAD || c.P != 1 || c.K != 4 || c.n_hidden != 3) return false;
-    for (int l = 0; l < 3; ++l)
-      if (c.width[l] > 3) return false;
-  }
-  return true;
-}
-
-size_t nis_flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay, size_t* off_fpart, size_t* off_mega) {
+size_t nis_flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay, size_t* off_fpart) {
   size_t off = 0;
   for (int i = 0; i < f->n_cells; ++i) {
     const nis_cell_desc& c = f->cells[i];
@@ -67,10 +50,6 @@ size_t nis_flow_layout(const nis_flow* f, int G, std::vector<CellLayout>* lay, s
   if (off_fpart) *off_fpart = off;
   off += (size_t)G * NIS_MAXB * 4;
   off = (off + 31) / 32 * 32;                                   // 256-byte aligned: the scratch starts with its counter block
-  if (off_mega) *off_mega = off;
-#ifdef NIS_DIAG
-  if (nis_mega_model(f)) off += (nis_mega_scratch_bytes() + 7) / 8;
-#endif
   return off;
 }
 
@@ -190,12 +169,7 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double*
 // affT > 0 (NIS_AFFINE with T transformed columns): the last layer's rows [scale | shift][T] are interleaved to
 // [t][scale, shift], so that a column's outputs are contiguous like those of the piecewise cells.
 // regmode == NIS_PACK_REL: the relative image of a PWQuad last layer (nis_common.h, nis_rel_row).
-// other regmode != 0 (diagnostics build, flow_mfma_reg.h): the last layer's rows are permuted so that a lane's four accumulator registers
-// hold four consecutive bins of one column (mf_reg_row); T, K: transformed columns and bins of the cell.
-#ifndef NIS_DIAG
-__host__ __device__ inline int mf_reg_row(int, int, int, int tile, int rho) { return 16 * tile + rho; }
-__host__ __device__ inline int mf_reg_row_sub(int, int, int, int, int) { return -1; }
-#endif
+// T, K: transformed columns and bins of the cell.
 __global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int RT, const double* __restrict__ wp,
                                                        const double* __restrict__ wlast, const double* __restrict__ bias,
                                                        double* __restrict__ wm_all, double* __restrict__ wm_last,
@@ -219,7 +193,6 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int
     int jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;                // packed row j <- blob row jo
     int js = -1;
     if (regmode == NIS_PACK_REL) jo = nis_rel_row(T, K, j, &js);
-    else if (regmode) jo = mf_reg_row(regmode, T, K, jt, lane & 15), js = mf_reg_row_sub(regmode, T, K, jt, lane & 15);
     double v = (regmode ? jo >= 0 && jo < R : j < R) ? wlast[(size_t)jo * WM + k] : 0.0;
     if (js >= 0) v -= wlast[(size_t)js * WM + k];
     wm_last[e] = v;
@@ -229,7 +202,6 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int
     int jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;
     int js = -1;
     if (regmode == NIS_PACK_REL) jo = nis_rel_row(T, K, j, &js);
-    else if (regmode) jo = mf_reg_row(regmode, T, K, j >> 4, j & 15), js = mf_reg_row_sub(regmode, T, K, j >> 4, j & 15);
     double v = (regmode ? jo >= 0 && jo < R : e < (size_t)R) ? bias[jo] : 0.0;
     if (js >= 0) v -= bias[js];
     bias_pad[e] = v;

@@ -1382,23 +1382,13 @@ hipError_t launch_apply_mfma(const CellK& c, const MfmaW& w, double* planes, lon
                              int grid, hipStream_t s);
 // true when launch_apply_mfma has a fused-integrand instantiation for this cell (PWLin, AffineCoupling, PWQuad with K == KM)
 static inline bool nis_mfma_fusable(int kind, int km) { return kind != NIS_PWQUAD || km < 0; }
-// Row order of the last Linear's matrix-core image: 0 = reference order (per-wave LDS image, k_cell_apply_mfma).  DIAGNOSTICS build
-// only (flow_mfma_reg.h, opt-in with NIS_REGBIJ=1): 1 = PWQuad with 16 bins, 2 = PWLin with 16 m bins -- the bijector on the
-// accumulator registers of four cooperating lanes, a measured dead end (12.5 / 3.03 / 7.90 ms per C3 / C4 / C5
-// iteration against 12.2 / 2.64 / 6.67 with the LDS image).  One function decides for the packer and the launcher.
+// Row order of the last Linear's matrix-core image: 0 = reference order, NIS_PACK_REL = the relative image (nis_common.h).
+// One function decides for the packer and the launcher.
 static inline int nis_mf_regmode(int kind, int K, int T, int wm) {
-#ifdef NIS_DIAG
-  const char* e = getenv("NIS_REGBIJ");
-  if (e && atoi(e) != 0 && wm >= 16) {
-    if (kind == NIS_PWQUAD && K == 16 && T >= 1 && T <= 16) return 1;
-    if (kind == NIS_PWLIN && K >= 16 && K % 16 == 0) return 2;
-  }
-#endif
   // PWQuad with K == KM on the matrix cores: the relative image (nis_common.h; -DNIS_MF_REL=0 builds the reference rows for A/B runs)
   if (NIS_MF_REL && wm >= 16 && kind == NIS_PWQUAD && (K == 4 || K == 8 || K == 16 || K == 32)) return NIS_PACK_REL;
   return 0;
 }
-static inline bool nis_mf_regbij(int regmode) { return regmode != 0 && regmode != NIS_PACK_REL; }
 #define NIS_DECL_WM(W)                                                                                                      \
   template <>                                                                                                               \
   int stats_blocks_per_cu<W>(int wx, bool folded);                                                                                          \

@@ -303,14 +303,7 @@ hipError_t launch_apply<NIS_WM>(const CellK& c, double* planes, long ld, long N,
 // ---------------------------------------------------------------------------------------------------------------
 // matrix-core (MFMA f64) variants for wide conditioners
 #if NIS_WM >= 16
-#ifdef NIS_DIAG
-#include "flow_mfma_reg.h"          // register-resident bijector: diagnostics build only (measured slower)
-#else
 #include "flow_mfma.h"
-#endif
-#ifdef NIS_DIAG
-#include "flow_mfma_pc.h"           // producer / consumer wave roles: diagnostics build only (measured slower)
-#endif
 
 // the cell as the apply kernel sees it: with the relative image (NIS_PACK_REL) a column has 2K rows (2K - 1 computed, one zero row)
 static CellK mf_view(const CellK& c_in) {
@@ -341,50 +334,15 @@ static int mf_pick_ncb(const CellK& c) {
 }
 static size_t mf_ring_bytes(const CellK& c) { return mf_ring_bytes_n(c, mf_pick_ncb(c)); }
 
-#ifdef NIS_DIAG
-// producer / consumer apply kernel (flow_mfma_pc.h, opt-in with NIS_MF_PC=1): two images per pair, ONE 512-thread workgroup per CU
-static size_t mfpc_ring_bytes_n(const CellK& c, int ncb) {
-  const size_t ring = (size_t)2 * NIS_MFPC_PAIRS * mf_cb_tiles(c.T, c.out, c.R, ncb) * 256 * sizeof(double);
-  return std::max<size_t>(ring, 3 * NIS_MFPC_TPB * sizeof(double));
-}
-static int mfpc_pick_ncb(const CellK& c) {           // 0: no batch size fits
-  static const int forced = getenv("NIS_MF_NCB") ? atoi(getenv("NIS_MF_NCB")) : 0;
-  for (int n = NIS_MF_NCB; n >= 1; n >>= 1) {
-    if (forced && n != forced) continue;
-    if (mfpc_ring_bytes_n(c, n) + MF_STATIC_LDS + 1024 <= 160 * 1024) return n;
-  }
-  return 0;
-}
-static bool mf_use_pc(const CellK& c) {
-  const char* e = getenv("NIS_MF_PC");
-  // PWQuad with more than 16 bins keeps the one-wave-per-SIMD kernel (its bin arrays need > 256 registers); cells packed as the relative
-  // image (regmode NIS_PACK_REL: PWQuad with K == KM) keep the product kernel too -- build with -DNIS_MF_REL=0 to A/B this variant on them
-  return e && atoi(e) != 0 && !c.regmode && (c.kind != NIS_PWQUAD || c.K <= 16) && mfpc_pick_ncb(c) > 0;
-}
-#else
-static bool mf_use_pc(const CellK&) { return false; }
-#endif
-
 template <>
 bool mfma_supported<NIS_WM>(const CellK& c_in) {
   const CellK c = mf_view(c_in);
-  if (mf_use_pc(c)) return true;
-#ifdef NIS_DIAG
-  if (nis_mf_regbij(c.regmode)) return true;       // register-resident bijector: no LDS image
-#endif
   return mf_ring_bytes(c) + 24 * 1024 <= 160 * 1024 && (c.kind == NIS_PWLIN || c.K <= 32);
 }
 
 template <>
 int mfma_blocks_per_cu<NIS_WM>(const CellK& c_in) {
   const CellK c = mf_view(c_in);
-  if (mf_use_pc(c)) return 1;                      // one 512-thread workgroup per CU: a producer and a consumer wave per SIMD
-#ifdef NIS_DIAG
-  if (nis_mf_regbij(c.regmode)) {                             // registers decide: one 256-thread workgroup = one wave per SIMD
-    static const int bpc = getenv("NIS_MFR_BPC") ? atoi(getenv("NIS_MFR_BPC")) : NIS_MFR_WAVES;
-    return bpc;
-  }
-#endif
   const size_t lds = mf_ring_bytes(c) + MF_STATIC_LDS;
   int n = (int)(160 * 1024 / lds);
   const int waves = (c.kind == NIS_PWLIN && NIS_MF_WAVES_LIN) ? NIS_MF_WAVES_LIN : NIS_MF_WAVES;
@@ -414,59 +372,6 @@ hipError_t launch_apply_mfma<NIS_WM>(const CellK& c_in, const MfmaW& w, double* 
                                      const FuseF& fz, int grid, hipStream_t s) {
   CellK c = mf_view(c_in);
   const bool rel = c.regmode == NIS_PACK_REL;
-#ifdef NIS_DIAG
-  if (nis_mf_regbij(c.regmode)) {        // PWQuad K = 16 / PWLin K = 16 m: bijector on the accumulator registers (flow_mfma_reg.h)
-    const bool fuse = fz.kind >= 0;
-    if (fuse && (bins || fz.fres)) return hipErrorInvalidValue;
-#define NIS_APPLY_MFR(KIND, FU)                                                                                               \
-  hipLaunchKernelGGL((k_cell_apply_mfr<KIND, NIS_WM, FU>), dim3(grid, c.Gy), dim3(NIS_MF_TPB), 0, s, c, planes, ld, N, bn_train, bins, \
-                     w.wm_all, w.wm_last, w.bias_pad, fz)
-    if (c.regmode == MF_REG_PWQUAD16) {
-      if (fuse) NIS_APPLY_MFR(NIS_PWQUAD, true);
-      else NIS_APPLY_MFR(NIS_PWQUAD, false);
-    } else {
-      if (fuse) NIS_APPLY_MFR(NIS_PWLIN, true);
-      else NIS_APPLY_MFR(NIS_PWLIN, false);
-    }
-#undef NIS_APPLY_MFR
-    return hipGetLastError();
-  }
-#endif
-#ifdef NIS_DIAG
-  if (mf_use_pc(c)) {                    // wave-specialised producer / consumer kernel (flow_mfma_pc.h)
-    c.mf_ncb = mfpc_pick_ncb(c);
-    const size_t ring = mfpc_ring_bytes_n(c, c.mf_ncb);
-    const bool fuse = fz.kind >= 0;
-    if (fuse && (!nis_mfma_fusable(c.kind, km) || bins || fz.fres)) return hipErrorInvalidValue;
-#define NIS_APPLY_PC(KIND, KMV, EX, FU)                                                                                            \
-  hipLaunchKernelGGL((k_cell_apply_mfpc<KIND, NIS_WM, KMV, EX, FU>), dim3(grid, c.Gy), dim3(NIS_MFPC_TPB), ring, s, c, planes, ld, N, \
-                     bn_train, bins, w.wm_all, w.wm_last, w.bias_pad, fz)
-#define NIS_APPLY_PCQ(KMV)                                  \
-  do {                                                      \
-    if (fuse) NIS_APPLY_PC(NIS_PWQUAD, KMV, true, true);    \
-    else if (km < 0) NIS_APPLY_PC(NIS_PWQUAD, KMV, true, false); \
-    else NIS_APPLY_PC(NIS_PWQUAD, KMV, false, false);       \
-  } while (0)
-    if (c.kind == NIS_PWLIN) {
-      if (fuse) NIS_APPLY_PC(NIS_PWLIN, 4, true, true);
-      else NIS_APPLY_PC(NIS_PWLIN, 4, false, false);
-    } else if (c.kind == NIS_AFFINE) {
-      if (fuse) NIS_APPLY_PC(NIS_AFFINE, 4, true, true);
-      else NIS_APPLY_PC(NIS_AFFINE, 4, false, false);
-    } else {
-      switch (km < 0 ? -km : km) {
-        case 4: NIS_APPLY_PCQ(4); break;
-        case 8: NIS_APPLY_PCQ(8); break;
-        case 16: NIS_APPLY_PCQ(16); break;
-        case 32: NIS_APPLY_PCQ(32); break;
-        default: return hipErrorInvalidValue;
-      }
-    }
-#undef NIS_APPLY_PCQ
-#undef NIS_APPLY_PC
-    return hipGetLastError();
-  }
-#endif
   c.mf_ncb = mf_pick_ncb(c);
   if (rel != (NIS_MF_REL != 0 && c.kind == NIS_PWQUAD && km < 0)) return hipErrorInvalidValue;      // packer and launcher disagree
   if (fz.kind >= 0) {                      // last cell of an integrate step: integrand * J + moment records fused (FUSE instantiations)

@@ -207,7 +207,7 @@ __host__ __device__ inline int nis_rel_row(int T, int K, int j, int* js) {
 struct CellK {
   int kind, d, P, T, K, L, out, R;       // out = conditioner outputs per transformed column, R = T*out
   int mf_ncb;                            // matrix-core apply kernel: transformed columns per bijector batch (4, 2 or 1; set at launch)
-  int regmode;                           // row order of the last Linear's matrix-core image: 0 reference order, NIS_PACK_REL, or (diagnostics build) MF_REG_* of flow_mfma_reg.h
+  int regmode;                           // row order of the last Linear's matrix-core image: 0 reference order or NIS_PACK_REL
   int width[NIS_MAX_HIDDEN];
   int in_plane[NIS_MAX_DIM];             // local column j -> state plane
   int jplane;                            // plane of the running Jacobian

@@ -253,10 +253,14 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
   // (2 -> 10 with cuts: 1-4 % of the weights differed from run to run).  tests/test_host_logic.py checks the built object: no spills
   // in any instantiation that takes this path.
   constexpr bool PIPE_OK = NF <= 6;
-  const bool vec_rows = PIPE_OK && !col_major && (NIN % 2 == 0) && k.r_ld == NIN && k.ncol == NIN && ((unsigned long long)r & 15ull) == 0;
+  // ... and for calls that return the momenta ONLY: the hand-written wait below counts the momenta stores of a whole tile, so every path
+  // through a pipelined tile must issue them (tests/isa_vmem_check.py walks the built code object with the hardware's VM_CNT rule; a
+  // weights-only call -- one store per tile -- would need its own loop copy and has no measured user: the fused flow -> weight tail is
+  // column-major and takes the compiler-tracked loads anyway).
+  const bool vec_rows = PIPE_OK && momenta != nullptr && !col_major && (NIN % 2 == 0) && k.r_ld == NIN && k.ncol == NIN && ((unsigned long long)r & 15ull) == 0;
   // vec_rows: SOFTWARE-PIPELINED inputs.  The 16-byte loads of the NEXT tile are issued by inline asm (rb_issue16) into registers the
   // compiler regards as ready, and the one wait that guards them is written by hand at the top of the next iteration:
-  // s_waitcnt vmcnt(<number of stores a whole tile issues after its loads>).  vmcnt counts loads and stores in issue order on
+  // s_waitcnt vmcnt(<number of momenta stores a whole tile issues after its loads>).  vmcnt counts loads and stores in issue order on
   // gfx9, so that wait lets the loads land without waiting for the tile's own stores; the compiler's bookkeeping cannot express it
   // (at the loop header it merges the pre-loop state, no store behind the loads, into vmcnt(0): every wave then sat out the full
   // HBM latency of its stores once per tile).  Whole tiles only (fixed store count); a ragged last tile waits for vmcnt(0).
@@ -290,9 +294,11 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
     const bool live = FULL ? true : tid < ns;
     double rv[NPS + 2];
     bool nan_in = false;
+    const bool has_mom = VEC || momenta != nullptr;     // the pipelined path exists for calls with momenta only (vec_rows)
     if (VEC) {
-      if (FULL && momenta) rb_wait_loads<LM / 2 + 1>(rawn);      // the previous whole tile's stores stay in flight
-      else if (FULL) rb_wait_loads<1>(rawn);                      // weights only: one store per tile
+      // the previous whole tile's LM / 2 momenta stores stay in flight (its weight store, issued last, may or may not exist: not counted,
+      // which at worst waits for the OLDEST momenta store as well)
+      if (FULL) rb_wait_loads<LM / 2>(rawn);
       else rb_wait_loads<0>(rawn);
 #pragma unroll
       for (int c = 0; c < NPS + 2; ++c) {
@@ -430,8 +436,8 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
         p.z += f * nz;
         rb_set_square(p, m2);                                                         // the boosted energy is re-derived from the mass shell
       }
-      if (STREAM) {
-        if (momenta) put_leg(2 + c, p);
+      if constexpr (STREAM) {
+        if (has_mom) put_leg(2 + c, p);
       } else {
         mom[2 + c] = p;
       }
@@ -441,8 +447,8 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
       Q.z -= p.z;
       rb_set_square(Q, M[c + 1] * M[c + 1]);
     }
-    if (STREAM) {
-      if (momenta) put_leg(NF + 1, Q);
+    if constexpr (STREAM) {
+      if (has_mom) put_leg(NF + 1, Q);
     } else {
       mom[NF + 1] = Q;
     }
@@ -461,12 +467,12 @@ void k_rambo(RamboK k, const double* __restrict__ r, long N, double* __restrict_
       in0 = {E1 / 2.0, 0., 0., Z / 2.0};
       in1 = {E2 / 2.0, 0., 0., -(Z / 2.0)};
     }
-    if (!STREAM) {
+    if constexpr (!STREAM) {
       mom[0] = in0;
       mom[1] = in1;
     }
-    if (momenta) {                                   // COM-frame copy is what the reference returns (:282,308)
-      if (STREAM) {
+    if (has_mom) {                                   // COM-frame copy is what the reference returns (:282,308)
+      if constexpr (STREAM) {
         put_leg(0, in0);
         put_leg(1, in1);
       } else {

@@ -463,11 +463,6 @@ class FlowEngine:
         _lib.check(rc, "nis_flow_backward")
         return gflat, gx
 
-    def resident(self, G, N, train, f_kind):
-        """True when `integrate_steps` / `integrate_steps_rng` run the persistent whole-step kernel (flow_mega.hip) for G
-        batches of N float32 rows: the batch then lives in LDS and no plane buffer is needed."""
-        return bool(self.L.nis_integrate_resident(self.handle, G, N, _lib.NIS_BN_TRAIN if train else _lib.NIS_BN_EVAL, f_kind))
-
     def integrate_steps(self, w, train, f_kind, f_params, out4, planes=None, token=None, want_fres=False):
         """G iterations of integrate()'s loop body in ONE library call.  w: (G, N, d) (or (N, d) for G = 1),
         out4: (G, 4) float64 device tensor/view receiving {count, mean, M2, max} per iteration.  The iterations
@@ -485,7 +480,7 @@ class FlowEngine:
         if token is None:
             token = self.pack_token()
         keep = planes is not None
-        if planes is None and not (w2.dtype == torch.float32 and not want_fres and self.resident(G, N, train, f_kind)):
+        if planes is None:
             planes = self._planes_scratch(G, N, dev)
         fres = torch.empty((G, N), dtype=torch.double, device=dev) if want_fres else None
         fp = (C.c_double * 4)(*(list(f_params) + [0.0] * 4)[:4])
@@ -552,7 +547,7 @@ class FlowEngine:
                 raise _lib.NisError("integrate_steps_rng: the workspace passed in is too small for this set size")
         if token is None:
             token = self.pack_token()
-        if planes is None and not self.resident(G, N, train, f_kind):
+        if planes is None:
             planes = self._planes_scratch(G, N, dev)
         fp = (C.c_double * 4)(*(list(f_params) + [0.0] * 4)[:4])
         with _lib.on_device(dev):
@@ -606,11 +601,6 @@ class FlowEngine:
                 cache.clear()
             plan = cache[key] = TrainPlan(self, G, N, dev, f, maxf, preburn, est)
         return plan
-
-    def resident_status(self, dev):
-        """Raise if a hand-off of the persistent kernel timed out (status bit 1; synchronises)."""
-        if self._ws is not None and int(self._ws[:4].view(torch.int32)[0].item()) & 2:
-            raise _lib.NisError("k_flow_mega: a team hand-off timed out (workgroups not co-resident?); results are invalid")
 
     integrate_step = integrate_steps
 

@@ -1523,37 +1523,6 @@ def test_graph_replay_of_a_launch_set_equals_eager_launches():
     np.testing.assert_allclose(fed, ref, rtol=1e-12)
 
 
-@pytest.mark.parametrize("variant", ["chains2", "chains3", "resident", "regbij", "pcwaves"])
-def test_diagnostics_build_variants_agree_with_the_plain_path(variant):
-    """Several chains on side streams, the persistent LDS-resident kernel and the register-resident bijector of the matrix-core
-    apply kernel are measured dead ends that live in the DIAGNOSTICS library only (libnis_hip_diag.so,
-    `python -m nf_amd.build --diag`): there they must still give the records of the plain path (1e-12: the record partition
-    differs; regbij: identical bins, values to rounding) and the same BatchNorm running statistics."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    diag = os.path.join(root, "nf_amd", "lib", "libnis_hip_diag.so")
-    if not os.path.exists(diag):
-        pytest.skip("diagnostics library not built (python -m nf_amd.build --diag)")
-    env = dict(os.environ, NIS_LIB=diag)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "diag_variants_check.py"), variant], capture_output=True, text=True,
-                       env=env, timeout=600)
-    assert r.returncode == 0 and "OK " + variant in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-
-
-def test_product_library_has_no_dead_end_kernels():
-    """The product library carries neither the persistent kernel nor the multi-chain mode: the switches are inert there."""
-    from nf_amd import _lib
-    L = _lib.lib()
-    if "diag" in os.path.basename(_lib.LIB_PATH):
-        pytest.skip("running against the diagnostics library")
-    assert L.nis_diag_build() == 0
-    from nf_amd.normalizing_flows.manager import PWQuadManager
-    NF = PWQuadManager(n_flow=2)
-    NF.create_model(2, 4, [3] * 3)
-    assert not NF.best_model.engine().resident(20, 1_000_000, True, _lib.NIS_F_CAMEL)
-
-
 @pytest.mark.parametrize("n_cells,N", [(3, 20002), (4, 50_000), (3, 20001)])
 def test_in_kernel_draws_longer_d2_chains_match_the_fed_path(n_cells, N):
     """Chains of 3 and 4 cells with in-kernel draws: an INNER cell overwrites the state plane that also holds the float32 draws, so

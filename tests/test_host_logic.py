@@ -3,6 +3,7 @@ declares, the drop-in classes build the reference's topology / state_dict layout
 into the right plane maps, and the product path refuses to run without a GPU (no silent fallback)."""
 import ctypes
 import os
+import sys
 import re
 
 import numpy as np
@@ -200,18 +201,23 @@ def test_reference_checkpoints_load_and_training_state_round_trips(tmp_path, g_m
         type(NF)(n_flow=2).load_checkpoint(str(tmp_path / "torch"))
 
 
-def test_pipelined_rambo_instantiations_do_not_spill():
-    """k_rambo's hand-pipelined row loads (inline-asm issue, hand-written s_waitcnt) are sound only while the compiler never spills the
-    registers they land in: the path is compiled for maps of at most six final-state legs (rambo.hip: PIPE_OK), and none of those
-    instantiations may report a spilled register in the built object's metadata."""
-    import re
-    import shutil
-    import subprocess
-    import tempfile
+def _rambo_object():
     obj = os.path.join(ROOT, "nf_amd", "csrc", "build", "rambo.o")
     llvm = "/opt/rocm/lib/llvm/bin"
     if not os.path.exists(obj) or not os.path.exists(os.path.join(llvm, "llvm-readelf")):
         pytest.skip("no built rambo.o / llvm tools here")
+    return obj, llvm
+
+
+def test_pipelined_rambo_instantiations_do_not_spill():
+    """k_rambo's hand-pipelined row loads (inline-asm issue, hand-written s_waitcnt) are sound only while the compiler never spills the
+    registers they land in: the path is compiled for maps of at most six final-state legs (rambo.hip: PIPE_OK), and none of those
+    instantiations may report a spilled vector register or any scratch in the built object's metadata."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    obj, llvm = _rambo_object()
     td = tempfile.mkdtemp()
     try:
         subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", f".hip_fatbin={td}/fat.bin", obj], check=True)
@@ -224,13 +230,69 @@ def test_pipelined_rambo_instantiations_do_not_spill():
     for blk in notes.split(".agpr_count")[1:]:
         name = re.search(r"\.name:\s+(\S+)", blk)
         spill = re.search(r"\.vgpr_spill_count:\s+(\d+)", blk)
-        if not name or not spill:
+        sspill = re.search(r"\.sgpr_spill_count:\s+(\d+)", blk)
+        scratch = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+        if not name or not spill or not sspill or not scratch:
             continue
         m = re.match(r"_Z7k_ramboILi(\d+)ELi(\d+)E", name.group(1))
         if m and int(m.group(1)) <= 6:
             seen += 1
-            assert int(spill.group(1)) == 0, f"k_rambo<{m.group(1)}, {m.group(2)}> spills {spill.group(1)} registers"
+            what = f"k_rambo<{m.group(1)}, {m.group(2)}>"
+            assert int(spill.group(1)) == 0, f"{what} spills {spill.group(1)} vector registers"
+            # (scalar spills -- up to 95 in the PDF / cut modes -- go to lanes of VGPRs the compiler reserves for them, never to memory here;
+            # whether ANY instruction, v_writelane included, touches a row-image register in flight is what the ISA walk below checks)
+            assert int(scratch.group(1)) == 0, f"{what} uses {scratch.group(1)} bytes of scratch"
     assert seen >= 20, seen          # n = 2 .. 6, four modes each
+
+
+def test_pipelined_rambo_loads_are_never_touched_in_flight():
+    """The check the spill count cannot give: walk the built gfx950 code of every k_rambo instantiation with the
+    hardware's VM_CNT rule (tests/isa_vmem_check.py) -- a register with an outstanding vector-memory load must not be named by any
+    instruction until an `s_waitcnt vmcnt(n)` with enough younger operations behind the load has passed, on EVERY path (loop back-edge
+    included).  For the compiler's own loads that holds by construction; for the inline-asm `global_load_dwordx4` of the pipelined
+    path it proves that the hand-written wait is sufficient and that no copy / re-allocation touches the row image between issue and
+    wait.  The checker itself is tested: weakening the hand-written wait by one must produce violations."""
+    import re
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import isa_vmem_check as chk
+    obj, _ = _rambo_object()
+    td = tempfile.mkdtemp()
+    try:
+        text = chk.disassemble(obj, td)
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    fns = chk.functions(text)
+    seen = pipelined = 0
+    for name, (_, insts) in fns.items():
+        m = re.match(r"_Z7k_ramboILi(\d+)ELi(\d+)E", name)
+        if not m:
+            continue
+        nf, mode = int(m.group(1)), int(m.group(2))
+        if any(mn.startswith("s_setpc") for _, mn, _, _ in insts):        # (2 -> 10 with cuts calls out of line: no pipelined loads there)
+            assert nf > 6, name
+            continue
+        viol, stats = chk.check_function(insts, name)
+        assert not viol, f"k_rambo<{nf}, {mode}>: " + "; ".join(f"{a:#x} {t} touches {r}" for a, t, r in viol[:5])
+        assert stats["loads"] > 0 and stats["waits"] > 0
+        seen += 1
+        if nf <= 6 and nf % 2 == 0:                                        # even row length: the 16-byte pipelined loads exist
+            lm_half = 2 * (nf + 2)
+            hand = [i for i, (_, mn, ops, _) in enumerate(insts) if mn == "s_waitcnt" and ops.strip() == f"vmcnt({lm_half})"]
+            assert hand, f"k_rambo<{nf}, {mode}>: the hand-written s_waitcnt vmcnt({lm_half}) is not in the code"
+            assert sum(1 for _, mn, _, _ in insts if mn == "global_load_dwordx4") >= 2 * (3 * nf - 4 + (2 if mode >= 1 else 0)) // 2
+            pipelined += 1
+            # self-test of the checker on the plain map (in the PDF / cut modes the compiler's own waits for its table loads cover the row
+            # image as well): a hand-written wait that tolerates more outstanding operations than the tile has stores must be flagged
+            if mode == 0:
+                bad = list(insts)
+                for i in hand:
+                    a, mn, _, t = bad[i]
+                    bad[i] = (a, mn, f"vmcnt({lm_half + 2})", t)
+                v2, _ = chk.check_function(bad, name)
+                assert v2, f"k_rambo<{nf}, {mode}>: weakened wait not detected"
+    assert seen >= 30 and pipelined >= 12, (seen, pipelined)
 
 
 def test_relative_image_row_map_covers_every_row_once(tmp_path):

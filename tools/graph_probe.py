@@ -10,7 +10,6 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["NIS_STREAMS"] = os.environ.get("NIS_STREAMS", "1")
 from nf_amd import integrands                                    # noqa: E402
 from nf_amd.normalizing_flows.manager import PWQuadManager       # noqa: E402
 
