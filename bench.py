@@ -18,7 +18,7 @@ inside the timed region.  Rank 0 prints one JSON line.
 
 Extra objects on the line: `roofline` (dominant kernel of the step: fp64 VALU issue, which is what binds it; HIP events on
 the launch stream + the committed PMC instruction counts), `roofline_hbm` (the same kernel and the whole step against HBM),
-`cpu_baseline` (the PyTorch-CPU restatement on all host cores + the NumPy oracle on one), `rambo` (metric part ii),
+`cpu_baseline` (the PyTorch-CPU restatements of the flow and of the 2->4 map on all host cores + the NumPy oracles on one), `rambo` (metric part ii),
 `configs` (BASELINE configs C3 / C4 / C5 at their per-GPU sizes, matrix-core path), `integral` (estimate +- sigma).
 """
 import argparse
@@ -102,6 +102,10 @@ def bench_flow(args, rank, ws, dev):
     plan = eng.plan(G, BATCH, dev, f.nis_kind, f.nis_params)      # one captured launch set (the capture runs a 512-sample set)
     seed = 1234 + rank
     plan.reset(seed, 0)
+    # the launch set is captured AFTER the process group is up (init_from_env ran first): with NIS_BENCH_REQUIRE_GRAPH=1 (multi-rank
+    # rehearsals) an eager fallback of the capture is an error instead of a silently different timed region
+    if os.environ.get("NIS_BENCH_REQUIRE_GRAPH") and not plan.captured:
+        raise SystemExit("bench.py: the launch set was not captured into a hipGraph (eager fallback) although NIS_BENCH_REQUIRE_GRAPH is set")
     out = torch.zeros((args.steps, 4), dtype=torch.double, device=dev)
     scratch = torch.zeros((max(G, args.warmup, 1), 4), dtype=torch.double, device=dev)
     tok = plan.token
@@ -176,7 +180,7 @@ def bench_flow(args, rank, ws, dev):
                               valu_insts_per_sample=round(rec["valu_insts"] * 64.0 / (pmc.get("steps_per_launch", G) * BATCH), 1),
                               note="both apply launches of a set (cell 0, last cell with the fused camel) averaged")
     return dict(dt=dt, samples=BATCH * args.steps * ws, sig=sig, sig_err=sig_err, sig_mc=sig_mc, roofline=roof, roofline_hbm=roof_hbm,
-                roofline_issue=roof_issue, G=G)
+                roofline_issue=roof_issue, G=G, graph=bool(plan.captured))
 
 
 def bench_rambo(args, rank, ws, dev):
@@ -334,10 +338,13 @@ def bench_train_step(name, rank, ws, dev, steps=20):
 def cpu_baseline():
     """The reference-equivalent CPU path on the GPU box's host cores: oracle/flow_torch.py -- the PyTorch-CPU fp64
     restatement of the C2 integrate loop, pinned to the reference's golden vectors -- on ALL cores (1 warm-up + median of 5
-    iterations of 1e6 samples), the NumPy oracle on ONE core beside it, and the NumPy RAMBO oracle (2e5 points)."""
+    iterations of 1e6 samples), the NumPy oracle on ONE core beside it; for metric part (ii) oracle/rambo_torch.py -- the PyTorch-CPU
+    restatement of generateKinematics_batch, same thread count, 2 -> 4 massive at the metric's 1e6 points -- and the NumPy RAMBO oracle
+    on one core (2e5 points)."""
     from oracle import flow as oflow
     from oracle import flow_torch as otorch
     from oracle import rambo as orambo
+    from oracle import rambo_torch as orambo_t
     from nf_amd.normalizing_flows.layers.coupling_cells import PWQuad
     torch.manual_seed(0)
     cells = torch.nn.Sequential(PWQuad(2, 1, 4, [3] * 3), PWQuad(2, 1, 4, [3] * 3)).double()
@@ -383,13 +390,26 @@ def cpu_baseline():
     t1 = time.perf_counter()
     orambo.generate_kinematics([100.] * 2, [100.] * 4, 1000., r, 0, 0, -1)
     dtr = time.perf_counter() - t1
+    # metric part (ii) on all cores: the torch-CPU restatement at the metric's batch (README.md:53-58 workload), 1 warm-up + median of 3
+    rt = torch.rand(BATCH, 8, dtype=torch.double, generator=gen)
+    orambo_t.generate_kinematics([100.] * 2, [100.] * 4, 1000., rt[:100_000])
+    tr = []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        orambo_t.generate_kinematics([100.] * 2, [100.] * 4, 1000., rt)
+        tr.append(time.perf_counter() - t1)
+    t_rb = float(np.median(tr))
     return {"value": BATCH / t_all, "unit": "samples/s", "cores": cores, "kind": "port",     # cores = threads used; host_cpus = os.cpu_count()
             "sample": f"oracle.flow_torch.integrate (PyTorch CPU float64, torch.set_num_threads({cores}), fastest of {cands} on this host): C2 model, "
                       f"1e6 samples per iteration, 1 warm-up + median of 5 ({t_all * 1e3:.0f} ms per iteration)",
             "one_core": {"value": n_it * BATCH / dt1, "unit": "samples/s", "cores": 1,
                          "sample": f"oracle.flow.integrate (NumPy float64): {n_it} iterations x 1e6 samples ({dt1:.1f} s)",
                          "integral": float(sig), "sigma": float(sig_err)},
-            "rambo": {"value": n_rb / dtr, "unit": "samples/s", "cores": 1, "sample": f"oracle.rambo 2->4 massive (NumPy), {n_rb} points ({dtr:.1f} s)"},
+            "rambo": {"value": BATCH / t_rb, "unit": "samples/s", "cores": cores, "kind": "port",
+                      "sample": f"oracle.rambo_torch.generate_kinematics (PyTorch CPU float64, {cores} threads): 2->4 massive, E_cm 1000, 1e6 points "
+                                f"per call, 1 warm-up + median of 3 ({t_rb:.2f} s per call)",
+                      "one_core": {"value": n_rb / dtr, "unit": "samples/s", "cores": 1,
+                                   "sample": f"oracle.rambo 2->4 massive (NumPy), {n_rb} points ({dtr:.1f} s)"}},
             "host_cpus": host}
 
 
@@ -440,7 +460,7 @@ def main():
         "config": {"workload": "C2: 2-D camel, PWQuad 2 cells, n_bins 4, NN [3,3,3], train-mode BN, draw inside the step (device Philox, float32 "
                                "lattice), fused camel*J + moments",
                    "batch_per_gpu": BATCH, "global_batch": BATCH * ws, "parallelism": f"sample-shard x{ws}",
-                   "collective": "one all-reduce of (steps,4) moment records", "steps_per_launch_set": flow["G"],
+                   "collective": "one all-reduce (SUM) of the zero-padded (world, steps, 4) moment records + one merge launch (nf_amd/parallel.py: allreduce_moments)", "steps_per_launch_set": flow["G"], "launch_set": ("hipGraph replay" if flow["graph"] else "eager launches"),
                    "backend": (dist.get_backend() if ws > 1 else "none"),
                    "rccl_ranks": (dist.get_world_size() if ws > 1 and dist.get_backend() == "nccl" else 0 if ws > 1 else 1),
                    "samples_per_rank": BATCH * args.steps},

@@ -741,6 +741,15 @@ class TrainPlan:
                 print(f"nf_amd: training-step capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
         torch.cuda.current_stream(self.dev).wait_stream(side)
         self.captured = self.gA is not None
+        # ONE set of buffers: a second forward() overwrites the history the first one's backward still needs.  `generation` counts the
+        # forwards, `_holder` is a weak reference to the token of the autograd node that owns the current history (dead once that node
+        # has run its backward or was dropped): `busy()` tells the caller to take another path, `backward()` refuses a stale generation.
+        self.generation = 0
+        self._holder = None
+
+    def busy(self):
+        """True while the history of the last forward() is still owed to an autograd node that has not run its backward."""
+        return self._holder is not None and self._holder() is not None
 
     def _forward_calls(self):
         eng, L = self.eng, self.eng.L
@@ -767,8 +776,15 @@ class TrainPlan:
                                                   self.bws.numel(), _lib.stream_ptr(self.dev))
             _lib.check(rc, "nis_flow_backward_loss_batched")
 
-    def forward(self, w):
-        """Draws (G, N, d) -> bookkeeping rows (G, 8) (a fresh tensor; the plan's own copy is overwritten by the next replay)."""
+    def forward(self, w, holder=None):
+        """Draws (G, N, d) -> bookkeeping rows (G, 8) (a fresh tensor; the plan's own copy is overwritten by the next replay).
+        `holder`: any weak-referenceable object that lives as long as the caller still wants backward() for THIS forward."""
+        if self.busy():
+            raise _lib.NisError("TrainPlan.forward: the previous forward's history is still awaiting its backward (check busy() and take "
+                                "the eager path or another plan)")
+        import weakref
+        self.generation += 1
+        self._holder = weakref.ref(holder) if holder is not None else None
         self.w.copy_(w)
         if self.gA is not None:
             self.gA.replay()
@@ -778,8 +794,12 @@ class TrainPlan:
         self.eng._raise_on_status(self.ws[:4].view(torch.int32))
         return self.out.clone()
 
-    def backward(self, gloss):
-        """Upstream cotangent of the summed losses -> [gradient blob per cell] (fresh tensors)."""
+    def backward(self, gloss, generation=None):
+        """Upstream cotangent of the summed losses -> [gradient blob per cell] (fresh tensors).  `generation`: the value of
+        `self.generation` right after the forward this backward belongs to; a later forward has overwritten the history -> error."""
+        if generation is not None and generation != self.generation:
+            raise _lib.NisError(f"TrainPlan.backward: stale history (forward #{generation}, the plan is at #{self.generation}): the gradient "
+                                "would be that of another minibatch set")
         self.gloss.copy_(gloss.detach().reshape(1))
         if self.gB is not None:
             self.gB.replay()

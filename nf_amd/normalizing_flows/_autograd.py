@@ -76,6 +76,11 @@ class _HipLossFn(torch.autograd.Function):
         return (None, None, None, None, None, None) + tuple(grads)
 
 
+class _PlanToken:
+    """Lives as long as the autograd node that owns a TrainPlan's current history (flow.TrainPlan.busy)."""
+    __slots__ = ("__weakref__",)
+
+
 class _HipEpochLossFn(torch.autograd.Function):
     """The G minibatches of ONE optimizer step (manager.py:219-270: the epoch's loss is the mean of the minibatch losses and
     backward runs once) as three library calls: nis_flow_forward_hist_batched -> nis_loss_terms_batched -> (backward)
@@ -87,11 +92,14 @@ class _HipEpochLossFn(torch.autograd.Function):
         w = w.detach()
         builtin = hasattr(f, "nis_kind")
         ctx.plan = None
-        if builtin and _train_graph_ok(engine, w):
+        plan = engine.train_plan(w.shape[0], w.shape[1], w.device, f, maxf, preburn, est) if builtin and _train_graph_ok(engine, w) else None
+        # the plan has ONE history: while an earlier forward of the same shape still awaits its backward (an epoch of more minibatches
+        # than one call carries: manager.py:212-280 runs every chunk's forward before the single loss.backward()) this call runs eagerly
+        if plan is not None and not plan.busy():
             # launch-bound regime: both halves of the step are captured graphs (flow.TrainPlan); same calls, same results
-            plan = engine.train_plan(w.shape[0], w.shape[1], w.device, f, maxf, preburn, est)
-            out = plan.forward(w)
-            ctx.engine, ctx.plan = engine, plan
+            ctx.token = _PlanToken()
+            out = plan.forward(w, holder=ctx.token)
+            ctx.engine, ctx.plan, ctx.generation = engine, plan, plan.generation
             ctx.mark_non_differentiable(out)
             return out[:, 2].sum(), out
         xj, saved = engine.forward_train_batched(w, True, want_xj=not builtin and not preburn)
@@ -108,7 +116,8 @@ class _HipEpochLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _gout):
         if ctx.plan is not None:
-            gflat = ctx.plan.backward(gloss)
+            gflat = ctx.plan.backward(gloss, ctx.generation)
+            ctx.token = None                    # the history is free again
         else:
             gflat = ctx.engine.backward_loss_batched(ctx.saved, ctx.fv, ctx.maxf, ctx.rec, gloss, ctx.est)
             ctx.saved = ctx.fv = None

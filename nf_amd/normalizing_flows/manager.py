@@ -485,14 +485,11 @@ class BasicManager(ModelAPI):
             # the G plane sets into weight * J moment records.  The status word accumulates on the device and is read once.
             eng = model.engine()
             G = max(1, min(int(self.batch_iterations), nitn, max(1, (1 << 27) // max(1, neval * (self.n_flow + 1)))))
-            key = (G, eng.d, neval, str(dev))
-            if getattr(self, "_planar_key", None) != key:
-                self._planar_key = key
-                self._planar_buf = (torch.empty((G, 4), dtype=torch.double, device=dev),
-                                    torch.empty((G, eng.d + 1, neval), dtype=torch.double, device=dev),
-                                    torch.zeros(1, dtype=torch.int32, device=dev))
-            scratch, planes, status = self._planar_buf
-            status.zero_()
+            # kept planes live for this call only (torch's caching allocator makes the re-allocation free; a buffer cached on the
+            # manager held 0.5 - 0.8 GB away from the training workspaces for the manager's lifetime: ADVICE r3)
+            scratch = torch.empty((G, 4), dtype=torch.double, device=dev)
+            planes = torch.empty((G, eng.d + 1, neval), dtype=torch.double, device=dev)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
             if in_kernel:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             i = 0
@@ -519,11 +516,7 @@ class BasicManager(ModelAPI):
             eng = model.engine()
             d = eng.d
             G = max(1, min(int(self.batch_iterations), nitn, max(1, (1 << 27) // max(1, neval * (d + 1)))))
-            key = ("callable", G, d, neval, str(dev))
-            if getattr(self, "_planar_key", None) != key:
-                self._planar_key = key
-                self._planar_buf = (None, torch.empty((G, d + 1, neval), dtype=torch.double, device=dev), None)
-            planes = self._planar_buf[1]
+            planes = torch.empty((G, d + 1, neval), dtype=torch.double, device=dev)        # this call's only (see above)
             identity = list(eng.out_col) == list(range(d))
             cols = None if identity else torch.as_tensor(eng.out_col, device=dev)
             if in_kernel:

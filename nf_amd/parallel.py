@@ -104,50 +104,26 @@ def merge_gathered(buf):
     return out
 
 
-_GATHER_FORM = {}        # backend name -> "tensor" | "list": which all-gather form this backend accepts for CUDA tensors
-
-
-def gather_records(loc, group=None):
-    """(world,) + loc.shape gathered copies of a CUDA tensor, one collective: `all_gather_into_tensor` (RCCL: one ncclAllGather)
-    where the backend implements it, else the list form into views of the same buffer (gloo on CUDA tensors: the rehearsal of
-    several ranks on one GPU then runs the very code path -- gather + `nis_merge_moments` -- the RCCL job runs)."""
-    ws = dist.get_world_size(group)
-    backend = dist.get_backend(group)
-    buf = torch.empty((ws,) + tuple(loc.shape), dtype=loc.dtype, device=loc.device)
-    form = _GATHER_FORM.get(backend)
-    if form in (None, "tensor") and hasattr(dist, "all_gather_into_tensor"):
-        try:
-            dist.all_gather_into_tensor(buf, loc, group=group)
-            _GATHER_FORM[backend] = "tensor"
-            return buf
-        except (RuntimeError, NotImplementedError):
-            if form == "tensor":
-                raise
-    dist.all_gather(list(buf.unbind(0)), loc, group=group)
-    _GATHER_FORM[backend] = "list"
-    return buf
-
-
 def allreduce_moments(local, group=None):
-    """local: (nitn, 4) float64 records of this rank (any device).  Returns the merged (nitn, 4) records,
-    identical on every rank.  One collective.
+    """local: (nitn, 4) float64 records of this rank (any device).  Returns the merged (nitn, 4) records, identical on every rank.
 
-    On a GPU (any backend): ONE all-gather of the records (world x nitn x 32 bytes) and ONE merge launch (`nis_merge_moments`) --
-    the collective and the merge are inside the job's timed region, so they are two launches, not a dozen tensor operations.
-    On CPU tensors (gloo tests without a GPU): all-reduce (SUM) of a zero-padded (world, nitn, 4) buffer = an exact gather,
-    merged in torch ops."""
+    ONE collective on every backend and device -- the single all-reduce SURVEY.md 8(e) / the north star name: all-reduce (SUM) of a
+    zero-padded (world, nitn, 4) buffer in which a rank fills only its own slot.  x + 0 is exact, so the result is an exact gather
+    (world x nitn x 32 bytes: latency-bound), and every rank then applies the same Chan merge to identical inputs: on a GPU ONE launch
+    (`nis_merge_moments`; collective and merge are inside the job's timed region), on CPU tensors (gloo tests without a GPU) the same
+    formula in torch ops.  RCCL and the gloo rehearsal of several ranks on one GPU run the same branch; a failing collective raises."""
     rank, ws = world()
     if ws == 1:
         return local
-    if local.is_cuda:
-        return merge_gathered(gather_records(local.contiguous(), group))
     buf = torch.zeros((ws,) + tuple(local.shape), dtype=torch.double, device=local.device)
     buf[rank] = local
-    # max slot: an empty rank holds -inf there, which must not poison the SUM -> sanitise per slot
+    # max slot: an empty rank holds -inf there; kept out of the SUM (-inf + 0 is fine, but a NaN-free buffer is the simpler contract)
     buf[rank, ..., 3] = torch.nan_to_num(local[..., 3], neginf=0.0)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    if local.is_cuda:
+        return merge_gathered(buf)                  # (world, nitn, 4) -> (nitn, 4), one launch
     recs = buf.movedim(0, -2)                       # (nitn, world, 4)
-    return merge_moments_t(recs)                    # stays on the device: the merge is part of the timed job
+    return merge_moments_t(recs)
 
 
 def shard_size(total, rank, ws):

@@ -2150,6 +2150,63 @@ def test_captured_training_step_equals_eager(shape, monkeypatch):
         np.testing.assert_allclose(sa[k], sb[k], rtol=1e-11, atol=1e-15, err_msg=k)
 
 
+def test_captured_training_step_with_more_chunks_than_one_plan_holds(monkeypatch):
+    """a TrainPlan owns ONE history.  An epoch of more minibatches than one fused call carries runs every chunk's
+    forward before the single loss.backward() (manager.py:212-280); the second chunk of equal shape must NOT reuse the plan while the
+    first one's backward is outstanding (it used to: both backward nodes then replayed on the LAST chunk's history -- silently
+    2 x grad(chunk 2)).  Now the busy plan sends the second chunk down the eager path; gradients equal the all-eager run, and a direct
+    misuse of the plan raises."""
+    import copy
+    from nf_amd import _lib, integrands
+    from nf_amd.normalizing_flows import manager as mgr
+    shape = dict(kind="pwquad", d=2, n_cells=2, K=4, NN=[3, 3, 3])
+    torch.manual_seed(32)
+    base = build_manager(shape)
+    f = integrands.Camel()
+    g = torch.Generator().manual_seed(9)
+    draws = [torch.rand(1000, 2, dtype=torch.double, generator=g) for _ in range(40)]
+    monkeypatch.setattr(mgr.BasicManager, "_minibatches_per_call", lambda self, mbs: 2)     # 4 minibatches per epoch = two chunks of 2
+
+    def run(graph):
+        if graph:
+            monkeypatch.setenv("NIS_TRAIN_GRAPH", "1")
+        else:
+            monkeypatch.delenv("NIS_TRAIN_GRAPH", raising=False)
+        NF = build_manager(shape)
+        NF._model = copy.deepcopy(base._model)
+        NF.best_model = NF._model
+        it = iter(draws)
+        NF.sample_hook = lambda n, dd, dtype, stage: next(it)[:n].to(dtype)
+        optim = torch.optim.Adamax(NF._model.parameters(), lr=2e-3, weight_decay=1e-4)
+        NF._train_variance_forward_seq(f, optim, False, None, 4000, 3, 0, True, True, mini_batch_size=1000, integrate=False, preburn_time=0)
+        return NF, t2n(torch.stack(NF.history)), [t2n(p.grad) for p in NF._model.parameters()]
+
+    NFa, ha, ga = run(True)
+    plans = NFa._model.engine()._train_plans
+    assert plans and all(p.captured and not p.busy() for p in plans.values())
+    _, hb, gb = run(False)
+    np.testing.assert_allclose(ha, hb, rtol=1e-12)
+    for x, y in zip(ga, gb):
+        np.testing.assert_allclose(x, y, rtol=1e-10, atol=1e-16)
+    # direct misuse: a second forward while a holder of the first is alive, and a backward of an overwritten generation
+    plan = next(iter(plans.values()))
+
+    class Tok:
+        pass
+    t1 = Tok()
+    w = torch.rand(plan.G, plan.N, 2, dtype=torch.double, device=dev())
+    plan.forward(w, holder=t1)
+    gen1 = plan.generation
+    assert plan.busy()
+    with pytest.raises(_lib.NisError, match="awaiting its backward"):
+        plan.forward(w, holder=Tok())
+    del t1
+    assert not plan.busy()
+    plan.forward(w)
+    with pytest.raises(_lib.NisError, match="stale history"):
+        plan.backward(torch.ones(1, dtype=torch.double, device=dev()), gen1)
+
+
 # NIS_TEST_SWEEP_SEED=<int> shifts the seed of every random sweep below (other shapes, same tests); NIS_TEST_SWEEP_SCALE=<k> multiplies the
 # number of cases.  The default run is the committed, fixed set.  Shifted seeds can hit knife-edge samples that are ambiguous in the
 # reference itself (DESIGN.md 4d: a width at the threshold of vanishing in the cumulative sum makes the bin depend on the last bit of exp();
@@ -2234,7 +2291,8 @@ def test_random_cell_shapes_forward_and_adjoint(kind, d, P, K, NN, N):
             cell.load_state_dict(sd)
             o_t = model_torch(model, x.to(dev()))
         keep = ((o_h - o_t).abs() <= 1e-8 * o_t.abs() + 1e-12).all(dim=1)
-        assert float(keep.double().mean()) > 0.9, f"train={train}: only {int(keep.sum())} of {N} samples agree in the forward pass"
+        # a handful of edge samples, not a tenth of the batch: a forward bug that touches more rows than that fails here
+        assert int((~keep).sum()) <= max(3, N // 200), f"train={train}: {int((~keep).sum())} of {N} samples disagree in the forward pass"
         cell.load_state_dict(sd)
         gx_h, gp_h = grads(False)
         cell.load_state_dict(sd)

@@ -127,6 +127,22 @@ def test_rambo_matches_reference(case, g_rambo):
     np.testing.assert_array_equal(wgt == 0, g_rambo.get(case, "weight") == 0)
 
 
+@pytest.mark.parametrize("case", _cases("rambo.npz"))
+def test_rambo_torch_restatement_matches_reference(case, g_rambo):
+    """oracle/rambo_torch.py (the all-core CPU baseline of bench.py for the 2 -> n map) against the reference's golden vectors, at the
+    tolerances the NumPy oracle holds; and bit-for-bit the same cut mask."""
+    import torch
+    from oracle import rambo_torch as otr
+    m = g_rambo.meta[case]
+    mom, wgt = otr.generate_kinematics(m["initial"], m["final"], m["E_cm"], torch.from_numpy(np.ascontiguousarray(g_rambo.get(case, "r"))),
+                                       m["cuts"][0], m["cuts"][1], m["cuts"][2], pdf_active=m["pdf_active"], tau=m["tau"])
+    mom, wgt = mom.numpy(), wgt.numpy()
+    scale = np.abs(g_rambo.get(case, "momenta")).max()
+    np.testing.assert_allclose(mom, g_rambo.get(case, "momenta"), rtol=1e-10, atol=1e-11 * scale)
+    np.testing.assert_allclose(wgt, g_rambo.get(case, "weight"), rtol=1e-10)
+    np.testing.assert_array_equal(wgt == 0, g_rambo.get(case, "weight") == 0)
+
+
 def test_rambo_invariants(g_rambo):
     """Known answers independent of the reference: momentum conservation, on-shell legs,
     flat massless weight."""

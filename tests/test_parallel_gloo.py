@@ -160,3 +160,29 @@ def test_data_parallel_single_process_is_a_no_op():
     sc = dp.sync_step(model, torch.tensor([1.5], dtype=torch.double))
     assert torch.equal(model.weight.grad, g) and float(sc[0]) == 1.5
     assert float(dp.sync_max(torch.tensor(2.0))) == 2.0 and float(dp.mean(torch.tensor(2.0))) == 2.0
+
+
+def test_rccl_init_refuses_more_local_ranks_than_devices(monkeypatch):
+    """`init_from_env("nccl")` on a node that shows fewer GPUs than local ranks must fail BEFORE any rendezvous with a message that
+    names the fix (two ranks on one device otherwise die deep inside the first collective: `ncclInvalidUsage: Duplicate GPU detected`).
+    Runs without a GPU: the device count is what the check reads."""
+    from nf_amd import parallel
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.delenv("NIS_DIST_BACKEND", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    called = []
+    monkeypatch.setattr(dist, "init_process_group", lambda *a, **k: called.append((a, k)))
+    with pytest.raises(RuntimeError, match="RCCL needs one GPU per rank: 8 local ranks but 1 visible"):
+        parallel.init_from_env("nccl")
+    assert not called, "no rendezvous may be started"
+    # the rehearsal switch takes the same call through gloo, several ranks per device: device = local rank modulo the device count
+    monkeypatch.setenv("NIS_DIST_BACKEND", "gloo")
+    picked = []
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: picked.append(d))
+    rank, ws, local = parallel.init_from_env("nccl")
+    assert (rank, ws, local) == (3, 8, 3) and picked == [0]
+    assert len(called) == 1 and called[0][1]["backend"] == "gloo" and "device_id" not in called[0][1]

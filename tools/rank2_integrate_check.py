@@ -34,8 +34,7 @@ captured = bool(plan.captured)
 out = torch.zeros((G, 4), dtype=torch.double, device=dev)
 plan.reset(100 + rank, 0)                            # different draws per rank
 plan.run(out, replay=True)
-merged = parallel.allreduce_moments(out)             # CUDA tensor: gather + nis_merge_moments
-form = parallel._GATHER_FORM.get(dist.get_backend())
+merged = parallel.allreduce_moments(out)             # CUDA tensor: one all-reduce of the zero-padded buffer + nis_merge_moments
 # reference: gather the records on the host and merge them with the NumPy Chan update
 mine = out.cpu()
 allrec = [torch.zeros_like(mine) for _ in range(ws)]
@@ -55,7 +54,7 @@ ok = captured and ok_merge and ok_same and ok_int
 flags = torch.tensor([1 if ok else 0])
 dist.all_reduce(flags, op=dist.ReduceOp.MIN)
 if rank == 0:
-    print(f"{'R2_OK' if int(flags) else 'R2_FAIL'} world={ws} backend={dist.get_backend()} gather_form={form} captured={captured} merge={ok_merge} "
+    print(f"{'R2_OK' if int(flags) else 'R2_FAIL'} world={ws} backend={dist.get_backend()} captured={captured} merge={ok_merge} "
           f"identical={ok_same} integrate={ok_int} sig={float(sig):.6f}+-{float(err):.2e}", flush=True)
 dist.barrier()
 dist.destroy_process_group()
