@@ -12,9 +12,11 @@
 //     from its accumulator registers;
 //   * in the head the bijector adjoint leaves dZ of (sample l&15, column slot l>>4) in that lane's registers: with the
 //     k index running over the 4 column slots of a batch, row q of each slot is one MFMA k-step of d a_L = W_L^T dZ;
-//   * only the weight gradients dW = d h a^T reduce over SAMPLES, which this layout keeps in the n index.  They are
-//     taken from the planes the chain stores anyway (dZ, d h, a) by a tall-skinny MFMA GEMM (k_bwd_xty_w) whose
-//     k index runs over samples.
+//   * only the weight gradients dW = d h a^T reduce over SAMPLES, which this layout keeps in the n index.  The hidden layers'
+//     (round 4) are accumulated INSIDE k_bwd_layer_w: the wave's d h and a tiles cross a padded per-wave LDS image and come
+//     back with samples on the k index (16 MFMAs per tile at width 32), per-workgroup records go to the reduction the chain
+//     runs anyway -- no d h / a planes, no GEMM launch.  The last layer's dW_L = dZ a_L^T is still taken from the dZ / a_L planes
+//     the head stores by a tall-skinny MFMA GEMM (k_bwd_xty_w) whose k index runs over samples.
 #include <algorithm>
 #include <cstring>
 
@@ -33,12 +35,16 @@ constexpr int RPW = WM >= 64 ? 2 : 4;           // row tiles (of 16) per workgro
 constexpr int GREC = RPW * 16 * (WM + 1);       // its record: RPW*16 rows x (WM products | row sum)
 constexpr int SREC = 2 * WM;                    // BatchNorm record: sum dy | sum dy*xhat
 constexpr int BNLDS = (NIS_MAX_HIDDEN + 1) * 4 * WM;
+constexpr int TS = 17;                          // row stride (doubles) of the staging tiles [feature][16 samples]: transposed reads without bank conflicts
+constexpr int STAGE = NW * 2 * WM * TS;         // k_bwd_layer_w: per wave the d h tile and the a tile of its current 16 samples
 
 struct BwdW {
   const double* wm_all;                         // MFMA fragments of the hidden layers / last layer (k_pack_mfma)
   const double* wm_last;
   const double* bias_pad;
-  double* dhp;                                  // WM planes: dL/d(pre-BN_l activations), A operand of the dW GEMM
+  double* partg;                                // k_bwd_layer_w: records of dW_{l-1} (row groups of GREC per workgroup, the GEMM's record layout)
+  long partg_gs;                                //   doubles between the minibatches' record areas
+  int nb;                                       //   workgroups per minibatch (record index = group * nb + blockIdx.x)
 };
 
 // Workspace buffers (dZ, dy, d h, a) are tile-major: [16-sample tile][feature][16 samples], so one wave's tile is a
@@ -174,7 +180,7 @@ __device__ __forceinline__ void bww_batch(BwdK& k, BwdW* w) {
   k.dzp += g * k.wsp_gs;
   k.part += g * k.part_gs;
   if (k.sums) k.sums += g * k.sums_gs;
-  if (w) w->dhp += g * k.wsp_gs;
+  if (w) w->partg += g * w->partg_gs;
 }
 
 __device__ __forceinline__ void bww_stage(const BwdK& k, double* lds_bn, int* lds_plane) {
@@ -549,13 +555,421 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
 }
 
 // ---------------------------------------------------------------------------------------------
-// layer l (L..1): BN_l backward -> d h_l planes, a_{l-1} planes, dy_{l-1} = relu'(.) W_{l-1}^T d h_l, sums of BN_{l-1}
+// head, round 4: BIJECTOR waves + GEMM waves.  One 512-thread workgroup per CU; waves 0..3 (one per SIMD) own a 16-sample tile each
+// and run only the vector work (forward recompute of the hidden stack, the bijector adjoint, ReLU / BatchNorm bookkeeping); waves
+// 4..7 (the second wave of each SIMD) run only the three GEMMs of the last Linear for ALL four tiles:
+//     Z = W_L a_L (+ exp -> the tile's LDS ring)  |  d a_L += W_L^T dZ  |  dW_L += dZ a_L^T, db_L += sum dZ
+// so a weight fragment fetched from L2 feeds 2-4 MFMAs instead of one, dZ never leaves the LDS ring (no 8 R bytes per sample written
+// and read back, no k_bwd_xty_w launch for the last layer), and neither role carries the other's registers (the one-role head spilled
+// 52-85 dwords at 256 VGPRs).  f64 MFMA and VALU work serialise on a SIMD whichever wave issues them (profiles/r04_mfma_valu_overlap.txt),
+// so the roles are phases separated by workgroup barriers, not a pipeline:
+//   P1 bijector waves: a_L tile -> LDS        P2 GEMM waves: exp(W_L a_L) of one column batch -> rings
+//   P3 bijector waves: dZ in place in rings   P4 GEMM waves: d a_L, dW_L from the rings       P5 d a_L -> LDS -> dy, BatchNorm sums
+// dW_L lives in the GEMM waves' registers for the whole launch: (column batch, 16-row tile) pairs are dealt round-robin to the four
+// waves, MAXP pairs each; the host takes this kernel when the cell's pairs fit (else the one-role head + k_bwd_xty_w).
+constexpr int TPB2 = 512;
+constexpr int MAXP = WM == 16 ? 8 : WM == 32 ? 6 : 3;     // pairs per GEMM wave: MAXP * JT accumulator tiles = 64 / 96 / 96 VGPRs
+constexpr int DAW = 4 / (JT < 4 ? JT : 4);                // d a_L: a GEMM wave owns feature tile g % JT of DAW sample tiles (JT = 4: every wave all four... one tile column)
+
+struct Head2 {
+  int ncb, ncbat, rows_cb, ntile_cb;            // columns per batch, batches, ncb * out, 16-row tiles of a batch's image
+  int ngl;                                      // row groups of the dW_L record (GEMM layout: RPW * 16 rows x (WM + 1))
+};
+
+// blob row of ring row j of column batch cb (-1: no such row).  Piecewise cells: rows are [t][out] in both; AffineCoupling: the ring is
+// [t][scale, shift] (packed interleaved), the blob [scale | shift][T]
+template <int KIND>
+__device__ __forceinline__ int head2_row(const CellK& c, const Head2& h, int cb, int j) {
+  if (j >= h.rows_cb) return -1;
+  if (KIND == NIS_AFFINE) {
+    const int t = cb * h.ncb + (j >> 1);
+    return t < c.T ? ((j & 1) ? c.T + t : t) : -1;
+  }
+  const int r = cb * h.rows_cb + j;
+  return r < c.R ? r : -1;
+}
+
+// LDS of the two-role head
+struct Head2Lds {
+  double* rings;           // NW rings of ring_rows x TS: exp(Z) of the current column batch, then dZ in place
+  double* aLt;             // NW a_L tiles, WM x TS
+  double* daT;             // NW d a_L tiles, WM x TS
+  double* xhT;             // NW xhat_L tiles, WM x TS (parked by the bijector wave over its column batches: 2 KQ registers less in the bijector phase)
+  const double* lds_bn;
+  const int* lds_plane;
+  const double* etab;
+  double (*sm)[SREC];
+  int ring_rows;
+};
+
+// ---- role 1: bijector wave `wave` (0 .. NW-1).  Barrier sequence per tile set: B1 | per batch: B2 B3 [B5] | B4  -- the same as role 2's.
+template <int KIND, int KM, bool KEXACT>
+__device__ __forceinline__ void head2_bijector(const BwdK& k, const BwdW& w, const Head2& h, const Head2Lds& m, int wave) {
+  const CellK& c = k.c;
+  const int lane = threadIdx.x & 63, gq = lane >> 4, s = lane & 15;
+  const int L = c.L, K = KEXACT ? KM : c.K, out = c.out;
+  const long ld = k.ld, N = k.N;
+  const double* bnL = m.lds_bn + (size_t)L * 4 * WM;
+  double* const at = m.aLt + (size_t)wave * WM * TS;
+  double* const xt = m.xhT + (size_t)wave * WM * TS;
+  const double* const dt = m.daT + (size_t)wave * WM * TS;
+  const long wstride = (long)gridDim.x * NW * 16;
+  for (long base0 = (long)blockIdx.x * NW * 16; base0 < N; base0 += wstride) {       // (uniform trip count: every wave meets every barrier)
+    // ---------------- P1: hidden stack -> a_L, xhat_L tiles in LDS (this lane's entries: feature 4 q + gq, sample s)
+    const long i = base0 + 16 * wave + s;
+    const bool iv = i < N;
+    {
+      double H[KQ][ST], XH[KQ][ST];
+      nis_d4 acc[JT][ST];
+      bww_forward(c, k.x, ld, N, base0 + 16 * wave, m.lds_plane, m.lds_bn, w.wm_all, L, H, XH, acc);
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * jt + gq + 4 * r;
+          const double sc = bnL[j], sh = bnL[WM + j], mu = bnL[2 * WM + j], rs = bnL[3 * WM + j];
+          const double v = acc[jt][0][r];
+          xt[j * TS + s] = (v - mu) * rs;
+          at[j * TS + s] = fmax(fma(v, sc, sh), 0.0);            // a_L
+        }
+    }
+    const double gJ = iv ? k.g[(size_t)c.jplane * ld + i] : 0.0;
+    const double Jout = iv ? k.xo[(size_t)c.jplane * ld + i] : 1.0;
+    double jfprod = 1.0;
+    __syncthreads();                                             // B1
+    for (int cb = 0; cb < h.ncbat; ++cb) {
+      // the inputs of this batch's column are requested before the wait for the GEMM waves' exponentials
+      const int t = cb * h.ncb + gq;
+      const bool valid = gq < h.ncb && t < c.T && iv;
+      const int tc = min(t, c.T - 1);
+      const size_t colp = (size_t)m.lds_plane[c.P + tc] * ld;
+      const double xraw = valid ? k.x[colp + i] : 0.5;
+      const double gy = valid ? k.g[colp + i] : 0.0;
+      const double gJv = valid ? gJ : 0.0;
+      __syncthreads();                                           // B2: the rings hold exp(Z) of batch cb
+      // ---------------- P3: (sample s, column slot gq) per lane; dZ replaces the exponentials in the ring
+      if (gq < h.ncb) {
+        double* const zw = m.rings + (size_t)wave * m.ring_rows * TS + (size_t)gq * out * TS + s;
+        const double* const zr = zw;
+        double gx = 0.0, jf = 1.0;
+        if (KIND == NIS_PWQUAD) {
+          const bool clamped = xraw > 1.0 - 1e-6;
+          const double xb = clamped ? 1.0 - 1e-6 : xraw;
+          double V[KM + 1], W[KM];
+#pragma unroll
+          for (int q = 0; q < KM + 1; ++q) V[q] = (KEXACT || q <= K) ? (valid ? zr[q * TS] : 1.0) : 0.0;
+#pragma unroll
+          for (int q = 0; q < KM; ++q) W[q] = (KEXACT || q < K) ? (valid ? zr[(K + 1 + q) * TS] : 1.0) : 0.0;
+          double wn = 0.0;
+#pragma unroll
+          for (int q = 0; q < KM; ++q)
+            if (q < K) wn += W[q];
+          int b;
+          double left;
+          pwquad_bin<KM, false>(xb, K, W, wn, &b, &left);
+          const double iwn = 1.0 / wn;
+          double area = 0.0;
+#pragma unroll
+          for (int q = 0; q < KM; ++q)
+            if (q < K) {
+              W[q] = W[q] * iwn;
+              area += (V[q] + V[q + 1]) / 2 * W[q];
+            }
+          const double iarea = 1.0 / area;
+#pragma unroll
+          for (int q = 0; q < KM + 1; ++q)
+            if (q <= K) V[q] = V[q] * iarea;
+          const double Wb = valid ? zr[(K + 1 + b) * TS] * iwn : 1.0;
+          const double Vb = valid ? zr[b * TS] * iarea : 1.0, Vb1 = valid ? zr[(b + 1) * TS] * iarea : 1.0;
+          const double alpha = (xb - left) / Wb;
+          const double D = Vb1 - Vb;
+          jf = lerp_torch(Vb, Vb1, alpha);
+          const double gjf = gJv * Jout / jf;                  // J_out = J_in prod_t jf_t
+          const double galpha = gy * jf * Wb + gjf * D;
+          gx = clamped ? 0.0 : galpha / Wb;
+          const double gleft = -galpha / Wb;
+          // gradients w.r.t. the normalised heights / widths are sparse in q: re-formed on the fly in each pass (see k_bwd_head_w)
+          const double hgy = gy / 2;
+          const double A0 = gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha);
+          const double A1 = gy * alpha * alpha / 2 * Wb + gjf * alpha;
+          const double B0 = gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb;
+#define NIS_GV(q, wm1, wq) (((q) >= 1 && (q) - 1 < b ? hgy * (wm1) : 0.0) + ((q) < b ? hgy * (wq) : 0.0) + ((q) == b ? A0 : 0.0) + ((q) == b + 1 ? A1 : 0.0))
+#define NIS_GW0(q) (((q) < b ? hgy * (V[q] + V[(q) + 1]) + gleft : 0.0) + ((q) == b ? B0 : 0.0))
+          double S = 0.0;
+#pragma unroll
+          for (int q = 0; q < KM + 1; ++q)
+            if (KEXACT || q <= K) {
+              const double wm1 = q >= 1 ? W[q >= 1 ? q - 1 : 0] : 0.0;
+              const double wq = (q < KM && (KEXACT || q < K)) ? W[q < KM ? q : 0] : 0.0;
+              S += NIS_GV(q, wm1, wq) * V[q];
+            }
+          double Sw = 0.0;
+#pragma unroll
+          for (int q = 0; q < KM; ++q)
+            if (KEXACT || q < K) Sw += (NIS_GW0(q) - S * (V[q] + V[q + 1]) / 2) * W[q];
+          double wprev = 0.0;
+#pragma unroll
+          for (int q = 0; q < KM + 1; ++q)
+            if (KEXACT || q <= K) {                          // wave-uniform
+              const bool hasw = q < KM && (KEXACT || q < K);
+              const double wq = hasw ? W[q < KM ? q : 0] : 0.0;
+              const double vq = V[q];
+              const double dzv = NIS_GV(q, wprev, wq) * vq - S * vq * (wprev + wq) / 2;
+              if (hasw) {
+                const double dzw = wq * (NIS_GW0(q) - S * (vq + V[q + 1]) / 2 - Sw);
+                zw[(K + 1 + q) * TS] = valid ? dzw : 0.0;
+              }
+              zw[q * TS] = valid ? dzv : 0.0;
+              wprev = wq;
+            }
+#undef NIS_GV
+#undef NIS_GW0
+        } else if (KIND == NIS_AFFINE) {
+          const double s0 = 20.0 * (valid ? zr[0] : 1.0), z1 = valid ? zr[TS] : 0.0;
+          const double u = xraw * s0 + (z1 > 0.0 ? z1 : 0.0);
+          const double q = 1.0 / (u * u + 1.0);
+          jf = s0 * q;
+          const double gjf = gJv * Jout / jf;
+          const double gu = gy * (q / (M_PI / 2)) - gjf * (2.0 * u * s0 * q * q);
+          gx = gu * s0;
+          zw[0] = valid ? (gu * xraw + gjf * q) * s0 : 0.0;
+          zw[TS] = (valid && z1 > 0.0) ? gu : 0.0;
+        } else {
+          // PWLin: Q_q = K e_q / tot, y = Q_b alpha + sum_{q<b} e_q / tot, jf = Q_b
+          const double ak = xraw * K;
+          const double bf = floor(ak);
+          const double alpha = (ak - bf) / K;
+          const int b = (int)bf;
+          double tot = 0.0, below = 0.0, eb = 0.0;
+          for (int q = 0; q < K; ++q) {
+            const double e = valid ? zr[q * TS] : 1.0;
+            const bool hit = q == b;
+            below = hit ? tot : below;
+            eb = hit ? e : eb;
+            tot += e;
+          }
+          const double Qb = eb / (tot / K);
+          const double Qs = below / tot;
+          jf = Qb;
+          const double gjf = gJv * Jout / jf;
+          const double gQb = gy * alpha + gjf, gQs = gy;
+          gx = gy * Qb;
+          for (int q = 0; q < K; ++q) {
+            const double pq = (valid ? zr[q * TS] : 1.0) / tot;
+            const double dz = gQb * ((q == b ? Qb : 0.0) - Qb * pq) + gQs * ((q < b ? pq : 0.0) - Qs * pq);
+            zw[q * TS] = valid ? dz : 0.0;
+          }
+        }
+        if (valid) {
+          k.g[colp + i] = gx;
+          jfprod *= jf;
+        }
+      }
+      __syncthreads();                                           // B3: the rings hold dZ of batch cb
+      if (cb + 1 < h.ncbat) __syncthreads();                     // B5: the GEMM waves are done with them
+    }
+    __syncthreads();                                             // B4: d a_L tiles are in LDS
+    // ---------------- P5: through ReLU to BN_L's output; sums of BN_L
+    jfprod *= __shfl_xor(jfprod, 16, 64);
+    jfprod *= __shfl_xor(jfprod, 32, 64);
+    if (KIND == NIS_AFFINE) jfprod *= 1.0 / (M_PI / 2);
+    if (gq == 0 && iv) k.g[(size_t)c.jplane * ld + i] = gJ * jfprod;   // dL/dJ_in = dL/dJ_out prod_t dy_t/dx_t
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int j = 4 * q + gq;
+      const double dy = at[j * TS + s] > 0.0 ? dt[j * TS + s] : 0.0;
+      if (iv) k.dyp[tmx(WM, j, i)] = dy;
+      double t1 = iv ? dy : 0.0, t2 = iv ? dy * xt[j * TS + s] : 0.0;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        t1 += __shfl_xor(t1, o, 64);
+        t2 += __shfl_xor(t2, o, 64);
+      }
+      if (s == 0) {
+        m.sm[wave][j] += t1;
+        m.sm[wave][WM + j] += t2;
+      }
+    }
+    // (the next P1 overwrites the a_L tile: the GEMM waves passed their last use of it before B4)
+  }
+}
+
+// ---- role 2: GEMM wave gw (0 .. NW-1), all four tiles of the workgroup
+template <int KIND>
+__device__ __forceinline__ void head2_gemm(const BwdK& k, const BwdW& w, const Head2& h, const Head2Lds& m, int gw) {
+  const CellK& c = k.c;
+  const int lane = threadIdx.x & 63, gq = lane >> 4, s = lane & 15;
+  const long N = k.N;
+  const int ring_rows = m.ring_rows;
+  // dW_L tiles of this wave's pairs p = gw + 4 pi -> (column batch p / ntile_cb, row tile p % ntile_cb), and their row sums (db_L)
+  nis_d4 dW[MAXP][JT];
+  double rsum[MAXP];
+#pragma unroll
+  for (int pi = 0; pi < MAXP; ++pi) {
+    rsum[pi] = 0.0;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) dW[pi][jt] = nis_d4{0.0, 0.0, 0.0, 0.0};
+  }
+  const int djt = gw % JT;                                       // d a_L: feature tile djt of the sample tiles gw / JT + (NW / DAW) u
+  const long wstride = (long)gridDim.x * NW * 16;
+  for (long base0 = (long)blockIdx.x * NW * 16; base0 < N; base0 += wstride) {
+    nis_d4 da[DAW];
+#pragma unroll
+    for (int u = 0; u < DAW; ++u) da[u] = nis_d4{0.0, 0.0, 0.0, 0.0};
+    __syncthreads();                                             // B1: the a_L tiles are in LDS
+    for (int cb = 0; cb < h.ncbat; ++cb) {
+      const int r0 = cb * h.rows_cb;
+      const int r1 = min(c.R, r0 + h.rows_cb);
+      // ---------------- P2: exp(W_L a_L + b) of this batch's rows into the four rings; a weight fragment feeds four MFMAs
+      for (int jt = r0 / 16 + gw; jt * 16 < r1; jt += NW) {
+        double fa[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) fa[q] = w.wm_last[((size_t)jt * KQ + q) * 64 + lane];
+        nis_d4 z[NW];
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z[wv][r] = w.bias_pad[16 * jt + gq + 4 * r];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+          for (int wv = 0; wv < NW; ++wv)                        // B operand: a_L[feature 4 q + gq][sample s] of tile wv, as it was stored
+            z[wv] = mfma(fa[q], m.aLt[(size_t)wv * WM * TS + (4 * q + gq) * TS + s], z[wv]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * jt + gq + 4 * r - r0;
+          if (j >= 0 && j < h.rows_cb && 16 * jt + gq + 4 * r < c.R) {
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv)
+              m.rings[(size_t)wv * ring_rows * TS + j * TS + s] = (KIND == NIS_AFFINE && (j & 1)) ? z[wv][r] : nis_exp(z[wv][r], m.etab);
+          }
+        }
+      }
+      __syncthreads();                                           // B2
+      __syncthreads();                                           // B3: the rings hold dZ
+      // ---------------- P4: d a_L += W_L^T dZ (k index = ring rows), dW_L += dZ a_L^T (k index = samples), row sums
+      {
+        const int nk = (h.rows_cb + 3) / 4;
+        for (int kq = 0; kq < nk; ++kq) {
+          const int row = head2_row<KIND>(c, h, cb, 4 * kq + gq);
+          const double af = row >= 0 ? c.wlast[(size_t)row * WM + 16 * djt + s] : 0.0;
+#pragma unroll
+          for (int u = 0; u < DAW; ++u) {
+            const int wv = gw / JT + (NW / DAW) * u;
+            da[u] = mfma(af, m.rings[(size_t)wv * ring_rows * TS + (4 * kq + gq) * TS + s], da[u]);
+          }
+        }
+      }
+#pragma unroll
+      for (int pi = 0; pi < MAXP; ++pi) {
+        const int p = gw + NW * pi;
+        if (p / h.ntile_cb == cb) {                              // (wave-uniform)
+          const int rt = p - cb * h.ntile_cb;
+#pragma unroll
+          for (int wv = 0; wv < NW; ++wv) {
+            const double* ring = m.rings + (size_t)wv * ring_rows * TS + (size_t)(16 * rt + s) * TS + gq;
+            const double* at = m.aLt + (size_t)wv * WM * TS + (size_t)s * TS + gq;
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+              const double af = ring[4 * mm];                    // dZ[row 16 rt + s][sample 4 mm + gq]
+              rsum[pi] += af;
+#pragma unroll
+              for (int jt = 0; jt < JT; ++jt) dW[pi][jt] = mfma(af, at[(size_t)16 * jt * TS + 4 * mm], dW[pi][jt]);
+            }
+          }
+        }
+      }
+      if (cb + 1 < h.ncbat) __syncthreads();                     // B5: the next batch's P2 overwrites the rings
+    }
+    // ---------------- P5: d a_L tiles to LDS
+#pragma unroll
+    for (int u = 0; u < DAW; ++u) {
+      const int wv = gw / JT + (NW / DAW) * u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m.daT[(size_t)wv * WM * TS + (16 * djt + gq + 4 * r) * TS + s] = da[u][r];
+    }
+    __syncthreads();                                             // B4
+  }
+  // dW_L / db_L records of this workgroup in the GEMM's layout: [row group][workgroup][RPW * 16 rows x (WM products | row sum)]
+#pragma unroll
+  for (int pi = 0; pi < MAXP; ++pi) {
+    const int p = gw + NW * pi;
+    if (p < h.ncbat * h.ntile_cb) {
+      const int cb = p / h.ntile_cb, rt = p - cb * h.ntile_cb;
+      double rs = rsum[pi];
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = head2_row<KIND>(c, h, cb, 16 * rt + gq + 4 * r);
+        if (row >= 0) {
+          double* rec = w.partg + ((size_t)(row / (RPW * 16)) * w.nb + blockIdx.x) * GREC + (size_t)(row % (RPW * 16)) * (WM + 1);
+#pragma unroll
+          for (int jt = 0; jt < JT; ++jt) rec[16 * jt + s] = dW[pi][jt][r];
+        }
+      }
+      const int rowS = head2_row<KIND>(c, h, cb, 16 * rt + s);
+      if (gq == 0 && rowS >= 0)
+        w.partg[((size_t)(rowS / (RPW * 16)) * w.nb + blockIdx.x) * GREC + (size_t)(rowS % (RPW * 16)) * (WM + 1) + WM] = rs;
+    }
+  }
+}
+
+template <int KIND, int KM, bool KEXACT, bool BATCH>
+__global__ __launch_bounds__(TPB2, 1) void k_bwd_head2_w(BwdK k, BwdW w, Head2 h) {
+  extern __shared__ double mf_dyn[];                 // [NW rings of ntile_cb * 16 rows x TS] [NW x (a_L | d a_L | xhat_L) tiles of WM x TS]
+  __shared__ double lds_bn[BNLDS];
+  __shared__ int lds_plane[NIS_MAX_DIM];
+  __shared__ double etab[NIS_EXP_N];
+  __shared__ double sm[NW][SREC];
+  if (BATCH) bww_batch(k, &w);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  bww_stage(k, lds_bn, lds_plane);
+  nis_exp_init(etab);
+  Head2Lds m;
+  m.ring_rows = h.ntile_cb * 16;
+  m.rings = mf_dyn;
+  m.aLt = m.rings + (size_t)NW * m.ring_rows * TS;
+  m.daT = m.aLt + (size_t)NW * WM * TS;
+  m.xhT = m.daT + (size_t)NW * WM * TS;
+  m.lds_bn = lds_bn;
+  m.lds_plane = lds_plane;
+  m.etab = etab;
+  m.sm = sm;
+  // rows of a ring past the batch's own (rows_cb .. ring_rows) are read by the GEMMs and written by nobody: zero, once
+  const int npad = (m.ring_rows - h.rows_cb) * TS;
+  for (int e = tid; e < NW * npad; e += TPB2) m.rings[(size_t)(e / npad) * m.ring_rows * TS + (size_t)h.rows_cb * TS + e % npad] = 0.0;
+  for (int e = tid; e < NW * SREC; e += TPB2) sm[e / SREC][e % SREC] = 0.0;
+  __syncthreads();
+  // the roles are two separate code paths (their registers never coexist); both meet the same sequence of workgroup barriers
+  if (wave < NW)
+    head2_bijector<KIND, KM, KEXACT>(k, w, h, m, wave);
+  else
+    head2_gemm<KIND>(k, w, h, m, wave - NW);
+  __syncthreads();
+  if (tid < SREC) {
+    double t = 0.0;
+    for (int wv = 0; wv < NW; ++wv) t += sm[wv][tid];
+    k.part[(size_t)blockIdx.x * SREC + tid] = t;
+  }
+  // rows R .. ngl * RPW * 16 of the last group exist in the record only: zero
+  const int pad0 = k.c.R % (RPW * 16);
+  if (pad0 != 0) {
+    double* rec = w.partg + ((size_t)(h.ngl - 1) * w.nb + blockIdx.x) * GREC;
+    for (int e = pad0 * (WM + 1) + tid; e < GREC; e += TPB2) rec[e] = 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// layer l (L..1): BN_l backward -> d h_l, dW_{l-1} += d h_l a_{l-1}^T (records), dy_{l-1} = relu'(.) W_{l-1}^T d h_l, sums of BN_{l-1}
 template <bool BATCH>
 __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l) {
   __shared__ double lds_bn[BNLDS];
   __shared__ int lds_plane[NIS_MAX_DIM];
   __shared__ double lds_m[SREC];
   __shared__ double sm[NW][SREC];
+  __shared__ double stage[STAGE];                    // staging tiles; the epilogue's cross-wave sum of dW reuses it
   if (BATCH) bww_batch(k, &w);
   const CellK& c = k.c;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
@@ -569,6 +983,14 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
   double a1[KQ], a2[KQ];
 #pragma unroll
   for (int q = 0; q < KQ; ++q) a1[q] = a2[q] = 0.0;
+  // dW_{l-1}[row 16 it + gq + 4 r][column 16 jt + s]: the same tile layout as every other accumulator of this file
+  nis_d4 dW[JT][JT];
+#pragma unroll
+  for (int it = 0; it < JT; ++it)
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) dW[it][jt] = nis_d4{0.0, 0.0, 0.0, 0.0};
+  double* const tdh = stage + (size_t)wave * 2 * WM * TS;
+  double* const ta = tdh + WM * TS;
   const long wstride = (long)gridDim.x * NW * 16 * ST;
   for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
     double H[KQ][ST], XH[KQ][ST], DH[KQ][ST];
@@ -589,13 +1011,33 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
             const double dy = iv ? k.dyp[tmx(WM, j, i)] : 0.0;
             const double dh = iv ? sc * (dy - m1 - xh * m2) : 0.0;          // scale_l = gamma_l * rstd_l
             DH[q][st] = dh;
-            if (iv) {
-              w.dhp[tmx(WM, j, i)] = dh;
-              k.alp[tmx(WM, j, i)] = H[q][st];
-            }
           }
         }
     }
+    // dW_{l-1} += d h_l a_{l-1}^T over this tile's 16 samples: both tiles cross the wave's LDS image ([feature][TS], the wave's own
+    // accesses are served in order) and come back with the SAMPLES on the MFMA k index -- lane (i, k) supplies d h[16 it + i][4 m + k],
+    // a[16 jt + i][4 m + k].  Rows of samples past N carry d h = 0.
+    static_assert(ST == 1, "one sample tile per wave pass");
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      tdh[(4 * q + gq) * TS + s] = DH[q][0];
+      ta[(4 * q + gq) * TS + s] = H[q][0];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      double bf[JT];
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt) bf[jt] = jt < nqt ? ta[(16 * jt + s) * TS + 4 * m + gq] : 0.0;
+#pragma unroll
+      for (int it = 0; it < JT; ++it) {
+        const double af = tdh[(16 * it + s) * TS + 4 * m + gq];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+          if (jt < nqt) dW[it][jt] = mfma(af, bf[jt], dW[it][jt]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int qt = 0; qt < JT; ++qt) {
       nis_d4 dacc[ST];
@@ -624,6 +1066,29 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
     }
   }
   bww_emit_sums(a1, a2, sm, k.part + (size_t)blockIdx.x * SREC);
+  // dW records: wave after wave into one image (fixed summation order), then the workgroup's record in the GEMM's layout
+  // (row groups of RPW * 16 rows x (WM + 1); the row-sum column stays zero: no bias behind a hidden Linear's BatchNorm)
+  __syncthreads();
+  for (int wv = 0; wv < NW; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int it = 0; it < JT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = (16 * it + gq + 4 * r) * WM + 16 * jt + s;
+            stage[e] = (wv == 0 ? 0.0 : stage[e]) + dW[it][jt][r];
+          }
+    }
+    __syncthreads();
+  }
+  constexpr int NGH = (WM + RPW * 16 - 1) / (RPW * 16);
+  for (int e = tid; e < NGH * GREC; e += TPB) {
+    const int grp = e / GREC, in = e - grp * GREC;
+    const int row = grp * RPW * 16 + in / (WM + 1), col = in % (WM + 1);
+    w.partg[((size_t)grp * w.nb + blockIdx.x) * GREC + in] = (row < WM && col < WM) ? stage[row * WM + col] : 0.0;
+  }
 }
 
 // BN_0 backward: gradient of the pass-through columns
@@ -837,10 +1302,44 @@ int pick_ncb(int out) {
 long ldw_of(long N) { return (N + 15) / 16 * 16; }
 int groups_of(int rows) { return (rows + RPW * 16 - 1) / (RPW * 16); }
 
+// geometry of the two-role head (k_bwd_head2_w) for a cell, or ok = false when the cell is outside its class: PWQuad up to 16 bins,
+// PWLin, AffineCoupling; rings + tiles within the LDS; the dW_L pairs within the GEMM waves' accumulators
+struct Head2Plan {
+  bool ok;
+  Head2 h;
+  size_t dyn;        // dynamic LDS bytes
+};
+Head2Plan head2_plan(int kind, int K, int T, int out, int R) {
+  Head2Plan hp;
+  hp.ok = false;
+  hp.dyn = 0;
+  memset(&hp.h, 0, sizeof(hp.h));
+  static const int off = getenv("NIS_BWD_HEAD2") ? atoi(getenv("NIS_BWD_HEAD2")) == 0 : 0;     // NIS_BWD_HEAD2=0: the one-role head + GEMM launch (A/B)
+  if (off) return hp;
+  if (WM > 32 || (kind == NIS_PWQUAD && K > 16)) return hp;     // (width 64: the roles do not fit 256 registers; keeps the one-wave-per-SIMD head)
+  const size_t fixed = (size_t)(BNLDS + NIS_EXP_N + NW * SREC) * sizeof(double) + NIS_MAX_DIM * sizeof(int) + 512;
+  for (int n = std::min(NCB, T >= 3 ? 4 : T >= 2 ? 2 : 1); n >= 1; n >>= 1) {
+    Head2 h;
+    h.ncb = n;
+    h.ncbat = (T + n - 1) / n;
+    h.rows_cb = n * out;
+    h.ntile_cb = (h.rows_cb + 15) / 16;
+    h.ngl = groups_of(R);
+    const size_t dyn = (size_t)NW * ((size_t)h.ntile_cb * 16 + 3 * WM) * TS * sizeof(double);
+    if (dyn + fixed > 160 * 1024 || h.ncbat * h.ntile_cb > NW * MAXP) continue;
+    hp.ok = true;
+    hp.h = h;
+    hp.dyn = dyn;
+    return hp;
+  }
+  return hp;
+}
+
 struct Plan {
   int nb;            // workgroups of the head / layer launches
+  int nb2;           // workgroups of the two-role head: one 512-thread workgroup per CU
   int ngl, ngh;      // row groups of the last-layer / hidden GEMMs
-  int nxl, nxh;      // sample chunks (workgroups in x) of those GEMMs
+  int nxl;           // sample chunks (workgroups in x) of the last layer's GEMM
   size_t part;       // doubles of the record area of the chain kernels (BatchNorm sums: nb x SREC)
   size_t partg;      // doubles of the record area of the weight-gradient GEMMs
 };
@@ -850,13 +1349,13 @@ Plan plan_for(int R, long N, int G) {         // the G minibatches of a launch (
   const int cus = device_cus();
   const long per_wg = (long)NW * 16 * ST;
   p.nb = (int)std::max<long>(1, std::min<long>((N + per_wg - 1) / per_wg, std::max<long>(1, (long)cus * 2 / G)));
+  p.nb2 = (int)std::max<long>(1, std::min<long>((N + per_wg - 1) / per_wg, std::max<long>(1, (long)cus / G)));
   p.ngl = groups_of(R);
   p.ngh = groups_of(WM);
   const long tiles_wg = ((N + 15) / 16 + NW - 1) / NW;
   p.nxl = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 2 / (p.ngl * G))));      // 2 resident workgroups per CU
-  p.nxh = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 2 / (p.ngh * G))));
   p.part = (size_t)p.nb * SREC;
-  p.partg = std::max((size_t)p.ngl * p.nxl, (size_t)p.ngh * p.nxh) * GREC;
+  p.partg = std::max((size_t)p.ngl * std::max(p.nxl, p.nb2), (size_t)p.ngh * p.nb) * GREC;   // hidden layers / two-role head: one record per workgroup
   return p;
 }
 }  // namespace
@@ -870,9 +1369,11 @@ bool bwd_wide_supported<NIS_WM>(const nis_cell_desc& cd) {
 template <>
 size_t bwd_wide_workspace_doubles<NIS_WM>(const nis_cell_desc& cd, int64_t N, int G) {
   const int T = cd.d - cd.P;
-  const int R = T * (cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K);
+  const int out = cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K;
+  const int R = T * out;
   const Plan p = plan_for(R, (long)N, G);
-  return (size_t)G * ((size_t)(3 * WM + R) * ldw_of((long)N) + p.part + p.partg + (size_t)(cd.n_hidden + 2) * SREC +
+  const size_t planes = head2_plan(cd.kind, cd.K, T, out, R).ok ? WM : 2 * WM + R;       // two-role head: dy only (no a_L / dZ planes)
+  return (size_t)G * (planes * ldw_of((long)N) + p.part + p.partg + (size_t)(cd.n_hidden + 2) * SREC +
                       (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC);
 }
 
@@ -886,9 +1387,10 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   w.wm_last = mw.wm_last;
   w.bias_pad = mw.bias_pad;
   const long ldw = ldw_of(N);                      // workspace planes: 16-sample aligned rows (vector loads in the GEMM)
-  // per minibatch (blockIdx.z): planes [dy | a | dh | dZ], then -- behind the planes of all minibatches -- the record areas, the
+  // per minibatch (blockIdx.z): planes [dy | a_L | dZ], then -- behind the planes of all minibatches -- the record areas, the
   // reduced BatchNorm sums and the reduced GEMM results, each G sets
-  const size_t wsp = (size_t)(3 * WM + c.R) * ldw;
+  const Head2Plan hp = head2_plan(c.kind, c.K, c.T, c.out, c.R);
+  const size_t wsp = (size_t)(hp.ok ? WM : 2 * WM + c.R) * ldw;
   const size_t nsum = (size_t)(L + 2) * SREC, ngem = (size_t)(p.ngl + L * p.ngh) * GREC;
   k.ldw = ldw;
   k.wsp_gs = (long)wsp;
@@ -896,8 +1398,7 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   k.sums_gs = (long)nsum;
   k.dyp = ws;
   k.alp = ws + (size_t)WM * ldw;
-  w.dhp = ws + (size_t)2 * WM * ldw;
-  k.dzp = ws + (size_t)3 * WM * ldw;
+  k.dzp = ws + (size_t)2 * WM * ldw;
   double* part = ws + (size_t)G * wsp;
   double* partg = part + (size_t)G * p.part;
   double* sums = partg + (size_t)G * p.partg;
@@ -905,56 +1406,88 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   double* ghid = glast + (size_t)p.ngl * GREC;
   k.part = part;
   k.sums = nullptr;
+  w.partg = partg;
+  w.partg_gs = (long)p.partg;
+  w.nb = p.nb;
   CellK& cm = k.c;                                  // (k is this function's own copy)
-  cm.mf_ncb = pick_ncb(c.out);
-  if (cm.mf_ncb < 1) return NIS_E_UNSUPPORTED;
-  const size_t ring = ring_bytes(c.out, cm.mf_ncb);
-  const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : c.K <= 16 ? 16 : 32;
   const unsigned Gz = (unsigned)G;
+  auto reduce_pair = [&](double* sums_out, int nparts, int ngroups, int nx, double* gemm_out) {
+    RedJob a = {part, sums_out, nparts, SREC, 1, (long)p.part, (long)nsum};
+    RedJob b = {partg, gemm_out, nx, GREC, ngroups, (long)p.partg, (long)ngem};
+    hipLaunchKernelGGL(k_bwd_reduce2_w, dim3((GREC + 3) / 4, 1 + ngroups, Gz), dim3(TPB), 0, s, a, b);
+  };
+  if (hp.ok) {
+    // two-role head: dW_L / db_L records come out of the head itself (no dZ / a_L planes, no GEMM launch)
+    w.nb = p.nb2;
+    cm.mf_ncb = hp.h.ncb;
+#define NIS_HEAD2(KIND, KMV, EX)                                                                                                  \
+  do {                                                                                                                            \
+    if (G > 1) hipLaunchKernelGGL((k_bwd_head2_w<KIND, KMV, EX, true>), dim3(p.nb2, 1, Gz), dim3(TPB2), hp.dyn, s, k, w, hp.h);    \
+    else hipLaunchKernelGGL((k_bwd_head2_w<KIND, KMV, EX, false>), dim3(p.nb2, 1, 1), dim3(TPB2), hp.dyn, s, k, w, hp.h);         \
+  } while (0)
+    if (c.kind == NIS_PWLIN)
+      NIS_HEAD2(NIS_PWLIN, 4, false);
+    else if (c.kind == NIS_AFFINE)
+      NIS_HEAD2(NIS_AFFINE, 4, false);
+    else if (c.K == 4)
+      NIS_HEAD2(NIS_PWQUAD, 4, true);
+    else if (c.K == 8)
+      NIS_HEAD2(NIS_PWQUAD, 8, true);
+    else if (c.K == 16)
+      NIS_HEAD2(NIS_PWQUAD, 16, true);
+    else if (c.K < 4)
+      NIS_HEAD2(NIS_PWQUAD, 4, false);
+    else if (c.K < 8)
+      NIS_HEAD2(NIS_PWQUAD, 8, false);
+    else
+      NIS_HEAD2(NIS_PWQUAD, 16, false);
+#undef NIS_HEAD2
+    reduce_pair(sums, p.nb2, p.ngl, p.nb2, glast);
+  } else {
+    cm.mf_ncb = pick_ncb(c.out);
+    if (cm.mf_ncb < 1) return NIS_E_UNSUPPORTED;
+    const size_t ring = ring_bytes(c.out, cm.mf_ncb);
+    const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : c.K <= 16 ? 16 : 32;
 #define NIS_HEAD(KIND, KMV, EX)                                                                                        \
   do {                                                                                                                 \
     if (G > 1) hipLaunchKernelGGL((k_bwd_head_w<KIND, KMV, EX, true>), dim3(p.nb, 1, Gz), dim3(TPB), ring, s, k, w);    \
     else hipLaunchKernelGGL((k_bwd_head_w<KIND, KMV, EX, false>), dim3(p.nb, 1, 1), dim3(TPB), ring, s, k, w);         \
   } while (0)
-  if (c.kind == NIS_PWLIN)
-    NIS_HEAD(NIS_PWLIN, 4, false);
-  else if (c.kind == NIS_AFFINE)
-    NIS_HEAD(NIS_AFFINE, 4, false);
-  else if (c.K == 4)
-    NIS_HEAD(NIS_PWQUAD, 4, true);
-  else if (c.K == 8)
-    NIS_HEAD(NIS_PWQUAD, 8, true);
-  else if (c.K == 16)
-    NIS_HEAD(NIS_PWQUAD, 16, true);
-  else if (km == 4)
-    NIS_HEAD(NIS_PWQUAD, 4, false);
-  else if (km == 8)
-    NIS_HEAD(NIS_PWQUAD, 8, false);
-  else if (km == 16)
-    NIS_HEAD(NIS_PWQUAD, 16, false);
-  else if (c.K <= 32)
-    NIS_HEAD(NIS_PWQUAD, 32, false);
-  else
-    NIS_HEAD(NIS_PWQUAD, NIS_KM_BIG, false);
+    // (cells outside the two-role head's class: PWQuad with more than 16 bins, or too many rows for the GEMM waves' accumulators / the LDS)
+    if (c.kind == NIS_PWLIN)
+      NIS_HEAD(NIS_PWLIN, 4, false);
+    else if (c.kind == NIS_AFFINE)
+      NIS_HEAD(NIS_AFFINE, 4, false);
+    else if (c.K == 4)
+      NIS_HEAD(NIS_PWQUAD, 4, true);
+    else if (c.K == 8)
+      NIS_HEAD(NIS_PWQUAD, 8, true);
+    else if (c.K == 16)
+      NIS_HEAD(NIS_PWQUAD, 16, true);
+    else if (km == 4)
+      NIS_HEAD(NIS_PWQUAD, 4, false);
+    else if (km == 8)
+      NIS_HEAD(NIS_PWQUAD, 8, false);
+    else if (km == 16)
+      NIS_HEAD(NIS_PWQUAD, 16, false);
+    else if (c.K <= 32)
+      NIS_HEAD(NIS_PWQUAD, 32, false);
+    else
+      NIS_HEAD(NIS_PWQUAD, NIS_KM_BIG, false);
 #undef NIS_HEAD
-  auto reduce_pair = [&](double* sums_out, int ngroups, int nx, double* gemm_out) {
-    RedJob a = {part, sums_out, p.nb, SREC, 1, (long)p.part, (long)nsum};
-    RedJob b = {partg, gemm_out, nx, GREC, ngroups, (long)p.partg, (long)ngem};
-    hipLaunchKernelGGL(k_bwd_reduce2_w, dim3((GREC + 3) / 4, 1 + ngroups, Gz), dim3(TPB), 0, s, a, b);
-  };
-  // dW_L = dZ a_L^T, db_L = row sums of dZ; then ONE launch reduces the head's BatchNorm sums and the GEMM's records
-  hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.ngl, Gz), dim3(TPB), 0, s, (const double*)k.dzp, c.R, c.R, (const double*)k.alp, N, partg, (long)wsp,
-                     (long)p.partg);
-  reduce_pair(sums, p.ngl, p.nxl, glast);
+    // dW_L = dZ a_L^T, db_L = row sums of dZ; then ONE launch reduces the head's BatchNorm sums and the GEMM's records
+    hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.ngl, Gz), dim3(TPB), 0, s, (const double*)k.dzp, c.R, c.R, (const double*)k.alp, N, partg, (long)wsp,
+                       (long)p.partg);
+    reduce_pair(sums, p.nb, p.ngl, p.nxl, glast);
+  }
+  w.nb = p.nb;
   for (int l = L; l >= 1; --l) {
     const int pass = L - l + 1;
     k.sums = sums + (size_t)(pass - 1) * SREC;
     if (G > 1) hipLaunchKernelGGL(k_bwd_layer_w<true>, dim3(p.nb, 1, Gz), dim3(TPB), 0, s, k, w, l);
     else hipLaunchKernelGGL(k_bwd_layer_w<false>, dim3(p.nb, 1, 1), dim3(TPB), 0, s, k, w, l);
-    // dW_{l-1} = d h_l a_{l-1}^T
-    hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxh, p.ngh, Gz), dim3(TPB), 0, s, (const double*)w.dhp, WM, c.width[l - 1], (const double*)k.alp, N, partg,
-                       (long)wsp, (long)p.partg);
-    reduce_pair(sums + (size_t)pass * SREC, p.ngh, p.nxh, ghid + (size_t)(l - 1) * p.ngh * GREC);
+    // (dW_{l-1} = d h_l a_{l-1}^T: accumulated by the layer kernel itself, one record per workgroup)
+    reduce_pair(sums + (size_t)pass * SREC, p.nb, p.ngh, p.nb, ghid + (size_t)(l - 1) * p.ngh * GREC);
   }
   k.sums = sums + (size_t)L * SREC;
   {
