@@ -37,6 +37,20 @@ extern "C" {
 #define NIS_MAX_CELLS   64
 #define NIS_MAX_LEGS    10   /* RAMBO: max number of final-state particles            */
 
+/* Device status words at the head of a flow workspace (int32 [0], [1]).  Word 0 is cleared by the first launch of every flow call,
+ * word 1 is STICKY: the kernels only ever OR into it, the caller clears it (e.g. once per integrate()) and reads it when it reads
+ * its results.
+ *   NIS_STATUS_PWLIN_RANGE     a PWLin input coordinate was 1.0 or negative (the reference's torch.gather raises, coupling_cells.py:136)
+ *   NIS_STATUS_BIN_AMBIGUOUS   some PWQuad bin decision rested on last bits: an edge quotient cumsum(W)/sum(W) within 2^-50 (relative) of
+ *                              x, or a width on the threshold of vanishing in the running sum at the end of the kept prefix (whether two
+ *                              edges are EQUAL -- the reference's argmax then takes the first, coupling_cells.py:198-202 -- turns on the
+ *                              last bit of exp()).  These are the samples on which the reference's own CPU and GPU builds disagree; for
+ *                              every sample that does not raise the flag the selected bin is the reference's, bit for bit.
+ * bins_out entries carry the same flag per (column, sample): bin | NIS_BIN_AMBIGUOUS_FLAG. */
+#define NIS_STATUS_PWLIN_RANGE    1
+#define NIS_STATUS_BIN_AMBIGUOUS  2
+#define NIS_BIN_AMBIGUOUS_FLAG    0x40000000
+
 enum { NIS_PWLIN = 0, NIS_PWQUAD = 1, NIS_AFFINE = 2 };
 enum { NIS_BN_EVAL = 0, NIS_BN_TRAIN = 1 };
 enum { NIS_F64 = 0, NIS_F32 = 1 };

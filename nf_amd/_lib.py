@@ -15,6 +15,8 @@ NIS_MAX_LEGS = 10
 
 NIS_PWLIN, NIS_PWQUAD, NIS_AFFINE = 0, 1, 2
 NIS_BN_EVAL, NIS_BN_TRAIN = 0, 1
+NIS_STATUS_PWLIN_RANGE, NIS_STATUS_BIN_AMBIGUOUS = 1, 2      # device status words of a flow workspace (include/nis_hip.h)
+NIS_BIN_AMBIGUOUS_FLAG = 0x40000000                           # bins_out entries: bin | flag
 NIS_F64, NIS_F32 = 0, 1
 NIS_F_CAMEL, NIS_F_NORMAL, NIS_F_ONE = 0, 1, 2
 NIS_F_NONE = -1        # integrate_steps*: no integrand, X / J kept in the planes for a caller-side f

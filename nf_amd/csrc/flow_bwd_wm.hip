@@ -557,19 +557,25 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
 // ---------------------------------------------------------------------------------------------
 // head, round 4: BIJECTOR waves + GEMM waves.  One 512-thread workgroup per CU; waves 0..3 (one per SIMD) own a 16-sample tile each
 // and run only the vector work (forward recompute of the hidden stack, the bijector adjoint, ReLU / BatchNorm bookkeeping); waves
-// 4..7 (the second wave of each SIMD) run only the three GEMMs of the last Linear for ALL four tiles:
+// 4..7 (the second wave of each SIMD) run only the three GEMMs of the last Linear:
 //     Z = W_L a_L (+ exp -> the tile's LDS ring)  |  d a_L += W_L^T dZ  |  dW_L += dZ a_L^T, db_L += sum dZ
-// so a weight fragment fetched from L2 feeds 2-4 MFMAs instead of one, dZ never leaves the LDS ring (no 8 R bytes per sample written
-// and read back, no k_bwd_xty_w launch for the last layer), and neither role carries the other's registers (the one-role head spilled
-// 52-85 dwords at 256 VGPRs).  f64 MFMA and VALU work serialise on a SIMD whichever wave issues them (profiles/r04_mfma_valu_overlap.txt),
-// so the roles are phases separated by workgroup barriers, not a pipeline:
-//   P1 bijector waves: a_L tile -> LDS        P2 GEMM waves: exp(W_L a_L) of one column batch -> rings
-//   P3 bijector waves: dZ in place in rings   P4 GEMM waves: d a_L, dW_L from the rings       P5 d a_L -> LDS -> dy, BatchNorm sums
-// dW_L lives in the GEMM waves' registers for the whole launch: (column batch, 16-row tile) pairs are dealt round-robin to the four
-// waves, MAXP pairs each; the host takes this kernel when the cell's pairs fit (else the one-role head + k_bwd_xty_w).
+// dZ never leaves the LDS ring (no 8 R bytes per sample written and read back, no k_bwd_xty_w launch for the last layer), dW_L lives in
+// the GEMM waves' registers for the whole launch ((column batch, 16-row tile) pairs dealt round-robin to the four waves, MAXP each), and
+// neither role carries the other's registers (the one-role head spilled 52-85 dwords at 256 VGPRs).
+// A tile goes  P1 a_L -> LDS | per column batch: P2 exp(W_L a_L) -> ring, P3 dZ in place, P4 d a_L and dW_L from the ring | P5 dy, sums:
+// P2 / P4 belong to the GEMM waves, P1 / P3 / P5 to the tile's bijector wave.  f64 MFMA and VALU work serialise on a SIMD whichever wave
+// issues them (profiles/r04_mfma_valu_overlap.txt), but a role alone leaves every memory latency open (first form of this kernel, the
+// roles taking turns: 551 us per C5 cell, the GEMM role's L2-fed phases at 30 % of their MFMA time), so the two tile PAIRS {0,1} and
+// {2,3} run one slot apart: in every slot the GEMM waves serve one pair while the other pair's bijector waves work, one workgroup barrier
+// per slot.  Pair schedule, period 2 C + 2 slots for C column batches (G = GEMM waves, B = the pair's bijector waves):
+//     G: P2(0) | B: P3(0) | G: P4(0), P2(1) | B: P3(1) | ... | G: P4(C-1), d a_L -> LDS | B: P5, P1 of the next tile
+// The host takes this kernel when the cell's pairs fit the accumulators and the LDS (else the one-role head + k_bwd_xty_w).
+#ifndef H2_NPAIR
+#define H2_NPAIR 1        // tile groups one slot apart: 2 = the pairs {0,1}, {2,3} (bijector and GEMM waves overlap, a fragment feeds 2 MFMAs); 1 = all four
+#endif                    //   tiles in step (the roles take turns, a fragment feeds 4 MFMAs).  Measured: profiles/r04_head2_ab.txt
 constexpr int TPB2 = 512;
-constexpr int MAXP = WM == 16 ? 8 : WM == 32 ? 6 : 3;     // pairs per GEMM wave: MAXP * JT accumulator tiles = 64 / 96 / 96 VGPRs
-constexpr int DAW = 4 / (JT < 4 ? JT : 4);                // d a_L: a GEMM wave owns feature tile g % JT of DAW sample tiles (JT = 4: every wave all four... one tile column)
+constexpr int NPAIR = H2_NPAIR, TG = NW / NPAIR;          // groups, tiles per group
+constexpr int MAXP = WM == 16 ? 8 : WM == 32 ? 5 : 3;     // pairs per GEMM wave: MAXP * JT accumulator tiles = 64 / 80 / 96 VGPRs
 
 struct Head2 {
   int ncb, ncbat, rows_cb, ntile_cb;            // columns per batch, batches, ncb * out, 16-row tiles of a batch's image
@@ -589,9 +595,29 @@ __device__ __forceinline__ int head2_row(const CellK& c, const Head2& h, int cb,
   return r < c.R ? r : -1;
 }
 
+// Timing-only instrumentation (-DH2_STAMPS, never in the shipped library): wave 0 of each role in workgroup 0 accumulates the 100 MHz
+// clock per activity and prints the sums at the end (tools/h2_stamps.sh).
+#ifdef H2_STAMPS
+#define H2_T0() unsigned long long h2t = __builtin_amdgcn_s_memrealtime(), h2acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define H2_T(k)                                                        \
+  do {                                                                 \
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();   \
+    h2acc[k] += now - h2t;                                             \
+    h2t = now;                                                         \
+  } while (0)
+#define H2_PRINT(role, id)                                                                                                              \
+  if (blockIdx.x == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0 && (id) == 0)                                                        \
+  printf("h2 %s: %llu %llu %llu %llu %llu %llu %llu %llu (x10 ns)\n", role, h2acc[0], h2acc[1], h2acc[2], h2acc[3], h2acc[4], h2acc[5], \
+         h2acc[6], h2acc[7])
+#else
+#define H2_T0()
+#define H2_T(k)
+#define H2_PRINT(role, id)
+#endif
+
 // LDS of the two-role head
 struct Head2Lds {
-  double* rings;           // NW rings of ring_rows x TS: exp(Z) of the current column batch, then dZ in place
+  double* rings;           // NW rings of ring_rows x TS: exp(Z) of the tile's current column batch, then dZ in place
   double* aLt;             // NW a_L tiles, WM x TS
   double* daT;             // NW d a_L tiles, WM x TS
   double* xhT;             // NW xhat_L tiles, WM x TS (parked by the bijector wave over its column batches: 2 KQ registers less in the bijector phase)
@@ -599,10 +625,18 @@ struct Head2Lds {
   const int* lds_plane;
   const double* etab;
   double (*sm)[SREC];
+  unsigned* gcnt;          // arrival counter of the GEMM waves' own barrier
   int ring_rows;
 };
 
-// ---- role 1: bijector wave `wave` (0 .. NW-1).  Barrier sequence per tile set: B1 | per batch: B2 B3 [B5] | B4  -- the same as role 2's.
+// slots of one launch: `iters` tile sets per workgroup, period 2 C + 2, the second pair one slot behind
+__device__ __forceinline__ long head2_iters(long N) {
+  const long per = (long)gridDim.x * NW * 16;
+  const long first = (long)blockIdx.x * NW * 16;
+  return first < N ? (N - first + per - 1) / per : 0;
+}
+
+// ---- role 1: bijector wave `wave` (0 .. NW-1) of pair wave >> 1
 template <int KIND, int KM, bool KEXACT>
 __device__ __forceinline__ void head2_bijector(const BwdK& k, const BwdW& w, const Head2& h, const Head2Lds& m, int wave) {
   const CellK& c = k.c;
@@ -612,16 +646,24 @@ __device__ __forceinline__ void head2_bijector(const BwdK& k, const BwdW& w, con
   const double* bnL = m.lds_bn + (size_t)L * 4 * WM;
   double* const at = m.aLt + (size_t)wave * WM * TS;
   double* const xt = m.xhT + (size_t)wave * WM * TS;
-  const double* const dt = m.daT + (size_t)wave * WM * TS;
+  double* const dt = m.daT + (size_t)wave * WM * TS;
   const long wstride = (long)gridDim.x * NW * 16;
-  for (long base0 = (long)blockIdx.x * NW * 16; base0 < N; base0 += wstride) {       // (uniform trip count: every wave meets every barrier)
-    // ---------------- P1: hidden stack -> a_L, xhat_L tiles in LDS (this lane's entries: feature 4 q + gq, sample s)
-    const long i = base0 + 16 * wave + s;
-    const bool iv = i < N;
+  const long iters = head2_iters(N);
+  const int C = h.ncbat, period = 2 * C + 2, pair = wave / TG;
+  const long T_total = iters * period + (NPAIR - 1);
+  // per-tile state, set by P1
+  long i = 0;
+  bool iv = false;
+  double gJ = 0.0, Jout = 1.0, jfprod = 1.0;
+  // P1: hidden stack -> a_L, xhat_L tiles in LDS (this lane's entries: feature 16 jt + gq + 4 r, sample s); d a_L tile zeroed
+  auto P1 = [&](long it) {
+    const long base = (long)blockIdx.x * NW * 16 + it * wstride + 16 * wave;
+    i = base + s;
+    iv = i < N;
     {
       double H[KQ][ST], XH[KQ][ST];
       nis_d4 acc[JT][ST];
-      bww_forward(c, k.x, ld, N, base0 + 16 * wave, m.lds_plane, m.lds_bn, w.wm_all, L, H, XH, acc);
+      bww_forward(c, k.x, ld, N, base, m.lds_plane, m.lds_bn, w.wm_all, L, H, XH, acc);
 #pragma unroll
       for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
@@ -631,145 +673,142 @@ __device__ __forceinline__ void head2_bijector(const BwdK& k, const BwdW& w, con
           const double v = acc[jt][0][r];
           xt[j * TS + s] = (v - mu) * rs;
           at[j * TS + s] = fmax(fma(v, sc, sh), 0.0);            // a_L
+          dt[j * TS + s] = 0.0;                                  // the GEMM waves accumulate d a_L here over the column batches
         }
     }
-    const double gJ = iv ? k.g[(size_t)c.jplane * ld + i] : 0.0;
-    const double Jout = iv ? k.xo[(size_t)c.jplane * ld + i] : 1.0;
-    double jfprod = 1.0;
-    __syncthreads();                                             // B1
-    for (int cb = 0; cb < h.ncbat; ++cb) {
-      // the inputs of this batch's column are requested before the wait for the GEMM waves' exponentials
-      const int t = cb * h.ncb + gq;
-      const bool valid = gq < h.ncb && t < c.T && iv;
-      const int tc = min(t, c.T - 1);
-      const size_t colp = (size_t)m.lds_plane[c.P + tc] * ld;
-      const double xraw = valid ? k.x[colp + i] : 0.5;
-      const double gy = valid ? k.g[colp + i] : 0.0;
-      const double gJv = valid ? gJ : 0.0;
-      __syncthreads();                                           // B2: the rings hold exp(Z) of batch cb
-      // ---------------- P3: (sample s, column slot gq) per lane; dZ replaces the exponentials in the ring
-      if (gq < h.ncb) {
-        double* const zw = m.rings + (size_t)wave * m.ring_rows * TS + (size_t)gq * out * TS + s;
-        const double* const zr = zw;
-        double gx = 0.0, jf = 1.0;
-        if (KIND == NIS_PWQUAD) {
-          const bool clamped = xraw > 1.0 - 1e-6;
-          const double xb = clamped ? 1.0 - 1e-6 : xraw;
-          double V[KM + 1], W[KM];
+    gJ = iv ? k.g[(size_t)c.jplane * ld + i] : 0.0;
+    Jout = iv ? k.xo[(size_t)c.jplane * ld + i] : 1.0;
+    jfprod = 1.0;
+  };
+  // P3: (sample s, column slot gq) per lane; dZ replaces the exponentials in the ring
+  auto P3 = [&](int cb) {
+    const int t = cb * h.ncb + gq;
+    const bool valid = gq < h.ncb && t < c.T && iv;
+    const int tc = min(t, c.T - 1);
+    const size_t colp = (size_t)m.lds_plane[c.P + tc] * ld;
+    const double xraw = valid ? k.x[colp + i] : 0.5;
+    const double gy = valid ? k.g[colp + i] : 0.0;
+    const double gJv = valid ? gJ : 0.0;
+    if (gq < h.ncb) {
+    double* const zw = m.rings + (size_t)wave * m.ring_rows * TS + (size_t)gq * out * TS + s;
+    const double* const zr = zw;
+    double gx = 0.0, jf = 1.0;
+    if (KIND == NIS_PWQUAD) {
+      const bool clamped = xraw > 1.0 - 1e-6;
+      const double xb = clamped ? 1.0 - 1e-6 : xraw;
+      double V[KM + 1], W[KM];
 #pragma unroll
-          for (int q = 0; q < KM + 1; ++q) V[q] = (KEXACT || q <= K) ? (valid ? zr[q * TS] : 1.0) : 0.0;
+      for (int q = 0; q < KM + 1; ++q) V[q] = (KEXACT || q <= K) ? (valid ? zr[q * TS] : 1.0) : 0.0;
 #pragma unroll
-          for (int q = 0; q < KM; ++q) W[q] = (KEXACT || q < K) ? (valid ? zr[(K + 1 + q) * TS] : 1.0) : 0.0;
-          double wn = 0.0;
+      for (int q = 0; q < KM; ++q) W[q] = (KEXACT || q < K) ? (valid ? zr[(K + 1 + q) * TS] : 1.0) : 0.0;
+      double wn = 0.0;
 #pragma unroll
-          for (int q = 0; q < KM; ++q)
-            if (q < K) wn += W[q];
-          int b;
-          double left;
-          pwquad_bin<KM, false>(xb, K, W, wn, &b, &left);
-          const double iwn = 1.0 / wn;
-          double area = 0.0;
+      for (int q = 0; q < KM; ++q)
+        if (q < K) wn += W[q];
+      int b;
+      double left;
+      pwquad_bin<KM, false>(xb, K, W, wn, &b, &left);
+      const double iwn = 1.0 / wn;
+      double area = 0.0;
 #pragma unroll
-          for (int q = 0; q < KM; ++q)
-            if (q < K) {
-              W[q] = W[q] * iwn;
-              area += (V[q] + V[q + 1]) / 2 * W[q];
-            }
-          const double iarea = 1.0 / area;
+      for (int q = 0; q < KM; ++q)
+        if (q < K) {
+          W[q] = W[q] * iwn;
+          area += (V[q] + V[q + 1]) / 2 * W[q];
+        }
+      const double iarea = 1.0 / area;
 #pragma unroll
-          for (int q = 0; q < KM + 1; ++q)
-            if (q <= K) V[q] = V[q] * iarea;
-          const double Wb = valid ? zr[(K + 1 + b) * TS] * iwn : 1.0;
-          const double Vb = valid ? zr[b * TS] * iarea : 1.0, Vb1 = valid ? zr[(b + 1) * TS] * iarea : 1.0;
-          const double alpha = (xb - left) / Wb;
-          const double D = Vb1 - Vb;
-          jf = lerp_torch(Vb, Vb1, alpha);
-          const double gjf = gJv * Jout / jf;                  // J_out = J_in prod_t jf_t
-          const double galpha = gy * jf * Wb + gjf * D;
-          gx = clamped ? 0.0 : galpha / Wb;
-          const double gleft = -galpha / Wb;
-          // gradients w.r.t. the normalised heights / widths are sparse in q: re-formed on the fly in each pass (see k_bwd_head_w)
-          const double hgy = gy / 2;
-          const double A0 = gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha);
-          const double A1 = gy * alpha * alpha / 2 * Wb + gjf * alpha;
-          const double B0 = gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb;
+      for (int q = 0; q < KM + 1; ++q)
+        if (q <= K) V[q] = V[q] * iarea;
+      const double Wb = valid ? zr[(K + 1 + b) * TS] * iwn : 1.0;
+      const double Vb = valid ? zr[b * TS] * iarea : 1.0, Vb1 = valid ? zr[(b + 1) * TS] * iarea : 1.0;
+      const double alpha = (xb - left) / Wb;
+      const double D = Vb1 - Vb;
+      jf = lerp_torch(Vb, Vb1, alpha);
+      const double gjf = gJv * Jout / jf;                  // J_out = J_in prod_t jf_t
+      const double galpha = gy * jf * Wb + gjf * D;
+      gx = clamped ? 0.0 : galpha / Wb;
+      const double gleft = -galpha / Wb;
+      // gradients w.r.t. the normalised heights / widths are sparse in q: re-formed on the fly in each pass (see k_bwd_head_w)
+      const double hgy = gy / 2;
+      const double A0 = gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha);
+      const double A1 = gy * alpha * alpha / 2 * Wb + gjf * alpha;
+      const double B0 = gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb;
 #define NIS_GV(q, wm1, wq) (((q) >= 1 && (q) - 1 < b ? hgy * (wm1) : 0.0) + ((q) < b ? hgy * (wq) : 0.0) + ((q) == b ? A0 : 0.0) + ((q) == b + 1 ? A1 : 0.0))
 #define NIS_GW0(q) (((q) < b ? hgy * (V[q] + V[(q) + 1]) + gleft : 0.0) + ((q) == b ? B0 : 0.0))
-          double S = 0.0;
+      double S = 0.0;
 #pragma unroll
-          for (int q = 0; q < KM + 1; ++q)
-            if (KEXACT || q <= K) {
-              const double wm1 = q >= 1 ? W[q >= 1 ? q - 1 : 0] : 0.0;
-              const double wq = (q < KM && (KEXACT || q < K)) ? W[q < KM ? q : 0] : 0.0;
-              S += NIS_GV(q, wm1, wq) * V[q];
-            }
-          double Sw = 0.0;
+      for (int q = 0; q < KM + 1; ++q)
+        if (KEXACT || q <= K) {
+          const double wm1 = q >= 1 ? W[q >= 1 ? q - 1 : 0] : 0.0;
+          const double wq = (q < KM && (KEXACT || q < K)) ? W[q < KM ? q : 0] : 0.0;
+          S += NIS_GV(q, wm1, wq) * V[q];
+        }
+      double Sw = 0.0;
 #pragma unroll
-          for (int q = 0; q < KM; ++q)
-            if (KEXACT || q < K) Sw += (NIS_GW0(q) - S * (V[q] + V[q + 1]) / 2) * W[q];
-          double wprev = 0.0;
+      for (int q = 0; q < KM; ++q)
+        if (KEXACT || q < K) Sw += (NIS_GW0(q) - S * (V[q] + V[q + 1]) / 2) * W[q];
+      double wprev = 0.0;
 #pragma unroll
-          for (int q = 0; q < KM + 1; ++q)
-            if (KEXACT || q <= K) {                          // wave-uniform
-              const bool hasw = q < KM && (KEXACT || q < K);
-              const double wq = hasw ? W[q < KM ? q : 0] : 0.0;
-              const double vq = V[q];
-              const double dzv = NIS_GV(q, wprev, wq) * vq - S * vq * (wprev + wq) / 2;
-              if (hasw) {
-                const double dzw = wq * (NIS_GW0(q) - S * (vq + V[q + 1]) / 2 - Sw);
-                zw[(K + 1 + q) * TS] = valid ? dzw : 0.0;
-              }
-              zw[q * TS] = valid ? dzv : 0.0;
-              wprev = wq;
-            }
+      for (int q = 0; q < KM + 1; ++q)
+        if (KEXACT || q <= K) {                          // wave-uniform
+          const bool hasw = q < KM && (KEXACT || q < K);
+          const double wq = hasw ? W[q < KM ? q : 0] : 0.0;
+          const double vq = V[q];
+          const double dzv = NIS_GV(q, wprev, wq) * vq - S * vq * (wprev + wq) / 2;
+          if (hasw) {
+            const double dzw = wq * (NIS_GW0(q) - S * (vq + V[q + 1]) / 2 - Sw);
+            zw[(K + 1 + q) * TS] = valid ? dzw : 0.0;
+          }
+          zw[q * TS] = valid ? dzv : 0.0;
+          wprev = wq;
+        }
 #undef NIS_GV
 #undef NIS_GW0
-        } else if (KIND == NIS_AFFINE) {
-          const double s0 = 20.0 * (valid ? zr[0] : 1.0), z1 = valid ? zr[TS] : 0.0;
-          const double u = xraw * s0 + (z1 > 0.0 ? z1 : 0.0);
-          const double q = 1.0 / (u * u + 1.0);
-          jf = s0 * q;
-          const double gjf = gJv * Jout / jf;
-          const double gu = gy * (q / (M_PI / 2)) - gjf * (2.0 * u * s0 * q * q);
-          gx = gu * s0;
-          zw[0] = valid ? (gu * xraw + gjf * q) * s0 : 0.0;
-          zw[TS] = (valid && z1 > 0.0) ? gu : 0.0;
-        } else {
-          // PWLin: Q_q = K e_q / tot, y = Q_b alpha + sum_{q<b} e_q / tot, jf = Q_b
-          const double ak = xraw * K;
-          const double bf = floor(ak);
-          const double alpha = (ak - bf) / K;
-          const int b = (int)bf;
-          double tot = 0.0, below = 0.0, eb = 0.0;
-          for (int q = 0; q < K; ++q) {
-            const double e = valid ? zr[q * TS] : 1.0;
-            const bool hit = q == b;
-            below = hit ? tot : below;
-            eb = hit ? e : eb;
-            tot += e;
-          }
-          const double Qb = eb / (tot / K);
-          const double Qs = below / tot;
-          jf = Qb;
-          const double gjf = gJv * Jout / jf;
-          const double gQb = gy * alpha + gjf, gQs = gy;
-          gx = gy * Qb;
-          for (int q = 0; q < K; ++q) {
-            const double pq = (valid ? zr[q * TS] : 1.0) / tot;
-            const double dz = gQb * ((q == b ? Qb : 0.0) - Qb * pq) + gQs * ((q < b ? pq : 0.0) - Qs * pq);
-            zw[q * TS] = valid ? dz : 0.0;
-          }
-        }
-        if (valid) {
-          k.g[colp + i] = gx;
-          jfprod *= jf;
-        }
+    } else if (KIND == NIS_AFFINE) {
+      const double s0 = 20.0 * (valid ? zr[0] : 1.0), z1 = valid ? zr[TS] : 0.0;
+      const double u = xraw * s0 + (z1 > 0.0 ? z1 : 0.0);
+      const double q = 1.0 / (u * u + 1.0);
+      jf = s0 * q;
+      const double gjf = gJv * Jout / jf;
+      const double gu = gy * (q / (M_PI / 2)) - gjf * (2.0 * u * s0 * q * q);
+      gx = gu * s0;
+      zw[0] = valid ? (gu * xraw + gjf * q) * s0 : 0.0;
+      zw[TS] = (valid && z1 > 0.0) ? gu : 0.0;
+    } else {
+      // PWLin: Q_q = K e_q / tot, y = Q_b alpha + sum_{q<b} e_q / tot, jf = Q_b
+      const double ak = xraw * K;
+      const double bf = floor(ak);
+      const double alpha = (ak - bf) / K;
+      const int b = (int)bf;
+      double tot = 0.0, below = 0.0, eb = 0.0;
+      for (int q = 0; q < K; ++q) {
+        const double e = valid ? zr[q * TS] : 1.0;
+        const bool hit = q == b;
+        below = hit ? tot : below;
+        eb = hit ? e : eb;
+        tot += e;
       }
-      __syncthreads();                                           // B3: the rings hold dZ of batch cb
-      if (cb + 1 < h.ncbat) __syncthreads();                     // B5: the GEMM waves are done with them
+      const double Qb = eb / (tot / K);
+      const double Qs = below / tot;
+      jf = Qb;
+      const double gjf = gJv * Jout / jf;
+      const double gQb = gy * alpha + gjf, gQs = gy;
+      gx = gy * Qb;
+      for (int q = 0; q < K; ++q) {
+        const double pq = (valid ? zr[q * TS] : 1.0) / tot;
+        const double dz = gQb * ((q == b ? Qb : 0.0) - Qb * pq) + gQs * ((q < b ? pq : 0.0) - Qs * pq);
+        zw[q * TS] = valid ? dz : 0.0;
+      }
     }
-    __syncthreads();                                             // B4: d a_L tiles are in LDS
-    // ---------------- P5: through ReLU to BN_L's output; sums of BN_L
+      if (valid) {
+        k.g[colp + i] = gx;
+        jfprod *= jf;
+      }
+    }
+  };
+  // P5: through ReLU to BN_L's output; sums of BN_L
+  auto P5 = [&]() {
     jfprod *= __shfl_xor(jfprod, 16, 64);
     jfprod *= __shfl_xor(jfprod, 32, 64);
     if (KIND == NIS_AFFINE) jfprod *= 1.0 / (M_PI / 2);
@@ -790,11 +829,43 @@ __device__ __forceinline__ void head2_bijector(const BwdK& k, const BwdW& w, con
         m.sm[wave][WM + j] += t2;
       }
     }
-    // (the next P1 overwrites the a_L tile: the GEMM waves passed their last use of it before B4)
+  };
+  H2_T0();
+  if (iters > 0) P1(0);
+  __syncthreads();
+  H2_T(0);
+  for (long t = 0; t < T_total; ++t) {
+    const long st = t - pair;
+    if (st >= 0 && st < iters * period && (st & 1)) {            // this pair's bijector slot
+      const long it = st / period;
+      const int kk = (int)((st - it * period) - 1) / 2;
+      if (kk < C) {
+        P3(kk);
+        H2_T(1);
+      } else {
+        P5();
+        H2_T(2);
+        if (it + 1 < iters) P1(it + 1);
+        H2_T(0);
+      }
+    }
+    __syncthreads();
+    H2_T(3);
   }
+  H2_PRINT("bijector P1 | P3 | P5 | barrier", wave);
 }
 
-// ---- role 2: GEMM wave gw (0 .. NW-1), all four tiles of the workgroup
+// barrier of the four GEMM waves only (between their reads of a pair's rings in P4 and the overwrite in P2 of the same slot): arrival
+// counter in LDS, bounded by the workgroup barriers around every slot (all four waves run the same slot sequence)
+__device__ __forceinline__ void head2_gemm_barrier(unsigned* cnt, unsigned& epoch) {
+  epoch += NW;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---- role 2: GEMM wave gw (0 .. NW-1); per slot the two tiles 2 p, 2 p + 1 of one pair
 template <int KIND>
 __device__ __forceinline__ void head2_gemm(const BwdK& k, const BwdW& w, const Head2& h, const Head2Lds& m, int gw) {
   const CellK& c = k.c;
@@ -810,86 +881,150 @@ __device__ __forceinline__ void head2_gemm(const BwdK& k, const BwdW& w, const H
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) dW[pi][jt] = nis_d4{0.0, 0.0, 0.0, 0.0};
   }
-  const int djt = gw % JT;                                       // d a_L: feature tile djt of the sample tiles gw / JT + (NW / DAW) u
-  const long wstride = (long)gridDim.x * NW * 16;
-  for (long base0 = (long)blockIdx.x * NW * 16; base0 < N; base0 += wstride) {
-    nis_d4 da[DAW];
-#pragma unroll
-    for (int u = 0; u < DAW; ++u) da[u] = nis_d4{0.0, 0.0, 0.0, 0.0};
-    __syncthreads();                                             // B1: the a_L tiles are in LDS
-    for (int cb = 0; cb < h.ncbat; ++cb) {
-      const int r0 = cb * h.rows_cb;
-      const int r1 = min(c.R, r0 + h.rows_cb);
-      // ---------------- P2: exp(W_L a_L + b) of this batch's rows into the four rings; a weight fragment feeds four MFMAs
-      for (int jt = r0 / 16 + gw; jt * 16 < r1; jt += NW) {
-        double fa[KQ];
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) fa[q] = w.wm_last[((size_t)jt * KQ + q) * 64 + lane];
-        nis_d4 z[NW];
-#pragma unroll
-        for (int wv = 0; wv < NW; ++wv)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) z[wv][r] = w.bias_pad[16 * jt + gq + 4 * r];
-#pragma unroll
-        for (int q = 0; q < KQ; ++q)
-#pragma unroll
-          for (int wv = 0; wv < NW; ++wv)                        // B operand: a_L[feature 4 q + gq][sample s] of tile wv, as it was stored
-            z[wv] = mfma(fa[q], m.aLt[(size_t)wv * WM * TS + (4 * q + gq) * TS + s], z[wv]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = 16 * jt + gq + 4 * r - r0;
-          if (j >= 0 && j < h.rows_cb && 16 * jt + gq + 4 * r < c.R) {
-#pragma unroll
-            for (int wv = 0; wv < NW; ++wv)
-              m.rings[(size_t)wv * ring_rows * TS + j * TS + s] = (KIND == NIS_AFFINE && (j & 1)) ? z[wv][r] : nis_exp(z[wv][r], m.etab);
-          }
-        }
-      }
-      __syncthreads();                                           // B2
-      __syncthreads();                                           // B3: the rings hold dZ
-      // ---------------- P4: d a_L += W_L^T dZ (k index = ring rows), dW_L += dZ a_L^T (k index = samples), row sums
-      {
+  const long iters = head2_iters(N);
+  const int C = h.ncbat, period = 2 * C + 2;
+  const long T_total = iters * period + (NPAIR - 1);
+  unsigned epoch = 0;
+  // d a_L: this wave owns feature tile djt of the tiles dtile + (NW / JT) v of the served group (v < DAT; none when dtile >= TG)
+  const int djt = gw % JT, dtile = gw / JT;
+  constexpr int DAT = (JT * TG + NW - 1) / NW;
+  const bool da_owner = dtile < TG;
+  constexpr int NKMAX = 36;                                      // k-steps of a column batch whose operands are requested at once (rows_cb <= 144)
+  H2_T0();
+  __syncthreads();                                               // (the bijector waves' first P1)
+  for (long t = 0; t < T_total; ++t) {
+    const int pr = (int)(t & (NPAIR - 1));                       // group served in this slot (the groups' GEMM slots are the even ones of their own clocks)
+    const long st = t - pr;
+    if (st < iters * period && !(st & 1)) {
+      const long it = st / period;
+      const int kk = (int)(st - it * period) / 2;                // 0 .. C
+      const int t0 = TG * pr;                                    // first tile of the group
+      (void)it;
+      if (kk >= 1) {
+        // ---------------- P4 of column batch kk - 1: d a_L += W_L^T dZ (k index = ring rows), dW_L += dZ a_L^T (k index = samples)
+        const int cb = kk - 1;
         const int nk = (h.rows_cb + 3) / 4;
-        for (int kq = 0; kq < nk; ++kq) {
-          const int row = head2_row<KIND>(c, h, cb, 4 * kq + gq);
-          const double af = row >= 0 ? c.wlast[(size_t)row * WM + 16 * djt + s] : 0.0;
+        // the A operands W_L[row 4 kq + gq][16 djt + s] of d a_L come from the row-major blob (L2): ALL of the batch's k-steps are
+        // requested first, the LDS-fed dW_L products run while they are in flight
+        double aop[NKMAX];
+#ifndef H2_SKIP_DA
+        if (da_owner) {
 #pragma unroll
-          for (int u = 0; u < DAW; ++u) {
-            const int wv = gw / JT + (NW / DAW) * u;
-            da[u] = mfma(af, m.rings[(size_t)wv * ring_rows * TS + (4 * kq + gq) * TS + s], da[u]);
+          for (int kq = 0; kq < NKMAX; ++kq) {
+            const int row = kq < nk ? head2_row<KIND>(c, h, cb, 4 * kq + gq) : -1;
+            aop[kq] = row >= 0 ? c.wlast[(size_t)row * WM + 16 * djt + s] : 0.0;
           }
         }
-      }
+#endif
+#ifndef H2_SKIP_DW
 #pragma unroll
-      for (int pi = 0; pi < MAXP; ++pi) {
-        const int p = gw + NW * pi;
-        if (p / h.ntile_cb == cb) {                              // (wave-uniform)
-          const int rt = p - cb * h.ntile_cb;
+        for (int pi = 0; pi < MAXP; ++pi) {
+          const int p = gw + NW * pi;
+          if (p / h.ntile_cb == cb) {                            // (wave-uniform)
+            const int rt = p - cb * h.ntile_cb;
 #pragma unroll
-          for (int wv = 0; wv < NW; ++wv) {
-            const double* ring = m.rings + (size_t)wv * ring_rows * TS + (size_t)(16 * rt + s) * TS + gq;
-            const double* at = m.aLt + (size_t)wv * WM * TS + (size_t)s * TS + gq;
+            for (int u = 0; u < TG; ++u) {
+              const int wv = t0 + u;
+              const double* ring = m.rings + (size_t)wv * ring_rows * TS + (size_t)(16 * rt + s) * TS + gq;
+              const double* at = m.aLt + (size_t)wv * WM * TS + (size_t)s * TS + gq;
 #pragma unroll
-            for (int mm = 0; mm < 4; ++mm) {
-              const double af = ring[4 * mm];                    // dZ[row 16 rt + s][sample 4 mm + gq]
-              rsum[pi] += af;
+              for (int mm = 0; mm < 4; ++mm) {
+                const double af = ring[4 * mm];                  // dZ[row 16 rt + s][sample 4 mm + gq]
+                rsum[pi] += af;
 #pragma unroll
-              for (int jt = 0; jt < JT; ++jt) dW[pi][jt] = mfma(af, at[(size_t)16 * jt * TS + 4 * mm], dW[pi][jt]);
+                for (int jt = 0; jt < JT; ++jt) dW[pi][jt] = mfma(af, at[(size_t)16 * jt * TS + 4 * mm], dW[pi][jt]);
+              }
             }
           }
         }
+#endif
+        H2_T(1);
+#ifndef H2_SKIP_DA
+        if (da_owner) {
+          nis_d4 da[DAT];
+#pragma unroll
+          for (int v = 0; v < DAT; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)                           // this wave is the only writer of its (feature tile, sample tile)s
+              da[v][r] = m.daT[(size_t)(t0 + dtile + (NW / JT) * v) * WM * TS + (size_t)(16 * djt + gq + 4 * r) * TS + s];
+#pragma unroll
+          for (int kq = 0; kq < NKMAX; ++kq)
+            if (kq < nk) {
+#pragma unroll
+              for (int v = 0; v < DAT; ++v)
+                da[v] = mfma(aop[kq], m.rings[(size_t)(t0 + dtile + (NW / JT) * v) * ring_rows * TS + (size_t)(4 * kq + gq) * TS + s], da[v]);
+            }
+#pragma unroll
+          for (int v = 0; v < DAT; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              m.daT[(size_t)(t0 + dtile + (NW / JT) * v) * WM * TS + (size_t)(16 * djt + gq + 4 * r) * TS + s] = da[v][r];
+        }
+#endif
+        H2_T(2);
       }
-      if (cb + 1 < h.ncbat) __syncthreads();                     // B5: the next batch's P2 overwrites the rings
-    }
-    // ---------------- P5: d a_L tiles to LDS
+      __builtin_amdgcn_sched_barrier(0);                         // (the fragment requests below must not be hoisted over P4: its operands hold the registers)
+      if (kk < C) {
+        // ---------------- P2 of column batch kk: exp(W_L a_L + b) of its rows into the pair's two rings
+        const int cb = kk;
+        const int r0 = cb * h.rows_cb;
+        const int r1 = min(c.R, r0 + h.rows_cb);
+        // this wave's row tiles: jt = r0 / 16 + ((gw + cb) & 3) + 4 n (the odd tile rotates with the batch); the next tile's fragments and
+        // bias are in flight while the current one is multiplied, the B operands a_L[feature 4 q + gq][sample s] (as stored) are read in one go
+        int jt = r0 / 16 + ((gw + cb) & (NW - 1));
+        double fa[KQ];
+        nis_d4 zb;
+#ifndef H2_SKIP_P2
+        if (jt * 16 < r1) {
 #pragma unroll
-    for (int u = 0; u < DAW; ++u) {
-      const int wv = gw / JT + (NW / DAW) * u;
+          for (int q = 0; q < KQ; ++q) fa[q] = w.wm_last[((size_t)jt * KQ + q) * 64 + lane];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) m.daT[(size_t)wv * WM * TS + (16 * djt + gq + 4 * r) * TS + s] = da[u][r];
+          for (int r = 0; r < 4; ++r) zb[r] = w.bias_pad[16 * jt + gq + 4 * r];
+        }
+#endif
+        if (kk >= 1) head2_gemm_barrier(m.gcnt, epoch);          // every GEMM wave has finished reading this group's rings
+#ifndef H2_SKIP_P2
+        for (; jt * 16 < r1; jt += NW) {
+          const int jn = (jt + NW) * 16 < r1 ? jt + NW : jt;     // (last tile: re-requests itself, unused)
+          double fb[KQ];
+          nis_d4 zn;
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) fb[q] = w.wm_last[((size_t)jn * KQ + q) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zn[r] = w.bias_pad[16 * jn + gq + 4 * r];
+          double aLf[TG][KQ];
+#pragma unroll
+          for (int u = 0; u < TG; ++u)
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) aLf[u][q] = m.aLt[(size_t)(t0 + u) * WM * TS + (4 * q + gq) * TS + s];
+          nis_d4 z[TG];
+#pragma unroll
+          for (int u = 0; u < TG; ++u) z[u] = zb;
+#pragma unroll
+          for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int u = 0; u < TG; ++u) z[u] = mfma(fa[q], aLf[u][q], z[u]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + gq + 4 * r - r0;
+            if (j >= 0 && j < h.rows_cb && 16 * jt + gq + 4 * r < c.R) {
+#pragma unroll
+              for (int u = 0; u < TG; ++u)
+                m.rings[(size_t)(t0 + u) * ring_rows * TS + j * TS + s] = (KIND == NIS_AFFINE && (j & 1)) ? z[u][r] : nis_exp(z[u][r], m.etab);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) fa[q] = fb[q];
+          zb = zn;
+        }
+#endif
+        H2_T(4);
+      }
     }
-    __syncthreads();                                             // B4
+    __syncthreads();
+    H2_T(5);
   }
+  H2_PRINT("gemm - | dW | d a | - | P2 | barrier", gw);
   // dW_L / db_L records of this workgroup in the GEMM's layout: [row group][workgroup][RPW * 16 rows x (WM products | row sum)]
 #pragma unroll
   for (int pi = 0; pi < MAXP; ++pi) {
@@ -922,11 +1057,13 @@ __global__ __launch_bounds__(TPB2, 1) void k_bwd_head2_w(BwdK k, BwdW w, Head2 h
   __shared__ int lds_plane[NIS_MAX_DIM];
   __shared__ double etab[NIS_EXP_N];
   __shared__ double sm[NW][SREC];
+  __shared__ unsigned gcnt;
   if (BATCH) bww_batch(k, &w);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   bww_stage(k, lds_bn, lds_plane);
   nis_exp_init(etab);
+  if (tid == 0) gcnt = 0;
   Head2Lds m;
   m.ring_rows = h.ntile_cb * 16;
   m.rings = mf_dyn;
@@ -937,6 +1074,7 @@ __global__ __launch_bounds__(TPB2, 1) void k_bwd_head2_w(BwdK k, BwdW w, Head2 h
   m.lds_plane = lds_plane;
   m.etab = etab;
   m.sm = sm;
+  m.gcnt = &gcnt;
   // rows of a ring past the batch's own (rows_cb .. ring_rows) are read by the GEMMs and written by nobody: zero, once
   const int npad = (m.ring_rows - h.rows_cb) * TS;
   for (int e = tid; e < NW * npad; e += TPB2) m.rings[(size_t)(e / npad) * m.ring_rows * TS + (size_t)h.rows_cb * TS + e % npad] = 0.0;
@@ -1326,7 +1464,8 @@ Head2Plan head2_plan(int kind, int K, int T, int out, int R) {
     h.ntile_cb = (h.rows_cb + 15) / 16;
     h.ngl = groups_of(R);
     const size_t dyn = (size_t)NW * ((size_t)h.ntile_cb * 16 + 3 * WM) * TS * sizeof(double);
-    if (dyn + fixed > 160 * 1024 || h.ncbat * h.ntile_cb > NW * MAXP) continue;
+    // (k_bwd_head2_w requests a batch's d a_L operands at once, NKMAX = 36 k-steps, and holds three row tiles of fragments per GEMM wave)
+    if (dyn + fixed > 160 * 1024 || h.ncbat * h.ntile_cb > NW * MAXP || h.rows_cb > 144 || h.ntile_cb + 1 > 3 * NW) continue;
     hp.ok = true;
     hp.h = h;
     hp.dyn = dyn;

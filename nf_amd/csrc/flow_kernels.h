@@ -807,46 +807,62 @@ __device__ __forceinline__ double lerp_torch(double a, double b, double w) {
 // -- probability ~1e-15 per bin -- the true division decides.  One division yields the selected left edge.
 // Ties (equal Wsum for consecutive bins, i.e. widths that vanish in the cumsum) resolve to the first bin, as argmax does.
 // the search with the reference's own comparison (one division per bin), for the columns the multiplied-out tests cannot decide
+// *amb (per lane): the decision rests on last bits -- an edge quotient within 2^-50 (relative) of x, or, at the end of the kept prefix, a
+// width on the threshold of vanishing in the running sum (2^-55 .. 2^-51 of it; a width below half an ulp, 2^-54 .. 2^-53, leaves the sum unchanged: whether two edges are EQUAL, where the reference's argmax
+// takes the first, then turns on the last bit of exp()).  These are the samples on which the reference's own CPU and GPU builds disagree;
+// everywhere else the selected bin is the reference's, bit for bit.  Surfaced as NIS_STATUS_BIN_AMBIGUOUS / NIS_BIN_AMBIGUOUS_FLAG.
 template <int KM>
-__device__ __forceinline__ void pwquad_bin_divide(double xb, int K, const double (&W)[KM], double wn, int* idx_out, double* run_out) {
+__device__ __forceinline__ void pwquad_bin_divide(double xb, int K, const double (&W)[KM], double wn, int* idx_out, double* run_out, bool* amb) {
   double run = 0.0, bestrun = 0.0;
   int idx = 0;
+  bool near_x = false, zone = false;
 #pragma unroll 1
   for (int k = 0; k < K; ++k) {
     double wk = W[0];
 #pragma unroll
     for (int u = 1; u < KM; ++u) wk = (u == k) ? W[u] : wk;
     run += wk;
-    const bool le = !((run / wn) > xb);                  // the reference's comparison, verbatim
+    const double quot = run / wn;
+    const bool le = !(quot > xb);                        // the reference's comparison, verbatim
     const bool up = le && (run > bestrun);
+    near_x |= k < K - 1 && fabs(quot - xb) <= xb * 0x1p-50;      // (the last edge is 1: a clamped x is 1e-6 below it)
+    const bool z = k > 0 && wk > run * 0x1p-55 && !(wk > run * 0x1p-51);
+    zone = le ? (up ? z : (zone || z)) : zone;
     bestrun = up ? run : bestrun;
     idx = up ? k + 1 : idx;
   }
   *idx_out = idx;
   *run_out = bestrun;
+  *amb = near_x || zone;
 }
 
 template <int KM, bool KEXACT>
-__device__ __forceinline__ void pwquad_bin_raw(double xb, int Krt, const double (&W)[KM], double wn, int* idx_out, double* run_out) {
+__device__ __forceinline__ void pwquad_bin_raw(double xb, int Krt, const double (&W)[KM], double wn, int* idx_out, double* run_out, bool* amb_out = nullptr) {
   const int K = KEXACT ? KM : Krt;
   const double q = xb * wn;
   const double qlo = q * (1.0 - 0x1p-50), qhi = q * (1.0 + 0x1p-50);
   double run = 0.0, bestrun = 0.0;
   int idx = 0;
   bool ambany = false;
+  // a width at or below 2^-50 of the TOTAL (a superset of "of the running sum at its edge") may tie two edges: such columns take the
+  // search with the divisions as well, which also decides whether the sample is flagged ambiguous (one v_min per edge on this path)
+  double wmin = wn;
   // the last edge is wn itself (same additions in the same order as the caller's sum): with x <= 1 - 1e-6 (every caller clamps, :167) it is
   // neither at or below q (1 - 2^-50) nor inside the band, so K - 1 edges are examined
 #pragma unroll
   for (int k = 0; k < KM - 1; ++k)
     if (KEXACT || k < K - 1) {
       run += W[k];
+      if (k > 0) wmin = fmin(wmin, W[k]);
       const bool le = run <= qlo;
       ambany |= (run > qlo) && (run < qhi);
       const bool up = le && (run > bestrun);
       bestrun = up ? run : bestrun;
       idx = up ? k + 1 : idx;
     }
-  if (__any(ambany)) pwquad_bin_divide<KM>(xb, K, W, wn, &idx, &bestrun);      // one wave-uniform test per column; practically never taken
+  ambany |= !(wmin > wn * 0x1p-50);
+  bool amb = false;
+  if (__any(ambany)) pwquad_bin_divide<KM>(xb, K, W, wn, &idx, &bestrun, &amb);      // one wave-uniform test per column; practically never taken
   // Wsum2[idx] = bestrun / wn (:186, :198) must exceed the 1e-30 sentinel, else bin 0 with left edge 0 wins; tested on
   // the raw sum (equivalent unless the quotient is within an ulp of 1e-30)
   const bool none = !(bestrun > 1e-30 * wn);
@@ -855,6 +871,7 @@ __device__ __forceinline__ void pwquad_bin_raw(double xb, int Krt, const double 
   idx = (idx > K - 1) ? K - 1 : idx;
   *idx_out = idx;
   *run_out = bestrun;                                    // raw cumulative width left of the bin
+  if (amb_out) *amb_out = amb;
 }
 
 // same, returning the normalised left edge Wsum2[idx] (used by the adjoint kernels)
@@ -877,7 +894,7 @@ __device__ __forceinline__ void pwquad_bin(double xb, int Krt, const double (&W)
 // bin's three values are read back by index (LDS pipe) instead of 3 K selects on the VALU pipe the kernel is bound by.
 template <int KM, bool KEXACT>
 __device__ __forceinline__ double pwquad_column(double xb, int Krt, const double (&V)[KM + 1], const double (&W)[KM], double* jf, int* bin,
-                                                double* gather = nullptr) {
+                                                double* gather = nullptr, bool* amb = nullptr) {
   const int K = KEXACT ? KM : Krt;
   xb = (xb > 1.0 - 1e-6) ? 1.0 - 1e-6 : xb;                       // :167
   double wn = 0.0;
@@ -894,7 +911,7 @@ __device__ __forceinline__ double pwquad_column(double xb, int Krt, const double
   }
   int idx;
   double run;
-  pwquad_bin_raw<KM, KEXACT>(xb, Krt, W, wn, &idx, &run);
+  pwquad_bin_raw<KM, KEXACT>(xb, Krt, W, wn, &idx, &run, amb);
   double A = 0.0, pre = 0.0, Wb = 1.0, Vb = 0.0, Vb1 = 0.0;
   if (gather) {
 #pragma unroll
@@ -933,31 +950,42 @@ __device__ __forceinline__ double pwquad_column(double xb, int Krt, const double
 // statement (guard band, exact re-test with the reference's division when a lane falls inside it, sentinel, clamp).
 // (ST: element stride of W -- 1 for a scratch array, 16 for a column of the matrix-core adjoint's LDS ring)
 template <int ST = 1>
-__device__ __forceinline__ void pwquad_bin_big(double xb, int K, const double* W, double wn, int* idx_out, double* run_out) {
+__device__ __forceinline__ void pwquad_bin_big(double xb, int K, const double* W, double wn, int* idx_out, double* run_out, bool* amb_out = nullptr) {
   const double q = xb * wn;
   const double qlo = q * (1.0 - 0x1p-50), qhi = q * (1.0 + 0x1p-50);
-  double run = 0.0, bestrun = 0.0;
+  double run = 0.0, bestrun = 0.0, wmin = wn;
   int idx = 0;
   bool ambany = false;
   for (int k = 0; k < K; ++k) {
-    run += W[k * ST];
+    const double wk = W[k * ST];
+    run += wk;
+    wmin = k > 0 ? fmin(wmin, wk) : wmin;
     const bool le = run <= qlo;
     ambany |= (run > qlo) && (run < qhi);
     const bool up = le && (run > bestrun);
     bestrun = up ? run : bestrun;
     idx = up ? k + 1 : idx;
   }
-  if (__any(ambany)) {
+  ambany |= !(wmin > wn * 0x1p-50);                      // a width that may tie two edges (see pwquad_bin_raw)
+  bool amb = false;
+  if (__any(ambany)) {                                   // pwquad_bin_divide, on the strided array
     run = 0.0;
     bestrun = 0.0;
     idx = 0;
+    bool near_x = false, zone = false;
     for (int k = 0; k < K; ++k) {
-      run += W[k * ST];
-      const bool le = !((run / wn) > xb);                // the reference's comparison, verbatim
+      const double wk = W[k * ST];
+      run += wk;
+      const double quot = run / wn;
+      const bool le = !(quot > xb);                      // the reference's comparison, verbatim
       const bool up = le && (run > bestrun);
+      near_x |= k < K - 1 && fabs(quot - xb) <= xb * 0x1p-50;
+      const bool z = k > 0 && wk > run * 0x1p-55 && !(wk > run * 0x1p-51);
+      zone = le ? (up ? z : (zone || z)) : zone;
       bestrun = up ? run : bestrun;
       idx = up ? k + 1 : idx;
     }
+    amb = near_x || zone;
   }
   const bool none = !(bestrun > 1e-30 * wn);
   idx = none ? 0 : idx;
@@ -965,14 +993,15 @@ __device__ __forceinline__ void pwquad_bin_big(double xb, int K, const double* W
   idx = (idx > K - 1) ? K - 1 : idx;
   *idx_out = idx;
   *run_out = bestrun;                                    // raw cumulative width left of the bin
+  if (amb_out) *amb_out = amb;
 }
-__device__ __forceinline__ double pwquad_column_big(double xb, int K, const double* V, const double* W, double* jf, int* bin) {
+__device__ __forceinline__ double pwquad_column_big(double xb, int K, const double* V, const double* W, double* jf, int* bin, bool* amb = nullptr) {
   xb = (xb > 1.0 - 1e-6) ? 1.0 - 1e-6 : xb;                       // :167
   double wn = 0.0;
   for (int k = 0; k < K; ++k) wn += W[k];                         // Wsum[-1]  :180-182
   int idx;
   double bestrun;
-  pwquad_bin_big(xb, K, W, wn, &idx, &bestrun);
+  pwquad_bin_big(xb, K, W, wn, &idx, &bestrun, amb);
   double A = 0.0, pre = 0.0;
   for (int k = 0; k < K; ++k) {
     pre = (k == idx) ? A : pre;                                   // VW[idx] A  :209-211
@@ -993,7 +1022,7 @@ __device__ __forceinline__ double pwquad_column_big(double xb, int K, const doub
 // stream the heights, and V_b, V_{b+1}, W_b are read BY INDEX instead of through K-long select chains.
 // REL: the relative image (nis_common.h, NIS_PACK_REL): rows 0..K-1 = V[k] / V[K], rows K..2K-2 = W[k] / W[K-1], row 2K-1 unused; V[K] = W[K-1] = 1.
 template <int KM, bool KEXACT, int ZS, bool REL = false>
-__device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const double* zr, double* jf, int* bin) {
+__device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const double* zr, double* jf, int* bin, bool* amb_out = nullptr) {
   static_assert(!REL || KEXACT, "the relative image exists for K == KM only");
   const int K = KEXACT ? KM : Krt;
   const int WO = REL ? K : K + 1;                                 // first width row
@@ -1028,8 +1057,10 @@ __device__ __forceinline__ double pwquad_column_lds(double xb, int Krt, const do
     const double wr = (REL && ir == K - 1) ? 1.0 : zr[(WO + (REL && ir == K - 1 ? 0 : ir)) * ZS];
     const double wl = (REL && il == K - 1) ? 1.0 : zr[(WO + (REL && il == K - 1 ? 0 : il)) * ZS];
     const bool amb = idx < K && run + wr < qhi;                    // (run + W[idx] IS the next edge of the loop above, bit for bit)
-    const bool tie = idx > 0 && !(wl > run * 0x1p-52);             // W[idx - 1] may have vanished in the sum: equal edges
-    if (__any(amb || tie)) pwquad_bin_divide<KM>(xb, K, W, wn, &idx, &run);
+    const bool tie = idx > 0 && !(wl > run * 0x1p-50);             // W[idx - 1] may have vanished in the sum (equal edges) or be on the threshold
+    bool flagged = false;
+    if (__any(amb || tie)) pwquad_bin_divide<KM>(xb, K, W, wn, &idx, &run, &flagged);
+    if (amb_out) *amb_out = flagged;
     const bool none = !(run > 1e-30 * wn);                         // :186, :198 (see pwquad_bin_raw)
     idx = none ? 0 : idx;
     run = none ? 0.0 : run;
@@ -1234,12 +1265,13 @@ __global__ __launch_bounds__(NIS_TPB, (SPEC != 0 && KM <= 4) ? NIS_SPEC_WAVES : 
       const int row0 = t * c.out;
       double y, jf;
       int bin;
+      bool amb = false;                                          // PWQuad: the bin decision rests on last bits (pwquad_bin_divide)
       if constexpr (KIND == NIS_PWQUAD && KM > 32) {             // 33 .. NIS_MAX_BINS bins: scratch arrays, runtime loops
         double V[NIS_KM_BIG + 1], W[NIS_KM_BIG];
         const int Kq = c.K;
         for (int k = 0; k <= Kq; ++k) V[k] = nis_exp(last_dot<WM, WX>(wl, bias, row0 + k, a), etab);                     // :173,189
         for (int k = 0; k < Kq; ++k) W[k] = nis_exp(last_dot<WM, WX>(wl, bias, row0 + Kq + 1 + k, a), etab);             // :175,178
-        y = pwquad_column_big(xb, Kq, V, W, &jf, &bin);
+        y = pwquad_column_big(xb, Kq, V, W, &jf, &bin, &amb);
       } else if (KIND == NIS_PWQUAD) {
         constexpr int KA = KM > 32 ? 1 : KM;                     // (the branch above took KM > 32)
         double V[KA + 1], W[KA];
@@ -1257,7 +1289,7 @@ __global__ __launch_bounds__(NIS_TPB, (SPEC != 0 && KM <= 4) ? NIS_SPEC_WAVES : 
           for (int k = 0; k < KM; ++k)
             W[k] = (KEXACT || k < c.K) ? nis_exp(last_dot<WM, WX>(wl, bias, row0 + Kq + 1 + k, a), etab) : 0.0;           // :175,178
         }
-        y = pwquad_column<KA, KEXACT>(xb, c.K, V, W, &jf, &bin, GATHER ? lds_gather + tid : nullptr);
+        y = pwquad_column<KA, KEXACT>(xb, c.K, V, W, &jf, &bin, GATHER ? lds_gather + tid : nullptr, &amb);
       } else if (KIND == NIS_AFFINE) {
         // AffineCoupling (coupling_cells.py:56-68): rows [scale | shift][T];  y = atan(20 e^z0 x + relu(z1)) / (pi/2)
         const double s0 = 20.0 * nis_exp(last_dot<WM, WX>(wl, bias, t, a), etab);
@@ -1292,7 +1324,11 @@ __global__ __launch_bounds__(NIS_TPB, (SPEC != 0 && KM <= 4) ? NIS_SPEC_WAVES : 
       }
       if (wplanes) col[out_off + i] = y;
       jprod *= jf;
-      if (KIND != NIS_AFFINE && bins_o && g == 0) bins_o[(size_t)(c.bins_row + t) * ld + i] = bin;
+      if (KIND == NIS_PWQUAD && amb && c.status) {               // (rare: a whole wave skips this)
+        atomicOr(c.status, NIS_STATUS_BIN_AMBIGUOUS);
+        atomicOr(c.status + 1, NIS_STATUS_BIN_AMBIGUOUS);        // sticky copy: cleared by the caller, not by the next call's first launch
+      }
+      if (KIND != NIS_AFFINE && bins_o && g == 0) bins_o[(size_t)(c.bins_row + t) * ld + i] = bin | (amb ? NIS_BIN_AMBIGUOUS_FLAG : 0);
       if (next) {
         if (SP) nv[0] = y;             // launch_apply checked next_src[0] == 1
 #pragma unroll

@@ -539,8 +539,13 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
           const double* zr = ring + (size_t)((r0 & 15) + slot * out) * 16 + s;
           double y, jf;
           int bin;
+          bool amb = false;                                      // the bin decision rests on last bits (pwquad_bin_divide)
           if (KIND == NIS_PWQUAD) {
-            y = pwquad_column_lds<KM, KEXACT, 16, REL>(xb, c.K, zr, &jf, &bin);
+            y = pwquad_column_lds<KM, KEXACT, 16, REL>(xb, c.K, zr, &jf, &bin, &amb);
+            if (amb && c.status) {
+              atomicOr(c.status, NIS_STATUS_BIN_AMBIGUOUS);
+              atomicOr(c.status + 1, NIS_STATUS_BIN_AMBIGUOUS);
+            }
           } else if (KIND == NIS_AFFINE) {
             // rows interleaved at pack time: [exp(z0), z1] per column (coupling_cells.py:56-68)
             const double s0 = 20.0 * zr[0], z1 = zr[16];
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(NIS_MF_TPB, (KIND == NIS_PWLIN && NIS_MF_WAVES_LIN)
                 fc1 = (c.P + t == fz.loc1) ? y : fc1;
               }
             }
-            if (KIND != NIS_AFFINE && bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin;
+            if (KIND != NIS_AFFINE && bins_out && g == 0) bins_out[(size_t)(c.bins_row + t) * ld + i] = bin | (amb ? NIS_BIN_AMBIGUOUS_FLAG : 0);
           }
         }
         __builtin_amdgcn_wave_barrier();

@@ -154,8 +154,27 @@ class FlowEngine:
         wsb = self.L.nis_flow_workspace_bytes(self.handle, G)
         if self._ws is None or self._ws.device != dev or self._ws.numel() < wsb:
             self._ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            self._ws[:8].zero_()                     # status words: [0] per call, [1] sticky (include/nis_hip.h)
             self._sig = None
         return self._ws, wsb
+
+    def _status_buffers(self):
+        bufs = [self._ws] if self._ws is not None else []
+        plans = getattr(self, "_plans", None)
+        if plans is not None:
+            bufs.append(plans[1].ws)
+        return bufs
+
+    def clear_bin_ambiguous(self):
+        """Clear the STICKY status word of every workspace this engine launches into (the kernels only ever OR into it)."""
+        for b in self._status_buffers():
+            b[4:8].zero_()
+
+    def bin_ambiguous(self):
+        """True when some PWQuad bin decision since the last `clear_bin_ambiguous()` rested on last bits (NIS_STATUS_BIN_AMBIGUOUS:
+        an edge quotient within 2^-50 of x, or a width on the threshold of vanishing at the decision point -- the samples on which the
+        reference's own CPU and GPU builds disagree).  Synchronises (one 4-byte read per workspace)."""
+        return any(int(b[4:8].view(torch.int32)[0].item()) & _lib.NIS_STATUS_BIN_AMBIGUOUS for b in self._status_buffers())
 
     # The running statistics live in blobs the kernels update behind torch's back; the count of such updates is kept ON THE
     # CELL (several engines can share a cell: `model[0](x)` through the cell's own engine and `model(x)` through the
@@ -220,7 +239,11 @@ class FlowEngine:
             self._stats_bump(1)
         status = ws[:4].view(torch.int32)
         self._raise_on_status(status)
-        return dict(planes=planes, xj=xj, bins=bins, status=status, ws=ws)
+        ambiguous = None
+        if want_bins:                                # entries are bin | NIS_BIN_AMBIGUOUS_FLAG (include/nis_hip.h)
+            ambiguous = (bins & _lib.NIS_BIN_AMBIGUOUS_FLAG) != 0
+            bins = bins & ~_lib.NIS_BIN_AMBIGUOUS_FLAG
+        return dict(planes=planes, xj=xj, bins=bins, ambiguous=ambiguous, status=status, ws=ws)
 
     def forward_sync(self, w, has_jac=False, want_xj=True, group=None):
         """Train-mode forward of THIS RANK'S rows of a batch that is sharded over the ranks of `group`, with the BatchNorm
@@ -280,7 +303,7 @@ class FlowEngine:
     def _raise_on_status(self, status):
         """PWLin with x == 1.0 indexes bin n_bins: the reference's torch.gather raises (coupling_cells.py:136); the kernel
         flags it instead.  Only models with a PWLin cell pay the device->host read of the status word."""
-        if any(c.KIND == _lib.NIS_PWLIN for c in self.cells) and int(status[0].item()) & 1:
+        if any(c.KIND == _lib.NIS_PWLIN for c in self.cells) and int(status[0].item()) & _lib.NIS_STATUS_PWLIN_RANGE:
             raise IndexError("index out of range in PWLin bin lookup (an input coordinate equals 1.0 or is negative)")
 
     # ---- training: forward with history + hand-written adjoint
@@ -524,7 +547,7 @@ class FlowEngine:
                                                  out4.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
         _lib.check(rc, "nis_integrate_steps_bins")
         self._stats_bump(1)
-        return out4[0], bins
+        return out4[0], bins & ~_lib.NIS_BIN_AMBIGUOUS_FLAG        # (FlowEngine.bin_ambiguous() tells whether any entry carried the flag)
 
     def integrate_steps_rng(self, G, N, dev, f_kind, f_params, out4, seed, stream0, token=None, w_out=None, rng_state=None,
                             train=True, planes=None, keep_planes=False, ws=None):
@@ -624,6 +647,7 @@ class IntegratePlan:
         self.state = torch.zeros(2, dtype=torch.int64, device=self.dev)
         self.out = torch.zeros((self.G, 4), dtype=torch.double, device=self.dev)
         self.ws = torch.empty(eng.L.nis_flow_workspace_bytes(eng.handle, self.G), dtype=torch.uint8, device=self.dev)
+        self.ws[:8].zero_()                              # status words (word 1 is sticky: FlowEngine.bin_ambiguous)
         self.planes = torch.empty((self.G, eng.d + 1, self.N), dtype=torch.double, device=self.dev)
         cells = eng.cells
         for c in cells:

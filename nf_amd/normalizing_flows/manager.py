@@ -419,8 +419,14 @@ class BasicManager(ModelAPI):
             return (0, 0)
         dev = self._device(dev if dev is not None else self._model_device())
         neval, nitn = int(neval), int(nitn)
+        eng = self.best_model.engine() if isinstance(self.best_model, FlowSequential) else None
+        if eng is not None:
+            eng.clear_bin_ambiguous()
         mom = self.moments_batches(f, nitn, neval, dev)                             # (nitn, 4) on the device
         mom = mom.cpu()                                                             # the only host sync
+        # did any PWQuad bin decision of this call rest on last bits (include/nis_hip.h: NIS_STATUS_BIN_AMBIGUOUS)?  Everywhere else the
+        # bins are the reference's, bit for bit.  Read behind the results' own synchronisation: a few bytes.
+        self.bin_ambiguous = bool(eng.bin_ambiguous()) if eng is not None else False
         var = (mom[:, 2] / (mom[:, 0] - 1.0)).to(torch.float32)                     # float32 stores (:391-392)
         mean = mom[:, 1].to(torch.float32)
         sig = torch.sum(mean / var) / torch.sum(1 / var)
