@@ -15,8 +15,9 @@
 //   * only the weight gradients dW = d h a^T reduce over SAMPLES, which this layout keeps in the n index.  The hidden layers'
 //     (round 4) are accumulated INSIDE k_bwd_layer_w: the wave's d h and a tiles cross a padded per-wave LDS image and come
 //     back with samples on the k index (16 MFMAs per tile at width 32), per-workgroup records go to the reduction the chain
-//     runs anyway -- no d h / a planes, no GEMM launch.  The last layer's dW_L = dZ a_L^T is still taken from the dZ / a_L planes
-//     the head stores by a tall-skinny MFMA GEMM (k_bwd_xty_w) whose k index runs over samples.
+//     runs anyway -- no d h / a planes, no GEMM launch.  The last layer's dW_L = dZ a_L^T is taken from the dZ / a_L planes the
+//     head stores by a tall-skinny MFMA GEMM (k_bwd_xty_w) whose k index runs over samples: accumulating it inside the head (dZ in
+//     the LDS ring, dW_L in the registers of dedicated GEMM waves) was built and measured slower, profiles/r04_head2_ab.txt.
 #include <algorithm>
 #include <cstring>
 
@@ -555,551 +556,6 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
 }
 
 // ---------------------------------------------------------------------------------------------
-// head, round 4: BIJECTOR waves + GEMM waves.  One 512-thread workgroup per CU; waves 0..3 (one per SIMD) own a 16-sample tile each
-// and run only the vector work (forward recompute of the hidden stack, the bijector adjoint, ReLU / BatchNorm bookkeeping); waves
-// 4..7 (the second wave of each SIMD) run only the three GEMMs of the last Linear:
-//     Z = W_L a_L (+ exp -> the tile's LDS ring)  |  d a_L += W_L^T dZ  |  dW_L += dZ a_L^T, db_L += sum dZ
-// dZ never leaves the LDS ring (no 8 R bytes per sample written and read back, no k_bwd_xty_w launch for the last layer), dW_L lives in
-// the GEMM waves' registers for the whole launch ((column batch, 16-row tile) pairs dealt round-robin to the four waves, MAXP each), and
-// neither role carries the other's registers (the one-role head spilled 52-85 dwords at 256 VGPRs).
-// A tile goes  P1 a_L -> LDS | per column batch: P2 exp(W_L a_L) -> ring, P3 dZ in place, P4 d a_L and dW_L from the ring | P5 dy, sums:
-// P2 / P4 belong to the GEMM waves, P1 / P3 / P5 to the tile's bijector wave.  f64 MFMA and VALU work serialise on a SIMD whichever wave
-// issues them (profiles/r04_mfma_valu_overlap.txt), but a role alone leaves every memory latency open (first form of this kernel, the
-// roles taking turns: 551 us per C5 cell, the GEMM role's L2-fed phases at 30 % of their MFMA time), so the two tile PAIRS {0,1} and
-// {2,3} run one slot apart: in every slot the GEMM waves serve one pair while the other pair's bijector waves work, one workgroup barrier
-// per slot.  Pair schedule, period 2 C + 2 slots for C column batches (G = GEMM waves, B = the pair's bijector waves):
-//     G: P2(0) | B: P3(0) | G: P4(0), P2(1) | B: P3(1) | ... | G: P4(C-1), d a_L -> LDS | B: P5, P1 of the next tile
-// The host takes this kernel when the cell's pairs fit the accumulators and the LDS (else the one-role head + k_bwd_xty_w).
-#ifndef H2_NPAIR
-#define H2_NPAIR 1        // tile groups one slot apart: 2 = the pairs {0,1}, {2,3} (bijector and GEMM waves overlap, a fragment feeds 2 MFMAs); 1 = all four
-#endif                    //   tiles in step (the roles take turns, a fragment feeds 4 MFMAs).  Measured: profiles/r04_head2_ab.txt
-constexpr int TPB2 = 512;
-constexpr int NPAIR = H2_NPAIR, TG = NW / NPAIR;          // groups, tiles per group
-constexpr int MAXP = WM == 16 ? 8 : WM == 32 ? 5 : 3;     // pairs per GEMM wave: MAXP * JT accumulator tiles = 64 / 80 / 96 VGPRs
-
-struct Head2 {
-  int ncb, ncbat, rows_cb, ntile_cb;            // columns per batch, batches, ncb * out, 16-row tiles of a batch's image
-  int ngl;                                      // row groups of the dW_L record (GEMM layout: RPW * 16 rows x (WM + 1))
-};
-
-// blob row of ring row j of column batch cb (-1: no such row).  Piecewise cells: rows are [t][out] in both; AffineCoupling: the ring is
-// [t][scale, shift] (packed interleaved), the blob [scale | shift][T]
-template <int KIND>
-__device__ __forceinline__ int head2_row(const CellK& c, const Head2& h, int cb, int j) {
-  if (j >= h.rows_cb) return -1;
-  if (KIND == NIS_AFFINE) {
-    const int t = cb * h.ncb + (j >> 1);
-    return t < c.T ? ((j & 1) ? c.T + t : t) : -1;
-  }
-  const int r = cb * h.rows_cb + j;
-  return r < c.R ? r : -1;
-}
-
-// Timing-only instrumentation (-DH2_STAMPS, never in the shipped library): wave 0 of each role in workgroup 0 accumulates the 100 MHz
-// clock per activity and prints the sums at the end (tools/h2_stamps.sh).
-#ifdef H2_STAMPS
-#define H2_T0() unsigned long long h2t = __builtin_amdgcn_s_memrealtime(), h2acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define H2_T(k)                                                        \
-  do {                                                                 \
-    const unsigned long long now = __builtin_amdgcn_s_memrealtime();   \
-    h2acc[k] += now - h2t;                                             \
-    h2t = now;                                                         \
-  } while (0)
-#define H2_PRINT(role, id)                                                                                                              \
-  if (blockIdx.x == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0 && (id) == 0)                                                        \
-  printf("h2 %s: %llu %llu %llu %llu %llu %llu %llu %llu (x10 ns)\n", role, h2acc[0], h2acc[1], h2acc[2], h2acc[3], h2acc[4], h2acc[5], \
-         h2acc[6], h2acc[7])
-#else
-#define H2_T0()
-#define H2_T(k)
-#define H2_PRINT(role, id)
-#endif
-
-// LDS of the two-role head
-struct Head2Lds {
-  double* rings;           // NW rings of ring_rows x TS: exp(Z) of the tile's current column batch, then dZ in place
-  double* aLt;             // NW a_L tiles, WM x TS
-  double* daT;             // NW d a_L tiles, WM x TS
-  double* xhT;             // NW xhat_L tiles, WM x TS (parked by the bijector wave over its column batches: 2 KQ registers less in the bijector phase)
-  const double* lds_bn;
-  const int* lds_plane;
-  const double* etab;
-  double (*sm)[SREC];
-  unsigned* gcnt;          // arrival counter of the GEMM waves' own barrier
-  int ring_rows;
-};
-
-// slots of one launch: `iters` tile sets per workgroup, period 2 C + 2, the second pair one slot behind
-__device__ __forceinline__ long head2_iters(long N) {
-  const long per = (long)gridDim.x * NW * 16;
-  const long first = (long)blockIdx.x * NW * 16;
-  return first < N ? (N - first + per - 1) / per : 0;
-}
-
-// ---- role 1: bijector wave `wave` (0 .. NW-1) of pair wave >> 1
-template <int KIND, int KM, bool KEXACT>
-__device__ __forceinline__ void head2_bijector(const BwdK& k, const BwdW& w, const Head2& h, const Head2Lds& m, int wave) {
-  const CellK& c = k.c;
-  const int lane = threadIdx.x & 63, gq = lane >> 4, s = lane & 15;
-  const int L = c.L, K = KEXACT ? KM : c.K, out = c.out;
-  const long ld = k.ld, N = k.N;
-  const double* bnL = m.lds_bn + (size_t)L * 4 * WM;
-  double* const at = m.aLt + (size_t)wave * WM * TS;
-  double* const xt = m.xhT + (size_t)wave * WM * TS;
-  double* const dt = m.daT + (size_t)wave * WM * TS;
-  const long wstride = (long)gridDim.x * NW * 16;
-  const long iters = head2_iters(N);
-  const int C = h.ncbat, period = 2 * C + 2, pair = wave / TG;
-  const long T_total = iters * period + (NPAIR - 1);
-  // per-tile state, set by P1
-  long i = 0;
-  bool iv = false;
-  double gJ = 0.0, Jout = 1.0, jfprod = 1.0;
-  // P1: hidden stack -> a_L, xhat_L tiles in LDS (this lane's entries: feature 16 jt + gq + 4 r, sample s); d a_L tile zeroed
-  auto P1 = [&](long it) {
-    const long base = (long)blockIdx.x * NW * 16 + it * wstride + 16 * wave;
-    i = base + s;
-    iv = i < N;
-    {
-      double H[KQ][ST], XH[KQ][ST];
-      nis_d4 acc[JT][ST];
-      bww_forward(c, k.x, ld, N, base, m.lds_plane, m.lds_bn, w.wm_all, L, H, XH, acc);
-#pragma unroll
-      for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = 16 * jt + gq + 4 * r;
-          const double sc = bnL[j], sh = bnL[WM + j], mu = bnL[2 * WM + j], rs = bnL[3 * WM + j];
-          const double v = acc[jt][0][r];
-          xt[j * TS + s] = (v - mu) * rs;
-          at[j * TS + s] = fmax(fma(v, sc, sh), 0.0);            // a_L
-          dt[j * TS + s] = 0.0;                                  // the GEMM waves accumulate d a_L here over the column batches
-        }
-    }
-    gJ = iv ? k.g[(size_t)c.jplane * ld + i] : 0.0;
-    Jout = iv ? k.xo[(size_t)c.jplane * ld + i] : 1.0;
-    jfprod = 1.0;
-  };
-  // P3: (sample s, column slot gq) per lane; dZ replaces the exponentials in the ring
-  auto P3 = [&](int cb) {
-    const int t = cb * h.ncb + gq;
-    const bool valid = gq < h.ncb && t < c.T && iv;
-    const int tc = min(t, c.T - 1);
-    const size_t colp = (size_t)m.lds_plane[c.P + tc] * ld;
-    const double xraw = valid ? k.x[colp + i] : 0.5;
-    const double gy = valid ? k.g[colp + i] : 0.0;
-    const double gJv = valid ? gJ : 0.0;
-    if (gq < h.ncb) {
-    double* const zw = m.rings + (size_t)wave * m.ring_rows * TS + (size_t)gq * out * TS + s;
-    const double* const zr = zw;
-    double gx = 0.0, jf = 1.0;
-    if (KIND == NIS_PWQUAD) {
-      const bool clamped = xraw > 1.0 - 1e-6;
-      const double xb = clamped ? 1.0 - 1e-6 : xraw;
-      double V[KM + 1], W[KM];
-#pragma unroll
-      for (int q = 0; q < KM + 1; ++q) V[q] = (KEXACT || q <= K) ? (valid ? zr[q * TS] : 1.0) : 0.0;
-#pragma unroll
-      for (int q = 0; q < KM; ++q) W[q] = (KEXACT || q < K) ? (valid ? zr[(K + 1 + q) * TS] : 1.0) : 0.0;
-      double wn = 0.0;
-#pragma unroll
-      for (int q = 0; q < KM; ++q)
-        if (q < K) wn += W[q];
-      int b;
-      double left;
-      pwquad_bin<KM, false>(xb, K, W, wn, &b, &left);
-      const double iwn = 1.0 / wn;
-      double area = 0.0;
-#pragma unroll
-      for (int q = 0; q < KM; ++q)
-        if (q < K) {
-          W[q] = W[q] * iwn;
-          area += (V[q] + V[q + 1]) / 2 * W[q];
-        }
-      const double iarea = 1.0 / area;
-#pragma unroll
-      for (int q = 0; q < KM + 1; ++q)
-        if (q <= K) V[q] = V[q] * iarea;
-      const double Wb = valid ? zr[(K + 1 + b) * TS] * iwn : 1.0;
-      const double Vb = valid ? zr[b * TS] * iarea : 1.0, Vb1 = valid ? zr[(b + 1) * TS] * iarea : 1.0;
-      const double alpha = (xb - left) / Wb;
-      const double D = Vb1 - Vb;
-      jf = lerp_torch(Vb, Vb1, alpha);
-      const double gjf = gJv * Jout / jf;                  // J_out = J_in prod_t jf_t
-      const double galpha = gy * jf * Wb + gjf * D;
-      gx = clamped ? 0.0 : galpha / Wb;
-      const double gleft = -galpha / Wb;
-      // gradients w.r.t. the normalised heights / widths are sparse in q: re-formed on the fly in each pass (see k_bwd_head_w)
-      const double hgy = gy / 2;
-      const double A0 = gy * alpha * Wb * (1.0 - alpha / 2) + gjf * (1.0 - alpha);
-      const double A1 = gy * alpha * alpha / 2 * Wb + gjf * alpha;
-      const double B0 = gy * (alpha * alpha / 2 * D + alpha * Vb) - galpha * alpha / Wb;
-#define NIS_GV(q, wm1, wq) (((q) >= 1 && (q) - 1 < b ? hgy * (wm1) : 0.0) + ((q) < b ? hgy * (wq) : 0.0) + ((q) == b ? A0 : 0.0) + ((q) == b + 1 ? A1 : 0.0))
-#define NIS_GW0(q) (((q) < b ? hgy * (V[q] + V[(q) + 1]) + gleft : 0.0) + ((q) == b ? B0 : 0.0))
-      double S = 0.0;
-#pragma unroll
-      for (int q = 0; q < KM + 1; ++q)
-        if (KEXACT || q <= K) {
-          const double wm1 = q >= 1 ? W[q >= 1 ? q - 1 : 0] : 0.0;
-          const double wq = (q < KM && (KEXACT || q < K)) ? W[q < KM ? q : 0] : 0.0;
-          S += NIS_GV(q, wm1, wq) * V[q];
-        }
-      double Sw = 0.0;
-#pragma unroll
-      for (int q = 0; q < KM; ++q)
-        if (KEXACT || q < K) Sw += (NIS_GW0(q) - S * (V[q] + V[q + 1]) / 2) * W[q];
-      double wprev = 0.0;
-#pragma unroll
-      for (int q = 0; q < KM + 1; ++q)
-        if (KEXACT || q <= K) {                          // wave-uniform
-          const bool hasw = q < KM && (KEXACT || q < K);
-          const double wq = hasw ? W[q < KM ? q : 0] : 0.0;
-          const double vq = V[q];
-          const double dzv = NIS_GV(q, wprev, wq) * vq - S * vq * (wprev + wq) / 2;
-          if (hasw) {
-            const double dzw = wq * (NIS_GW0(q) - S * (vq + V[q + 1]) / 2 - Sw);
-            zw[(K + 1 + q) * TS] = valid ? dzw : 0.0;
-          }
-          zw[q * TS] = valid ? dzv : 0.0;
-          wprev = wq;
-        }
-#undef NIS_GV
-#undef NIS_GW0
-    } else if (KIND == NIS_AFFINE) {
-      const double s0 = 20.0 * (valid ? zr[0] : 1.0), z1 = valid ? zr[TS] : 0.0;
-      const double u = xraw * s0 + (z1 > 0.0 ? z1 : 0.0);
-      const double q = 1.0 / (u * u + 1.0);
-      jf = s0 * q;
-      const double gjf = gJv * Jout / jf;
-      const double gu = gy * (q / (M_PI / 2)) - gjf * (2.0 * u * s0 * q * q);
-      gx = gu * s0;
-      zw[0] = valid ? (gu * xraw + gjf * q) * s0 : 0.0;
-      zw[TS] = (valid && z1 > 0.0) ? gu : 0.0;
-    } else {
-      // PWLin: Q_q = K e_q / tot, y = Q_b alpha + sum_{q<b} e_q / tot, jf = Q_b
-      const double ak = xraw * K;
-      const double bf = floor(ak);
-      const double alpha = (ak - bf) / K;
-      const int b = (int)bf;
-      double tot = 0.0, below = 0.0, eb = 0.0;
-      for (int q = 0; q < K; ++q) {
-        const double e = valid ? zr[q * TS] : 1.0;
-        const bool hit = q == b;
-        below = hit ? tot : below;
-        eb = hit ? e : eb;
-        tot += e;
-      }
-      const double Qb = eb / (tot / K);
-      const double Qs = below / tot;
-      jf = Qb;
-      const double gjf = gJv * Jout / jf;
-      const double gQb = gy * alpha + gjf, gQs = gy;
-      gx = gy * Qb;
-      for (int q = 0; q < K; ++q) {
-        const double pq = (valid ? zr[q * TS] : 1.0) / tot;
-        const double dz = gQb * ((q == b ? Qb : 0.0) - Qb * pq) + gQs * ((q < b ? pq : 0.0) - Qs * pq);
-        zw[q * TS] = valid ? dz : 0.0;
-      }
-    }
-      if (valid) {
-        k.g[colp + i] = gx;
-        jfprod *= jf;
-      }
-    }
-  };
-  // P5: through ReLU to BN_L's output; sums of BN_L
-  auto P5 = [&]() {
-    jfprod *= __shfl_xor(jfprod, 16, 64);
-    jfprod *= __shfl_xor(jfprod, 32, 64);
-    if (KIND == NIS_AFFINE) jfprod *= 1.0 / (M_PI / 2);
-    if (gq == 0 && iv) k.g[(size_t)c.jplane * ld + i] = gJ * jfprod;   // dL/dJ_in = dL/dJ_out prod_t dy_t/dx_t
-#pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-      const int j = 4 * q + gq;
-      const double dy = at[j * TS + s] > 0.0 ? dt[j * TS + s] : 0.0;
-      if (iv) k.dyp[tmx(WM, j, i)] = dy;
-      double t1 = iv ? dy : 0.0, t2 = iv ? dy * xt[j * TS + s] : 0.0;
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        t1 += __shfl_xor(t1, o, 64);
-        t2 += __shfl_xor(t2, o, 64);
-      }
-      if (s == 0) {
-        m.sm[wave][j] += t1;
-        m.sm[wave][WM + j] += t2;
-      }
-    }
-  };
-  H2_T0();
-  if (iters > 0) P1(0);
-  __syncthreads();
-  H2_T(0);
-  for (long t = 0; t < T_total; ++t) {
-    const long st = t - pair;
-    if (st >= 0 && st < iters * period && (st & 1)) {            // this pair's bijector slot
-      const long it = st / period;
-      const int kk = (int)((st - it * period) - 1) / 2;
-      if (kk < C) {
-        P3(kk);
-        H2_T(1);
-      } else {
-        P5();
-        H2_T(2);
-        if (it + 1 < iters) P1(it + 1);
-        H2_T(0);
-      }
-    }
-    __syncthreads();
-    H2_T(3);
-  }
-  H2_PRINT("bijector P1 | P3 | P5 | barrier", wave);
-}
-
-// barrier of the four GEMM waves only (between their reads of a pair's rings in P4 and the overwrite in P2 of the same slot): arrival
-// counter in LDS, bounded by the workgroup barriers around every slot (all four waves run the same slot sequence)
-__device__ __forceinline__ void head2_gemm_barrier(unsigned* cnt, unsigned& epoch) {
-  epoch += NW;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// ---- role 2: GEMM wave gw (0 .. NW-1); per slot the two tiles 2 p, 2 p + 1 of one pair
-template <int KIND>
-__device__ __forceinline__ void head2_gemm(const BwdK& k, const BwdW& w, const Head2& h, const Head2Lds& m, int gw) {
-  const CellK& c = k.c;
-  const int lane = threadIdx.x & 63, gq = lane >> 4, s = lane & 15;
-  const long N = k.N;
-  const int ring_rows = m.ring_rows;
-  // dW_L tiles of this wave's pairs p = gw + 4 pi -> (column batch p / ntile_cb, row tile p % ntile_cb), and their row sums (db_L)
-  nis_d4 dW[MAXP][JT];
-  double rsum[MAXP];
-#pragma unroll
-  for (int pi = 0; pi < MAXP; ++pi) {
-    rsum[pi] = 0.0;
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) dW[pi][jt] = nis_d4{0.0, 0.0, 0.0, 0.0};
-  }
-  const long iters = head2_iters(N);
-  const int C = h.ncbat, period = 2 * C + 2;
-  const long T_total = iters * period + (NPAIR - 1);
-  unsigned epoch = 0;
-  // d a_L: this wave owns feature tile djt of the tiles dtile + (NW / JT) v of the served group (v < DAT; none when dtile >= TG)
-  const int djt = gw % JT, dtile = gw / JT;
-  constexpr int DAT = (JT * TG + NW - 1) / NW;
-  const bool da_owner = dtile < TG;
-  constexpr int NKMAX = 36;                                      // k-steps of a column batch whose operands are requested at once (rows_cb <= 144)
-  H2_T0();
-  __syncthreads();                                               // (the bijector waves' first P1)
-  for (long t = 0; t < T_total; ++t) {
-    const int pr = (int)(t & (NPAIR - 1));                       // group served in this slot (the groups' GEMM slots are the even ones of their own clocks)
-    const long st = t - pr;
-    if (st < iters * period && !(st & 1)) {
-      const long it = st / period;
-      const int kk = (int)(st - it * period) / 2;                // 0 .. C
-      const int t0 = TG * pr;                                    // first tile of the group
-      (void)it;
-      if (kk >= 1) {
-        // ---------------- P4 of column batch kk - 1: d a_L += W_L^T dZ (k index = ring rows), dW_L += dZ a_L^T (k index = samples)
-        const int cb = kk - 1;
-        const int nk = (h.rows_cb + 3) / 4;
-        // the A operands W_L[row 4 kq + gq][16 djt + s] of d a_L come from the row-major blob (L2): ALL of the batch's k-steps are
-        // requested first, the LDS-fed dW_L products run while they are in flight
-        double aop[NKMAX];
-#ifndef H2_SKIP_DA
-        if (da_owner) {
-#pragma unroll
-          for (int kq = 0; kq < NKMAX; ++kq) {
-            const int row = kq < nk ? head2_row<KIND>(c, h, cb, 4 * kq + gq) : -1;
-            aop[kq] = row >= 0 ? c.wlast[(size_t)row * WM + 16 * djt + s] : 0.0;
-          }
-        }
-#endif
-#ifndef H2_SKIP_DW
-#pragma unroll
-        for (int pi = 0; pi < MAXP; ++pi) {
-          const int p = gw + NW * pi;
-          if (p / h.ntile_cb == cb) {                            // (wave-uniform)
-            const int rt = p - cb * h.ntile_cb;
-#pragma unroll
-            for (int u = 0; u < TG; ++u) {
-              const int wv = t0 + u;
-              const double* ring = m.rings + (size_t)wv * ring_rows * TS + (size_t)(16 * rt + s) * TS + gq;
-              const double* at = m.aLt + (size_t)wv * WM * TS + (size_t)s * TS + gq;
-#pragma unroll
-              for (int mm = 0; mm < 4; ++mm) {
-                const double af = ring[4 * mm];                  // dZ[row 16 rt + s][sample 4 mm + gq]
-                rsum[pi] += af;
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) dW[pi][jt] = mfma(af, at[(size_t)16 * jt * TS + 4 * mm], dW[pi][jt]);
-              }
-            }
-          }
-        }
-#endif
-        H2_T(1);
-#ifndef H2_SKIP_DA
-        if (da_owner) {
-          nis_d4 da[DAT];
-#pragma unroll
-          for (int v = 0; v < DAT; ++v)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)                           // this wave is the only writer of its (feature tile, sample tile)s
-              da[v][r] = m.daT[(size_t)(t0 + dtile + (NW / JT) * v) * WM * TS + (size_t)(16 * djt + gq + 4 * r) * TS + s];
-#pragma unroll
-          for (int kq = 0; kq < NKMAX; ++kq)
-            if (kq < nk) {
-#pragma unroll
-              for (int v = 0; v < DAT; ++v)
-                da[v] = mfma(aop[kq], m.rings[(size_t)(t0 + dtile + (NW / JT) * v) * ring_rows * TS + (size_t)(4 * kq + gq) * TS + s], da[v]);
-            }
-#pragma unroll
-          for (int v = 0; v < DAT; ++v)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              m.daT[(size_t)(t0 + dtile + (NW / JT) * v) * WM * TS + (size_t)(16 * djt + gq + 4 * r) * TS + s] = da[v][r];
-        }
-#endif
-        H2_T(2);
-      }
-      __builtin_amdgcn_sched_barrier(0);                         // (the fragment requests below must not be hoisted over P4: its operands hold the registers)
-      if (kk < C) {
-        // ---------------- P2 of column batch kk: exp(W_L a_L + b) of its rows into the pair's two rings
-        const int cb = kk;
-        const int r0 = cb * h.rows_cb;
-        const int r1 = min(c.R, r0 + h.rows_cb);
-        // this wave's row tiles: jt = r0 / 16 + ((gw + cb) & 3) + 4 n (the odd tile rotates with the batch); the next tile's fragments and
-        // bias are in flight while the current one is multiplied, the B operands a_L[feature 4 q + gq][sample s] (as stored) are read in one go
-        int jt = r0 / 16 + ((gw + cb) & (NW - 1));
-        double fa[KQ];
-        nis_d4 zb;
-#ifndef H2_SKIP_P2
-        if (jt * 16 < r1) {
-#pragma unroll
-          for (int q = 0; q < KQ; ++q) fa[q] = w.wm_last[((size_t)jt * KQ + q) * 64 + lane];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) zb[r] = w.bias_pad[16 * jt + gq + 4 * r];
-        }
-#endif
-        if (kk >= 1) head2_gemm_barrier(m.gcnt, epoch);          // every GEMM wave has finished reading this group's rings
-#ifndef H2_SKIP_P2
-        for (; jt * 16 < r1; jt += NW) {
-          const int jn = (jt + NW) * 16 < r1 ? jt + NW : jt;     // (last tile: re-requests itself, unused)
-          double fb[KQ];
-          nis_d4 zn;
-#pragma unroll
-          for (int q = 0; q < KQ; ++q) fb[q] = w.wm_last[((size_t)jn * KQ + q) * 64 + lane];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) zn[r] = w.bias_pad[16 * jn + gq + 4 * r];
-          double aLf[TG][KQ];
-#pragma unroll
-          for (int u = 0; u < TG; ++u)
-#pragma unroll
-            for (int q = 0; q < KQ; ++q) aLf[u][q] = m.aLt[(size_t)(t0 + u) * WM * TS + (4 * q + gq) * TS + s];
-          nis_d4 z[TG];
-#pragma unroll
-          for (int u = 0; u < TG; ++u) z[u] = zb;
-#pragma unroll
-          for (int q = 0; q < KQ; ++q)
-#pragma unroll
-            for (int u = 0; u < TG; ++u) z[u] = mfma(fa[q], aLf[u][q], z[u]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = 16 * jt + gq + 4 * r - r0;
-            if (j >= 0 && j < h.rows_cb && 16 * jt + gq + 4 * r < c.R) {
-#pragma unroll
-              for (int u = 0; u < TG; ++u)
-                m.rings[(size_t)(t0 + u) * ring_rows * TS + j * TS + s] = (KIND == NIS_AFFINE && (j & 1)) ? z[u][r] : nis_exp(z[u][r], m.etab);
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < KQ; ++q) fa[q] = fb[q];
-          zb = zn;
-        }
-#endif
-        H2_T(4);
-      }
-    }
-    __syncthreads();
-    H2_T(5);
-  }
-  H2_PRINT("gemm - | dW | d a | - | P2 | barrier", gw);
-  // dW_L / db_L records of this workgroup in the GEMM's layout: [row group][workgroup][RPW * 16 rows x (WM products | row sum)]
-#pragma unroll
-  for (int pi = 0; pi < MAXP; ++pi) {
-    const int p = gw + NW * pi;
-    if (p < h.ncbat * h.ntile_cb) {
-      const int cb = p / h.ntile_cb, rt = p - cb * h.ntile_cb;
-      double rs = rsum[pi];
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = head2_row<KIND>(c, h, cb, 16 * rt + gq + 4 * r);
-        if (row >= 0) {
-          double* rec = w.partg + ((size_t)(row / (RPW * 16)) * w.nb + blockIdx.x) * GREC + (size_t)(row % (RPW * 16)) * (WM + 1);
-#pragma unroll
-          for (int jt = 0; jt < JT; ++jt) rec[16 * jt + s] = dW[pi][jt][r];
-        }
-      }
-      const int rowS = head2_row<KIND>(c, h, cb, 16 * rt + s);
-      if (gq == 0 && rowS >= 0)
-        w.partg[((size_t)(rowS / (RPW * 16)) * w.nb + blockIdx.x) * GREC + (size_t)(rowS % (RPW * 16)) * (WM + 1) + WM] = rs;
-    }
-  }
-}
-
-template <int KIND, int KM, bool KEXACT, bool BATCH>
-__global__ __launch_bounds__(TPB2, 1) void k_bwd_head2_w(BwdK k, BwdW w, Head2 h) {
-  extern __shared__ double mf_dyn[];                 // [NW rings of ntile_cb * 16 rows x TS] [NW x (a_L | d a_L | xhat_L) tiles of WM x TS]
-  __shared__ double lds_bn[BNLDS];
-  __shared__ int lds_plane[NIS_MAX_DIM];
-  __shared__ double etab[NIS_EXP_N];
-  __shared__ double sm[NW][SREC];
-  __shared__ unsigned gcnt;
-  if (BATCH) bww_batch(k, &w);
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  bww_stage(k, lds_bn, lds_plane);
-  nis_exp_init(etab);
-  if (tid == 0) gcnt = 0;
-  Head2Lds m;
-  m.ring_rows = h.ntile_cb * 16;
-  m.rings = mf_dyn;
-  m.aLt = m.rings + (size_t)NW * m.ring_rows * TS;
-  m.daT = m.aLt + (size_t)NW * WM * TS;
-  m.xhT = m.daT + (size_t)NW * WM * TS;
-  m.lds_bn = lds_bn;
-  m.lds_plane = lds_plane;
-  m.etab = etab;
-  m.sm = sm;
-  m.gcnt = &gcnt;
-  // rows of a ring past the batch's own (rows_cb .. ring_rows) are read by the GEMMs and written by nobody: zero, once
-  const int npad = (m.ring_rows - h.rows_cb) * TS;
-  for (int e = tid; e < NW * npad; e += TPB2) m.rings[(size_t)(e / npad) * m.ring_rows * TS + (size_t)h.rows_cb * TS + e % npad] = 0.0;
-  for (int e = tid; e < NW * SREC; e += TPB2) sm[e / SREC][e % SREC] = 0.0;
-  __syncthreads();
-  // the roles are two separate code paths (their registers never coexist); both meet the same sequence of workgroup barriers
-  if (wave < NW)
-    head2_bijector<KIND, KM, KEXACT>(k, w, h, m, wave);
-  else
-    head2_gemm<KIND>(k, w, h, m, wave - NW);
-  __syncthreads();
-  if (tid < SREC) {
-    double t = 0.0;
-    for (int wv = 0; wv < NW; ++wv) t += sm[wv][tid];
-    k.part[(size_t)blockIdx.x * SREC + tid] = t;
-  }
-  // rows R .. ngl * RPW * 16 of the last group exist in the record only: zero
-  const int pad0 = k.c.R % (RPW * 16);
-  if (pad0 != 0) {
-    double* rec = w.partg + ((size_t)(h.ngl - 1) * w.nb + blockIdx.x) * GREC;
-    for (int e = pad0 * (WM + 1) + tid; e < GREC; e += TPB2) rec[e] = 0.0;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // layer l (L..1): BN_l backward -> d h_l, dW_{l-1} += d h_l a_{l-1}^T (records), dy_{l-1} = relu'(.) W_{l-1}^T d h_l, sums of BN_{l-1}
 template <bool BATCH>
 __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l) {
@@ -1245,15 +701,17 @@ __global__ __launch_bounds__(TPB) void k_bwd_input_w(BwdK k) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// out[r][q] = sum_i A[r][i] B[q][i] (+ row sums of A) for RPW*16 rows per workgroup row group: the MFMA k index
-// runs over samples.  Lane l owns samples 4 (l>>4) .. 4 (l>>4) + 3 of a 16-sample tile (one 32-byte load per row of the
-// tile-major buffers) and feeds sample 4 (l>>4) + m to k-step m.
-// The operands of the next tile are in flight while the current one is multiplied.
+// dW_L[r][q] = sum_i dZ[r][i] a_L[q][i] (+ row sums of dZ = db_L): the MFMA k index runs over samples.  Lane l owns samples
+// 4 (l>>4) .. 4 (l>>4) + 3 of a 16-sample tile (one 32-byte load per row of the tile-major buffers) and feeds sample 4 (l>>4) + m to
+// k-step m.  The four waves of a workgroup split the ROWS (row tiles w + 4 n of the workgroup's block of 4 XRT tiles) and walk the same
+// sample tiles, so dZ is read once and a_L once per workgroup (its four waves share the lines; round 3 gave every wave its own samples
+// and one row group, and re-read a_L once per row group: 5 x at C5).  The operands of the next tile are in flight while the current one
+// is multiplied; a wave owns its rows alone, so its accumulators ARE the workgroup's record (no cross-wave sum).
+constexpr int XRT = WM <= 32 ? 5 : 2;                     // row tiles per wave: XRT * JT accumulator tiles of 8 registers
 struct XtyOps {
-  nis_d4 a[RPW], b[JT];
+  nis_d4 a[XRT], b[JT];
 };
-__device__ __forceinline__ void xty_load(const double* __restrict__ Ap, int FA, int R, int rb, const double* __restrict__ Bp, long N, long tile,
-                                         XtyOps& o) {
+__device__ __forceinline__ void xty_load(const double* __restrict__ Ap, int R, int rt0, const double* __restrict__ Bp, long N, long tile, XtyOps& o) {
   const int lane = threadIdx.x & 63, gq = lane >> 4, s = lane & 15;
   const long i0 = tile * 16 + 4 * gq;
   const nis_d4 zero = {0.0, 0.0, 0.0, 0.0};
@@ -1261,9 +719,9 @@ __device__ __forceinline__ void xty_load(const double* __restrict__ Ap, int FA, 
 #pragma unroll
   for (int qt = 0; qt < JT; ++qt) o.b[qt] = in ? *reinterpret_cast<const nis_d4*>(Bp + ((size_t)tile * WM + 16 * qt + s) * 16 + 4 * gq) : zero;
 #pragma unroll
-  for (int rt = 0; rt < RPW; ++rt) {
-    const int row = rb + 16 * rt + s;
-    o.a[rt] = (in && row < R) ? *reinterpret_cast<const nis_d4*>(Ap + ((size_t)tile * FA + row) * 16 + 4 * gq) : zero;
+  for (int n = 0; n < XRT; ++n) {
+    const int row = 16 * (rt0 + NW * n) + s;
+    o.a[n] = (in && row < R) ? *reinterpret_cast<const nis_d4*>(Ap + ((size_t)tile * R + row) * 16 + 4 * gq) : zero;
   }
   if (in && i0 + 3 >= N) {
 #pragma unroll
@@ -1272,70 +730,64 @@ __device__ __forceinline__ void xty_load(const double* __restrict__ Ap, int FA, 
 #pragma unroll
         for (int qt = 0; qt < JT; ++qt) o.b[qt][m] = 0.0;
 #pragma unroll
-        for (int rt = 0; rt < RPW; ++rt) o.a[rt][m] = 0.0;
+        for (int n = 0; n < XRT; ++n) o.a[n][m] = 0.0;
       }
   }
 }
 
-__global__ __launch_bounds__(TPB, 2) void k_bwd_xty_w(const double* __restrict__ Ap, int FA, int R, const double* __restrict__ Bp, long N,
-                                                      double* __restrict__ part, long wsp_gs, long part_gs) {
-  __shared__ double sm[GREC];
+__global__ __launch_bounds__(TPB, 2) void k_bwd_xty_w(const double* __restrict__ Ap, int R, const double* __restrict__ Bp, long N,
+                                                      double* __restrict__ part, int ngroups, long wsp_gs, long part_gs) {
   Ap += (size_t)blockIdx.z * wsp_gs;                 // minibatch g = blockIdx.z: its planes, its record area
   Bp += (size_t)blockIdx.z * wsp_gs;
   part += (size_t)blockIdx.z * part_gs;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
-  const int rb = blockIdx.y * RPW * 16;
-  nis_d4 acc[RPW][JT];
-  double rsum[RPW];
+  const int rt0 = blockIdx.y * NW * XRT + wave;      // this wave's row tiles: rt0 + NW n
+  nis_d4 acc[XRT][JT];
+  double rsum[XRT];
 #pragma unroll
-  for (int rt = 0; rt < RPW; ++rt) {
-    rsum[rt] = 0.0;
+  for (int n = 0; n < XRT; ++n) {
+    rsum[n] = 0.0;
 #pragma unroll
-    for (int qt = 0; qt < JT; ++qt) acc[rt][qt] = nis_d4{0.0, 0.0, 0.0, 0.0};
+    for (int qt = 0; qt < JT; ++qt) acc[n][qt] = nis_d4{0.0, 0.0, 0.0, 0.0};
   }
-  const long ntiles = (N + 15) / 16, tstride = (long)gridDim.x * NW;
-  long tile = (long)blockIdx.x * NW + wave;
+  const long ntiles = (N + 15) / 16, tstride = gridDim.x;
+  long tile = blockIdx.x;
   XtyOps cur, nxt;
-  if (tile < ntiles) xty_load(Ap, FA, R, rb, Bp, N, tile, cur);
+  if (tile < ntiles) xty_load(Ap, R, rt0, Bp, N, tile, cur);
   for (; tile < ntiles; tile += tstride) {
     const bool more = tile + tstride < ntiles;
-    if (more) xty_load(Ap, FA, R, rb, Bp, N, tile + tstride, nxt);
+    if (more) xty_load(Ap, R, rt0, Bp, N, tile + tstride, nxt);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int rt = 0; rt < RPW; ++rt) {
-        rsum[rt] += cur.a[rt][m];
+      for (int n = 0; n < XRT; ++n) {
+        rsum[n] += cur.a[n][m];
 #pragma unroll
-        for (int qt = 0; qt < JT; ++qt) acc[rt][qt] = mfma(cur.a[rt][m], cur.b[qt][m], acc[rt][qt]);
+        for (int qt = 0; qt < JT; ++qt) acc[n][qt] = mfma(cur.a[n][m], cur.b[qt][m], acc[n][qt]);
       }
     if (more) cur = nxt;
   }
+  // the wave's rows of the workgroup's record: [row group of RPW * 16][workgroup][rows x (WM products | row sum)]; rows past R hold zeros
+  // (their operands were zero), row tiles past the last group are not part of any record
 #pragma unroll
-  for (int rt = 0; rt < RPW; ++rt) {
-    rsum[rt] += __shfl_xor(rsum[rt], 16, 64);
-    rsum[rt] += __shfl_xor(rsum[rt], 32, 64);
-  }
-  for (int wv = 0; wv < NW; ++wv) {                 // wave after wave: fixed summation order
-    if (wave == wv) {
+  for (int n = 0; n < XRT; ++n) {
+    const int rt = rt0 + NW * n;
+    if (rt * 16 >= ngroups * RPW * 16) continue;
+    double rs = rsum[n];
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
 #pragma unroll
-      for (int rt = 0; rt < RPW; ++rt) {
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * rt + gq + 4 * r;
+      double* rec = part + ((size_t)(row / (RPW * 16)) * gridDim.x + blockIdx.x) * GREC + (size_t)(row % (RPW * 16)) * (WM + 1);
 #pragma unroll
-        for (int qt = 0; qt < JT; ++qt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int e = (16 * rt + gq + 4 * r) * (WM + 1) + 16 * qt + s;
-            sm[e] = (wv == 0 ? 0.0 : sm[e]) + acc[rt][qt][r];
-          }
-        if (gq == 0) {
-          const int e = (16 * rt + s) * (WM + 1) + WM;
-          sm[e] = (wv == 0 ? 0.0 : sm[e]) + rsum[rt];
-        }
-      }
+      for (int qt = 0; qt < JT; ++qt) rec[16 * qt + s] = acc[n][qt][r];
     }
-    __syncthreads();
+    if (gq == 0) {
+      const int row = 16 * rt + s;
+      part[((size_t)(row / (RPW * 16)) * gridDim.x + blockIdx.x) * GREC + (size_t)(row % (RPW * 16)) * (WM + 1) + WM] = rs;
+    }
   }
-  double* rec = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GREC;
-  for (int e = tid; e < GREC; e += TPB) rec[e] = sm[e];
 }
 
 // records -> their sum: a workgroup owns 4 elements, 64 slices of the records each; fixed order (bitwise reproducible).
@@ -1440,45 +892,10 @@ int pick_ncb(int out) {
 long ldw_of(long N) { return (N + 15) / 16 * 16; }
 int groups_of(int rows) { return (rows + RPW * 16 - 1) / (RPW * 16); }
 
-// geometry of the two-role head (k_bwd_head2_w) for a cell, or ok = false when the cell is outside its class: PWQuad up to 16 bins,
-// PWLin, AffineCoupling; rings + tiles within the LDS; the dW_L pairs within the GEMM waves' accumulators
-struct Head2Plan {
-  bool ok;
-  Head2 h;
-  size_t dyn;        // dynamic LDS bytes
-};
-Head2Plan head2_plan(int kind, int K, int T, int out, int R) {
-  Head2Plan hp;
-  hp.ok = false;
-  hp.dyn = 0;
-  memset(&hp.h, 0, sizeof(hp.h));
-  static const int off = getenv("NIS_BWD_HEAD2") ? atoi(getenv("NIS_BWD_HEAD2")) == 0 : 0;     // NIS_BWD_HEAD2=0: the one-role head + GEMM launch (A/B)
-  if (off) return hp;
-  if (WM > 32 || (kind == NIS_PWQUAD && K > 16)) return hp;     // (width 64: the roles do not fit 256 registers; keeps the one-wave-per-SIMD head)
-  const size_t fixed = (size_t)(BNLDS + NIS_EXP_N + NW * SREC) * sizeof(double) + NIS_MAX_DIM * sizeof(int) + 512;
-  for (int n = std::min(NCB, T >= 3 ? 4 : T >= 2 ? 2 : 1); n >= 1; n >>= 1) {
-    Head2 h;
-    h.ncb = n;
-    h.ncbat = (T + n - 1) / n;
-    h.rows_cb = n * out;
-    h.ntile_cb = (h.rows_cb + 15) / 16;
-    h.ngl = groups_of(R);
-    const size_t dyn = (size_t)NW * ((size_t)h.ntile_cb * 16 + 3 * WM) * TS * sizeof(double);
-    // (k_bwd_head2_w requests a batch's d a_L operands at once, NKMAX = 36 k-steps, and holds three row tiles of fragments per GEMM wave)
-    if (dyn + fixed > 160 * 1024 || h.ncbat * h.ntile_cb > NW * MAXP || h.rows_cb > 144 || h.ntile_cb + 1 > 3 * NW) continue;
-    hp.ok = true;
-    hp.h = h;
-    hp.dyn = dyn;
-    return hp;
-  }
-  return hp;
-}
-
 struct Plan {
   int nb;            // workgroups of the head / layer launches
-  int nb2;           // workgroups of the two-role head: one 512-thread workgroup per CU
   int ngl, ngh;      // row groups of the last-layer / hidden GEMMs
-  int nxl;           // sample chunks (workgroups in x) of the last layer's GEMM
+  int nxl, nsg;      // last layer's GEMM: workgroups over the sample tiles, blocks of NW * XRT row tiles (grid y)
   size_t part;       // doubles of the record area of the chain kernels (BatchNorm sums: nb x SREC)
   size_t partg;      // doubles of the record area of the weight-gradient GEMMs
 };
@@ -1488,13 +905,12 @@ Plan plan_for(int R, long N, int G) {         // the G minibatches of a launch (
   const int cus = device_cus();
   const long per_wg = (long)NW * 16 * ST;
   p.nb = (int)std::max<long>(1, std::min<long>((N + per_wg - 1) / per_wg, std::max<long>(1, (long)cus * 2 / G)));
-  p.nb2 = (int)std::max<long>(1, std::min<long>((N + per_wg - 1) / per_wg, std::max<long>(1, (long)cus / G)));
   p.ngl = groups_of(R);
   p.ngh = groups_of(WM);
-  const long tiles_wg = ((N + 15) / 16 + NW - 1) / NW;
-  p.nxl = (int)std::max<long>(1, std::min<long>(tiles_wg, std::max(1, cus * 2 / (p.ngl * G))));      // 2 resident workgroups per CU
+  p.nsg = (p.ngl * RPW + NW * XRT - 1) / (NW * XRT);
+  p.nxl = (int)std::max<long>(1, std::min<long>((N + 15) / 16, std::max(1, cus * 2 / (p.nsg * G))));      // 2 resident workgroups per CU
   p.part = (size_t)p.nb * SREC;
-  p.partg = std::max((size_t)p.ngl * std::max(p.nxl, p.nb2), (size_t)p.ngh * p.nb) * GREC;   // hidden layers / two-role head: one record per workgroup
+  p.partg = std::max((size_t)p.ngl * p.nxl, (size_t)p.ngh * p.nb) * GREC;      // hidden layers: one record per workgroup of k_bwd_layer_w
   return p;
 }
 }  // namespace
@@ -1511,8 +927,7 @@ size_t bwd_wide_workspace_doubles<NIS_WM>(const nis_cell_desc& cd, int64_t N, in
   const int out = cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K;
   const int R = T * out;
   const Plan p = plan_for(R, (long)N, G);
-  const size_t planes = head2_plan(cd.kind, cd.K, T, out, R).ok ? WM : 2 * WM + R;       // two-role head: dy only (no a_L / dZ planes)
-  return (size_t)G * (planes * ldw_of((long)N) + p.part + p.partg + (size_t)(cd.n_hidden + 2) * SREC +
+  return (size_t)G * ((size_t)(2 * WM + R) * ldw_of((long)N) + p.part + p.partg + (size_t)(cd.n_hidden + 2) * SREC +
                       (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC);
 }
 
@@ -1528,8 +943,7 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   const long ldw = ldw_of(N);                      // workspace planes: 16-sample aligned rows (vector loads in the GEMM)
   // per minibatch (blockIdx.z): planes [dy | a_L | dZ], then -- behind the planes of all minibatches -- the record areas, the
   // reduced BatchNorm sums and the reduced GEMM results, each G sets
-  const Head2Plan hp = head2_plan(c.kind, c.K, c.T, c.out, c.R);
-  const size_t wsp = (size_t)(hp.ok ? WM : 2 * WM + c.R) * ldw;
+  const size_t wsp = (size_t)(2 * WM + c.R) * ldw;
   const size_t nsum = (size_t)(L + 2) * SREC, ngem = (size_t)(p.ngl + L * p.ngh) * GREC;
   k.ldw = ldw;
   k.wsp_gs = (long)wsp;
@@ -1555,71 +969,40 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
     RedJob b = {partg, gemm_out, nx, GREC, ngroups, (long)p.partg, (long)ngem};
     hipLaunchKernelGGL(k_bwd_reduce2_w, dim3((GREC + 3) / 4, 1 + ngroups, Gz), dim3(TPB), 0, s, a, b);
   };
-  if (hp.ok) {
-    // two-role head: dW_L / db_L records come out of the head itself (no dZ / a_L planes, no GEMM launch)
-    w.nb = p.nb2;
-    cm.mf_ncb = hp.h.ncb;
-#define NIS_HEAD2(KIND, KMV, EX)                                                                                                  \
-  do {                                                                                                                            \
-    if (G > 1) hipLaunchKernelGGL((k_bwd_head2_w<KIND, KMV, EX, true>), dim3(p.nb2, 1, Gz), dim3(TPB2), hp.dyn, s, k, w, hp.h);    \
-    else hipLaunchKernelGGL((k_bwd_head2_w<KIND, KMV, EX, false>), dim3(p.nb2, 1, 1), dim3(TPB2), hp.dyn, s, k, w, hp.h);         \
-  } while (0)
-    if (c.kind == NIS_PWLIN)
-      NIS_HEAD2(NIS_PWLIN, 4, false);
-    else if (c.kind == NIS_AFFINE)
-      NIS_HEAD2(NIS_AFFINE, 4, false);
-    else if (c.K == 4)
-      NIS_HEAD2(NIS_PWQUAD, 4, true);
-    else if (c.K == 8)
-      NIS_HEAD2(NIS_PWQUAD, 8, true);
-    else if (c.K == 16)
-      NIS_HEAD2(NIS_PWQUAD, 16, true);
-    else if (c.K < 4)
-      NIS_HEAD2(NIS_PWQUAD, 4, false);
-    else if (c.K < 8)
-      NIS_HEAD2(NIS_PWQUAD, 8, false);
-    else
-      NIS_HEAD2(NIS_PWQUAD, 16, false);
-#undef NIS_HEAD2
-    reduce_pair(sums, p.nb2, p.ngl, p.nb2, glast);
-  } else {
-    cm.mf_ncb = pick_ncb(c.out);
-    if (cm.mf_ncb < 1) return NIS_E_UNSUPPORTED;
-    const size_t ring = ring_bytes(c.out, cm.mf_ncb);
-    const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : c.K <= 16 ? 16 : 32;
+  cm.mf_ncb = pick_ncb(c.out);
+  if (cm.mf_ncb < 1) return NIS_E_UNSUPPORTED;
+  const size_t ring = ring_bytes(c.out, cm.mf_ncb);
+  const int km = c.K <= 4 ? 4 : c.K <= 8 ? 8 : c.K <= 16 ? 16 : 32;
 #define NIS_HEAD(KIND, KMV, EX)                                                                                        \
   do {                                                                                                                 \
     if (G > 1) hipLaunchKernelGGL((k_bwd_head_w<KIND, KMV, EX, true>), dim3(p.nb, 1, Gz), dim3(TPB), ring, s, k, w);    \
     else hipLaunchKernelGGL((k_bwd_head_w<KIND, KMV, EX, false>), dim3(p.nb, 1, 1), dim3(TPB), ring, s, k, w);         \
   } while (0)
-    // (cells outside the two-role head's class: PWQuad with more than 16 bins, or too many rows for the GEMM waves' accumulators / the LDS)
-    if (c.kind == NIS_PWLIN)
-      NIS_HEAD(NIS_PWLIN, 4, false);
-    else if (c.kind == NIS_AFFINE)
-      NIS_HEAD(NIS_AFFINE, 4, false);
-    else if (c.K == 4)
-      NIS_HEAD(NIS_PWQUAD, 4, true);
-    else if (c.K == 8)
-      NIS_HEAD(NIS_PWQUAD, 8, true);
-    else if (c.K == 16)
-      NIS_HEAD(NIS_PWQUAD, 16, true);
-    else if (km == 4)
-      NIS_HEAD(NIS_PWQUAD, 4, false);
-    else if (km == 8)
-      NIS_HEAD(NIS_PWQUAD, 8, false);
-    else if (km == 16)
-      NIS_HEAD(NIS_PWQUAD, 16, false);
-    else if (c.K <= 32)
-      NIS_HEAD(NIS_PWQUAD, 32, false);
-    else
-      NIS_HEAD(NIS_PWQUAD, NIS_KM_BIG, false);
+  if (c.kind == NIS_PWLIN)
+    NIS_HEAD(NIS_PWLIN, 4, false);
+  else if (c.kind == NIS_AFFINE)
+    NIS_HEAD(NIS_AFFINE, 4, false);
+  else if (c.K == 4)
+    NIS_HEAD(NIS_PWQUAD, 4, true);
+  else if (c.K == 8)
+    NIS_HEAD(NIS_PWQUAD, 8, true);
+  else if (c.K == 16)
+    NIS_HEAD(NIS_PWQUAD, 16, true);
+  else if (km == 4)
+    NIS_HEAD(NIS_PWQUAD, 4, false);
+  else if (km == 8)
+    NIS_HEAD(NIS_PWQUAD, 8, false);
+  else if (km == 16)
+    NIS_HEAD(NIS_PWQUAD, 16, false);
+  else if (c.K <= 32)
+    NIS_HEAD(NIS_PWQUAD, 32, false);
+  else
+    NIS_HEAD(NIS_PWQUAD, NIS_KM_BIG, false);
 #undef NIS_HEAD
-    // dW_L = dZ a_L^T, db_L = row sums of dZ; then ONE launch reduces the head's BatchNorm sums and the GEMM's records
-    hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.ngl, Gz), dim3(TPB), 0, s, (const double*)k.dzp, c.R, c.R, (const double*)k.alp, N, partg, (long)wsp,
-                       (long)p.partg);
-    reduce_pair(sums, p.nb, p.ngl, p.nxl, glast);
-  }
-  w.nb = p.nb;
+  // dW_L = dZ a_L^T, db_L = row sums of dZ; then ONE launch reduces the head's BatchNorm sums and the GEMM's records
+  hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.nsg, Gz), dim3(TPB), 0, s, (const double*)k.dzp, c.R, (const double*)k.alp, N, partg, p.ngl,
+                     (long)wsp, (long)p.partg);
+  reduce_pair(sums, p.nb, p.ngl, p.nxl, glast);
   for (int l = L; l >= 1; --l) {
     const int pass = L - l + 1;
     k.sums = sums + (size_t)(pass - 1) * SREC;
