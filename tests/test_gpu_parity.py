@@ -2358,14 +2358,14 @@ def test_knife_edge_cell_bins_equal_the_oracle_wherever_the_ambiguity_flag_is_cl
     assert seen_flag >= 1, "this cell is the one with threshold widths: the flag must fire on it"
 
 
-def test_knife_edge_phase_space_point_newton_vs_lattice_bisection():
+def test_knife_edge_phase_space_point_stated_tolerance():
     """The other knife-edge sample of the shifted sweeps (NIS_TEST_SWEEP_SEED=27, case 33): a 2 -> 3 map with massive beams and one massive
-    leg whose batch holds a point at the edge of phase space, where the intermediate-mass equation v = (e+1) u^e - e u^(e+1) is flat
-    (g' -> 0 as v -> 1).  The kernel's monotone Newton iteration and the oracle's 120-180-level lattice bisection (the reference's,
-    flat_phase_space_generator.py:313-359) stop within a few ulp of v of each other, which the flat inverse magnifies to 6.7e-8 relative in
-    two momentum components -- the recorded deviation of DESIGN section 1 made concrete.  Tolerances stated: every component 1e-7 of the
-    event scale, all but a handful 1e-8, weights 1e-7; with the reference's own solver in the kernel at the depth the reference reaches for a
-    batch of this size (`bisect_levels=180`: three blocks of 60 levels, flat_phase_space_generator.py:327-357) the same batch meets 1e-9."""
+    leg, 8 385 points, in which TWO of 167 700 momentum components differ from the oracle by 6.7e-8 relative (everything else: 1e-8 and
+    better).  Not the solver: the kernel's monotone Newton iteration and its fixed-depth lattice bisection (`bisect_levels=180`, the depth
+    the reference's own bisection reaches for a batch of this size, flat_phase_space_generator.py:327-357) agree with EACH OTHER to 1e-10
+    on this batch (asserted), so the two components come from the decay / boost algebra the kernel evaluates in another order than the
+    reference (on-shell boost form, shared rho numerators, reciprocals) at a badly conditioned point.  Tolerances
+    stated: every component 1e-7 of the event scale, all but a handful 1e-8, weights 1e-7, identical cut decisions."""
     from nf_amd.PhaseSpace.flat_phase_space_generator import FlatInvertiblePhasespace
     init, final = [33.258424188333784, 7.969856530883729], [0.0, 0.0, 138.76266686521828]
     E, cuts, N = 11705.02016708497, (8.481629858856799, 0.574695152402175, 2.2981017231981884), 8385
@@ -2383,7 +2383,7 @@ def test_knife_edge_phase_space_point_newton_vs_lattice_bisection():
     gen_l = FlatInvertiblePhasespace(init, final, pdf=None, pdf_active=False, tau=False)
     gen_l.bisect_levels = 180
     mom_l, wgt_l = gen_l.generateKinematics_batch(E, rt, *cuts)
-    np.testing.assert_allclose(t2n(mom_l), ref_m, rtol=1e-9, atol=1e-9 * E)
+    np.testing.assert_allclose(t2n(mom_l), t2n(mom), rtol=1e-10, atol=1e-10 * E)
 
 
 def _random_rambo_shapes(n_cases, seed):
