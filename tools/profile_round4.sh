@@ -39,7 +39,6 @@ if [ $WHAT = all ] || [ $WHAT = train ]; then
   python3 tools/train_probe.py C2 2000 5 50 both 2>&1 | grep "^C" >> $OUT/r04_train_probe.txt
   python3 tools/train_probe.py C5 2e5 1 5 both 2>&1 | grep "^C" >> $OUT/r04_train_probe.txt
   python3 tools/train_probe.py C5 2000 5 20 both 2>&1 | grep "^C" >> $OUT/r04_train_probe.txt
-  NIS_BWD_HEAD2=0 python3 tools/train_probe.py C5 2e5 1 5 batched 2>&1 | grep "^C" | sed 's/^/one-role head + GEMM launch: /' >> $OUT/r04_train_probe.txt
   python3 tools/host_sections.py 2000 5 2>&1 | grep -v "Warn\|amdgpu" >> $OUT/r04_train_probe.txt
   tools/probe/rambo_traffic 1000000 40 > $OUT/r04_rambo_traffic_probe.txt 2>&1 || true
 fi
