@@ -284,7 +284,8 @@ def bench_config(name, rank, ws, dev, steps=6):
         # (64 #MFMA + 4 #VALU) / (1024 SIMDs x 2.4 GHz).  Counts per launch from the committed PMC pass (not counted in this run).
         ak = pmc.get("kernels", {}).get("k_cell_apply_mfma", {})
         if ak.get("mfma_insts") and ak.get("valu_insts") and ak.get("samples_per_launch"):
-            per = N * steps / max(kern_n, 1)                                   # samples one apply launch of THIS run covers (x its launch-set size)
+            n_cells = len(NF.best_model.engine().cells)
+            per = N * steps * n_cells / max(kern_n, 1)                         # samples ONE apply launch of this run covers: a launch set's iterations x N (one launch per cell and set)
             scale = per / ak["samples_per_launch"]
             cyc = (64.0 * ak["mfma_insts"] + 4.0 * (ak["valu_insts"] - ak["mfma_insts"])) * scale
             t_att = cyc / (1024 * 2.4e9)

@@ -100,7 +100,7 @@ int nis_env_int(const char* name, int dflt) {
 
 // exact common width of the hidden layers when a specialised instantiation exists (WM = 4: 3-wide nets), else 0
 static int cell_wx(const nis_cell_desc& cd, int WM) {
-  if (WM != 4 || cd.P > 3 || nis_env_int("NIS_NO_WX", 0)) return 0;
+  if (WM != 4 || cd.P > 3) return 0;
   for (int l = 0; l < cd.n_hidden; ++l)
     if (cd.width[l] > 3) return 0;
   return 3;
@@ -108,9 +108,8 @@ static int cell_wx(const nis_cell_desc& cd, int WM) {
 
 template <int WM>
 static void cell_grids(int kind, int km, int wx, bool folded, int G, int64_t N, int* gs, int* ga) {
-  static const int bs = nis_env_int("NIS_STATS_BPC", 0), ba = nis_env_int("NIS_APPLY_BPC", 0);   // tuning overrides
-  *gs = nis_grid_for(bs > 0 ? bs : stats_blocks_per_cu<WM>(wx, folded), G, N, nis_stats_tpb(WM));
-  *ga = nis_grid_for(ba > 0 ? ba : apply_blocks_per_cu<WM>(kind, km, wx), G, N, NIS_TPB);
+  *gs = nis_grid_for(stats_blocks_per_cu<WM>(wx, folded), G, N, nis_stats_tpb(WM));
+  *ga = nis_grid_for(apply_blocks_per_cu<WM>(kind, km, wx), G, N, NIS_TPB);
 }
 
 struct RunOpts {
@@ -183,7 +182,6 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
       HIP_OK(launch_stats<WM>(c, planes, ld, N, 0, c.dcov ? c.nparts[0] : grid_stats, s));
       if (int rc = sync_records(o, c.partials, c.nparts[0], WM, s)) return rc;
     }
-    if (!c.pmerge) HIP_OK(launch_finalize<WM>(c, 0, s));
     for (int l = 1; l <= c.L; ++l) {
       if (l == 1 && c.derive1) continue;                       // BN_1 was derived from BN_0 (single pass-through column)
       {
@@ -194,7 +192,6 @@ static int run_cell(const CellK& c, const MfmaW& mw, bool mfma, double* planes, 
           HIP_OK(launch_stats<WM>(c, planes, ld, N, l, grid_stats, s));
         if (int rc = sync_records(o, c.partials + (size_t)l * c.G * c.maxb * WM * 3, c.nparts[l], WM, s)) return rc;
       }
-      if (!c.pmerge) HIP_OK(launch_finalize<WM>(c, l, s));
     }
   }
   if (pre_apply) HIP_OK(hipEventRecord(pre_apply, s));      // the next chain of the set starts here (flow_run: staggered chains)
@@ -213,15 +210,11 @@ static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid, int
   *ok = WM >= 16 && use_mfma() && mfma_supported<WM>(c);
   // one wave owns 2 tiles of 16 samples per pass; 4 waves per workgroup
   const int per_wg = 4 * 16 * 2;
-  static const int bpc = nis_env_int("NIS_MFMA_BPC", 0);          // tuning override
-  *grid = *ok ? nis_grid_for(bpc > 0 ? bpc : mfma_blocks_per_cu<WM>(c), G, N, per_wg) : 1;
-  // the statistics kernels run on the apply kernel's grid.  They hold no LDS image and ~100 VGPRs, but more workgroups per CU
-  // (NIS_MFMA_STATS_BPC = 4, 6, 8) measured 0 ... 8 % SLOWER (C3 13.9 -> 14.2 ms, C5 7.6 -> 8.2 ms per iteration): every
-  // workgroup's prologue merges the previous layer's records, one per workgroup
-  static const int bpc_s = nis_env_int("NIS_MFMA_STATS_BPC", 0);
-  *grid_stats = *ok ? (bpc_s > 0 ? std::max(*grid, nis_grid_for(bpc_s, G, N, per_wg)) : *grid) : 1;
-  // the statistics kernels keep THEIR residency (two 256-thread workgroups per CU) whatever the apply kernel's workgroup shape is
-  if (*ok && bpc_s <= 0) *grid_stats = nis_grid_for(2, G, N, per_wg);
+  *grid = *ok ? nis_grid_for(mfma_blocks_per_cu<WM>(c), G, N, per_wg) : 1;
+  // the statistics kernels keep THEIR residency (two 256-thread workgroups per CU) whatever the apply kernel's workgroup shape is.  They
+  // hold no LDS image and ~100 VGPRs, but 4 / 6 / 8 workgroups per CU measured 0 ... 8 % SLOWER (round 2: C3 13.9 -> 14.2 ms, C5
+  // 7.6 -> 8.2 ms per iteration): every workgroup's prologue merges the previous layer's records, one per workgroup
+  *grid_stats = *ok ? nis_grid_for(2, G, N, per_wg) : 1;
 }
 
 // Descriptor-level mirror of launch_apply's SPEC conditions (flow_wm.hip): every cell of a d = 2 PWQuad chain with 3-wide
@@ -231,7 +224,6 @@ static bool direct_rows_ok(const nis_flow* f, const std::vector<CellLayout>& lay
       o.fres_out || o.sync_fn || o.f_kind != NIS_F_CAMEL || !o.out4)
     return false;
   if (o.bn_mode != NIS_BN_TRAIN) return false;     // eval mode: inner cells carry no BN_0 rider and run the generic kernel
-  if (nis_env_int("NIS_NO_FOLD", 0) || nis_env_int("NIS_NO_WX", 0) || nis_env_int("NIS_NO_DERIVE1", 0) || getenv("NIS_NO_STATS_FOLD")) return false;
   if (ingest_P != 1) return false;
   bool in_w[2] = {true, true};
   for (int ci = 0; ci < f->n_cells; ++ci) {
@@ -284,7 +276,6 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   // a matrix-core first cell with 2..8 pass-through columns takes its BN_0 records from the covariance pass (CellK::dcov: BN_1 is
   // derived, the layer-1 statistics launch disappears) instead of the ingest rider, which has no co-moments
   const bool cell0_cov = train && lay[0].WM >= 16 && use_mfma() && c0.n_hidden >= 2 && dcov_fits(c0.P, lay[0].WM) && !o.sync_fn &&
-                         !nis_env_int("NIS_NO_DERIVE1", 0) &&
                          !nis_env_int("NIS_NO_DCOV", 0);
   // ... unless the batch is DRAWN by the ingest launch (o.rng): that kernel holds a sample's whole row in registers and adds the
   // co-moments to its records, so the first cell needs neither the covariance pass nor its layer-1 statistics launch
@@ -395,7 +386,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     wrows_gs = 2 * plane_gs;
     // even N: the second plane starts 8-byte aligned.  Two cells only: an INNER cell writes its float64 output plane over the
     // float32 planes other workgroups still read (row layout: a thread overwrites exactly the row it has read, any chain length)
-    bool k4 = N % 2 == 0 && f->n_cells == 2 && !nis_env_int("NIS_NO_PLANAR", 0);
+    bool k4 = N % 2 == 0 && f->n_cells == 2;
     for (int ci = 0; ci < f->n_cells; ++ci) k4 = k4 && lay[ci].KM == -4;
     if (k4) wplane_ld = (long)N;
   }
@@ -409,7 +400,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
     is2.g0 = g0;
     // ingest / emit: 256-thread streaming workgroups, 8 per CU; the read-only record pass of the direct mode runs best at 4
     // (half the BN_0 records for the first statistics launch to merge: C2 bench 21.8e9 -> 22.2e9 samples/s)
-    const int tgrid = nis_grid_for(nis_env_int("NIS_INGEST_BPC", direct ? 4 : 8), Gg, N, NIS_TPB);
+    const int tgrid = nis_grid_for(direct ? 4 : 8, Gg, N, NIS_TPB);
     bool col_in_w[2] = {direct, direct};
     nis_prof_mark(NIS_K_INGEST, 1, cs);
     hipError_t ie;
@@ -439,7 +430,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       int grid_stats = 1, grid_apply = 1;
       switch (L.WM) {
         // folded statistics launches (k_bn_stats_fold): train mode, one pass-through column, BN_1 derived
-        case 4: cell_grids<4>(cd.kind, L.KM, cell_wx(cd, L.WM), train && cd.P == 1 && !nis_env_int("NIS_NO_DERIVE1", 0) && !nis_env_int("NIS_NO_FOLD", 0),
+        case 4: cell_grids<4>(cd.kind, L.KM, cell_wx(cd, L.WM), train && cd.P == 1,
                               Gg, N, &grid_stats, &grid_apply); break;
         case 8: cell_grids<8>(cd.kind, L.KM, 0, false, Gg, N, &grid_stats, &grid_apply); break;
         case 16: cell_grids<16>(cd.kind, L.KM, 0, false, Gg, N, &grid_stats, &grid_apply); break;
@@ -476,26 +467,26 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       c.status = status;
       c.coef_gs = train ? (cd.n_hidden + 1) * 2 * L.WM : 0;     // eval: every batch shares the running-stat coefficients
       c.plane_gs = plane_gs;
-      c.derive1 = (train && cd.P == 1 && !nis_env_int("NIS_NO_DERIVE1", 0)) ? 1 : 0;
+      c.derive1 = (train && cd.P == 1) ? 1 : 0;
       // matrix-core cells with 2..8 pass-through columns: BN_0's records carry the co-moments of the block, BN_1 is derived from
       // them and the layer-1 statistics launch is skipped (not with the multi-rank record exchange: its records are per feature)
       c.dcov = (train && mfma && cd.n_hidden >= 2 && dcov_fits(cd.P, L.WM) && !o.sync_fn &&
-                (have_stats0 == false || stats0_cov) && !nis_env_int("NIS_NO_DERIVE1", 0) && !nis_env_int("NIS_NO_DCOV", 0)) ? 1 : 0;
+                (have_stats0 == false || stats0_cov) && !nis_env_int("NIS_NO_DCOV", 0)) ? 1 : 0;
       if (c.dcov && have_stats0) {
         c.derive1 = 1;                  // the producing launch (ingest with in-kernel draws) already wrote them: nparts[0] = its grid
       } else if (c.dcov) {
         c.derive1 = 1;
         // the covariance pass is a latency-bound stream (8 loads, 44 FMAs per sample, <= 128 VGPRs): two workgroups per CU (four: equal at G = 3, slower at G = 1 -- every consumer merges the records)
-        static const int bpc_cov = nis_env_int("NIS_COV_BPC", 2);
+        constexpr int bpc_cov = 2;
         c.nparts[0] = nis_grid_for(bpc_cov, Gg, N, 256);
       }
       // single pass-through column on the fp64 VALU kernels: BN_0, Linear_0 and BN_1 collapse into one affine map of x
       // (needs the layer-1 statistics launch to be gone: train mode with derive1, or eval mode)
-      c.fold = (cd.P == 1 && !mfma && (c.derive1 || !train) && !nis_env_int("NIS_NO_FOLD", 0)) ? 1 : 0;
+      c.fold = (cd.P == 1 && !mfma && (c.derive1 || !train)) ? 1 : 0;
       c.wx = cell_wx(cd, L.WM);
       c.sync_part = o.sync_fn ? o.sync_buf : nullptr;
       c.sync_world = o.sync_world;
-      c.pmerge = (G == 1 || o.hist || !nis_env_int("NIS_FINALIZE_KERNEL", 0)) ? 1 : 0;   // a launch costs >= 4.3 us, the prologue merge ~1 us
+      c.pmerge = 1;                                  // a k_bn_finalize launch costs >= 4.3 us, the consumers' prologue merge ~1 us
       if (direct) {
         c.wrows = wrows;
         c.wrows_gs = wrows_gs;

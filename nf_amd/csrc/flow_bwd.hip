@@ -668,8 +668,7 @@ static bool bwd_fused_w(const nis_cell_desc& cd, int wm) { return wm == 4 && cd.
 // workgroups (x extent) of the chain launches: as many as are resident at once (head: 2 per CU at ~240 VGPRs, layer kernels: 3-4), so a
 // thread amortises its prologue (record merge) and epilogue (one wave reduction per accumulator) over as many samples as possible
 static int bwd_grid(int G, int64_t N, bool head) {
-  static const int bh = nis_env_int("NIS_BWD_BPC_HEAD", 2), bl = nis_env_int("NIS_BWD_BPC", 3);
-  return std::min(BMAXB, nis_grid_for(head ? bh : bl, G, N, NIS_TPB));
+  return std::min(BMAXB, nis_grid_for(head ? 2 : 3, G, N, NIS_TPB));
 }
 
 size_t nis_bwd_cell_params(const nis_cell_desc& cd) {

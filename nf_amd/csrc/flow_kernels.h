@@ -409,7 +409,7 @@ __global__ __launch_bounds__(TPB) void k_bn_stats(CellK c, const double* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = c.g0 + blockIdx.y;
   planes += (size_t)g * c.plane_gs;
-  // G == 1: the previous layer's records are merged here; G > 1: k_bn_finalize already published the coefficients
+  // the previous layer's records are merged here (every workgroup of batch g redoes the small tree merge: cheaper than a launch)
   const double w_fold = fold_weight<WM>(c);
   load_coefs<WM, TPB>(c, g, layer, c.pmerge ? cellk_fresh(c, layer) : -1, blockIdx.x == 0, lds_coef, red);
   fold_coefs<WM>(c, lds_coef, layer, w_fold);
@@ -751,15 +751,6 @@ __global__ __launch_bounds__(TPB) void k_bn_stats0_cov(CellK c, const double* __
   }
   __syncthreads();                                  // lsh
   cov_records_emit<TPB>(S1, S2, cnt, lsh, P, c.partials + (((size_t)0 * c.G + g) * c.maxb + blockIdx.x) * WM * 3);
-}
-
-// G > 1: one workgroup per batch merges the records of BN layer `layer` and publishes scale / shift (+ the batch
-// mean / unbiased variance for the running-statistics update), so consumers only read 2*WM coefficients.
-template <int WM>
-__global__ __launch_bounds__(1024) void k_bn_finalize(CellK c, int layer) {
-  __shared__ double lds_coef[(NIS_MAX_HIDDEN + 1) * 2 * WM];
-  __shared__ double red[3 * 1024];
-  load_coefs<WM, 1024>(c, c.g0 + blockIdx.x, layer + 1, layer, true, lds_coef, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1397,8 +1388,6 @@ int apply_blocks_per_cu(int kind, int km, int wx);
 template <int WM>
 hipError_t launch_stats(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s);
 template <int WM>
-hipError_t launch_finalize(const CellK& c, int layer, hipStream_t s);
-template <int WM>
 hipError_t launch_apply(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz, int grid,
                         hipStream_t s);
 // matrix-core path (WM >= 16): weight fragments pre-packed per (row tile, k-step) as 64 contiguous doubles
@@ -1432,8 +1421,6 @@ static inline int nis_mf_regmode(int kind, int K, int T, int wm) {
   int apply_blocks_per_cu<W>(int kind, int km, int wx);                                                                          \
   template <>                                                                                                               \
   hipError_t launch_stats<W>(const CellK& c, const double* planes, long ld, long N, int layer, int grid, hipStream_t s);    \
-  template <>                                                                                                               \
-  hipError_t launch_finalize<W>(const CellK& c, int layer, hipStream_t s);                                                  \
   template <>                                                                                                               \
   hipError_t launch_apply<W>(const CellK& c, double* planes, long ld, long N, int bn_train, int km, int* bins, const FuseF& fz, \
                              int grid, hipStream_t s);                                                                      \

@@ -31,7 +31,7 @@ hipError_t launch_stats<NIS_WM>(const CellK& c, const double* planes, long ld, l
   constexpr int TPB = nis_stats_tpb(NIS_WM);
 #if NIS_WM == 4
   if (c.wx == 3) {                       // every layer at most 3 wide (README / C1 / C2 nets): 3x3 blocks instead of 4x4
-    static const bool hoisted = getenv("NIS_NO_STATS_FOLD") == nullptr;
+    constexpr bool hoisted = true;
     const bool rows = c.wrows && c.x_wcol >= 0;        // pass-through column still lives in the float32 rows of w
     if (rows && !(c.P == 1 && c.fold && hoisted && layer >= 2 && layer <= 5)) return hipErrorInvalidValue;
     if (rows && c.wplanar) {
@@ -66,12 +66,6 @@ hipError_t launch_stats<NIS_WM>(const CellK& c, const double* planes, long ld, l
   return hipGetLastError();
 }
 
-template <>
-hipError_t launch_finalize<NIS_WM>(const CellK& c, int layer, hipStream_t s) {
-  hipLaunchKernelGGL((k_bn_finalize<NIS_WM>), dim3(c.Gy), dim3(1024), 0, s, c, layer);
-  return hipGetLastError();
-}
-
 template <typename K>
 static int stats_occ_of(K kern) {
   constexpr int TPB = nis_stats_tpb(NIS_WM);
@@ -97,7 +91,7 @@ int stats_blocks_per_cu<NIS_WM>(int wx, bool folded) {
 #if NIS_WM == 4
   // k_bn_stats_fold keeps NIS_STATS_U loads in flight per wave and pays its prologue once per workgroup: one 512-thread
   // workgroup per CU measured best (C2 bench: 20.5e9 samples/s at 1, 20.2 at 2, 19.5 at 4)
-  if (wx == 3 && folded && getenv("NIS_NO_STATS_FOLD") == nullptr) return 1;
+  if (wx == 3 && folded) return 1;
   if (wx == 3) {
     if (v[1] < 0) v[1] = stats_occ_of(k_bn_stats<NIS_WM, TPB, 3>);
     return v[1];
@@ -323,8 +317,6 @@ static const size_t MF_STATIC_LDS = 7 * 1024;            // static LDS of k_cell
 // columns per bijector batch: four (every lane busy in the bijector phase) unless the image of four columns leaves ONE workgroup
 // per CU while two or one column(s) would admit two -- one wave per SIMD hides nothing (C3 ran at 2x its MFMA + VALU time)
 static int mf_pick_ncb(const CellK& c) {
-  static const int forced = getenv("NIS_MF_NCB") ? atoi(getenv("NIS_MF_NCB")) : 0;
-  if (forced == 1 || forced == 2 || forced == 4) return forced;
   const int waves = (c.kind == NIS_PWLIN && NIS_MF_WAVES_LIN) ? NIS_MF_WAVES_LIN : NIS_MF_WAVES;
   for (int n = NIS_MF_NCB; n >= 1; n >>= 1)
     if (waves * (mf_ring_bytes_n(c, n) + MF_STATIC_LDS) <= 160 * 1024) return n;

@@ -237,8 +237,8 @@ struct CellK {
   long plane_gs;                         // doubles between the plane sets of consecutive g: (d+1)*ld
   const double* sync_part;               // non-null (multi-rank exact BatchNorm): the freshest layer's records are the `sync_world` per-rank
   int sync_world;                        //   records gathered here (one record per rank) instead of this launch set's workgroup records
-  int pmerge;                            // 1: consumers merge the records of the freshest BN layer in their prologue (every workgroup of
-                                         //    batch g redoes the small tree merge); 0: k_bn_finalize launches publish the coefficients
+  int pmerge;                            // 1 (always since round 4): consumers merge the records of the freshest BN layer in their prologue
+                                         //    (every workgroup of batch g redoes the small tree merge: cheaper than a finalize launch)
   double* gstat;                         // G > 1: (L+1) x G x 2 x WM  batch mean | unbiased var for k_group_epilogue
   // ---- direct row input (d = 2 chains on the SPEC kernels, float32 w): a column that no cell has written yet is read
   //      straight from the (N, 2) float32 rows of w -- the ingest launch then only gathers BN_0's records

@@ -657,14 +657,11 @@ static int rambo_launch(const nis_rambo_desc* dh, const nis_pdf1d* pdfh, const d
   const int LMh = 4 * (n + 2);
   const size_t lds_bytes = (size_t)RB_TPB * (LMh + 1) * sizeof(double);      // output staging only
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
-  static const int mult = getenv("NIS_RAMBO_GRID_MULT") ? atoi(getenv("NIS_RAMBO_GRID_MULT")) : 2;
-  // workgroups: `mult` x what the chip holds at once (shared by the G plane sets).  NIS_RAMBO_BALANCE=1: evenly loaded instead --
-  // ceil(tiles / rounds) workgroups of `rounds` tiles each (no partial last round)
-  int64_t ntiles_h = (N + RB_TPB - 1) / RB_TPB, cap = std::max<int64_t>(1, (int64_t)per_cu * 256 * mult / G);
+  // workgroups: twice what the chip holds at once (shared by the G plane sets).  An evenly loaded grid -- ceil(tiles / rounds) workgroups of
+  // `rounds` tiles each -- measured 7 % SLOWER in round 2 (55.1 vs 51.7 us per 1e6): oversubscribed workgroups balance better
+  int64_t ntiles_h = (N + RB_TPB - 1) / RB_TPB, cap = std::max<int64_t>(1, (int64_t)per_cu * 256 * 2 / G);
   if (mom_part) cap = std::min<int64_t>(cap, NIS_MAXB);                // one moment record per workgroup
-  const int64_t rounds = std::max<int64_t>(1, (ntiles_h + cap - 1) / cap);
-  static const int balance = getenv("NIS_RAMBO_BALANCE") ? 1 : 0;      // measured 7 % SLOWER (55.1 vs 51.7 us per 1e6): oversubscribed workgroups balance better
-  const int grid = (int)std::max<int64_t>(1, balance ? (ntiles_h + rounds - 1) / rounds : std::min<int64_t>(cap, ntiles_h));
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cap, ntiles_h));
   if (grid_out) *grid_out = grid;
   const bool has_pdf = (dh->flags & (NIS_RAMBO_PDF_ACTIVE | NIS_RAMBO_LAB_BOOST)) != 0;          // TAU only matters with PDFs
   const bool has_cuts = dh->pT_mincut > 0. || dh->delR_mincut > 0. || dh->rap_maxcut > 0.;
