@@ -113,9 +113,13 @@ static int occ_of(K kern) {
   int by_lds = at.sharedSizeBytes > 0 ? (int)(160 * 1024 / at.sharedSizeBytes) : 8;
   int n = waves < by_lds ? waves : (by_lds < 1 ? 1 : by_lds);
   // These kernels are fp64-issue bound: a CU works off its workgroups at the same rate with 2 or with 6 resident waves
-  // per SIMD, so MORE and smaller workgroups than fit at once only improve the balance between CUs (measured optimum
-  // for the C2 apply kernel: 5 per CU, 212 us vs 277 us at the 3 that are resident).
-  if (n < 5) n = 5;
+  // per SIMD, so MORE and smaller workgroups than fit at once only improve the balance between CUs (round 1: 5 per CU 212 us vs
+  // 277 us at the 3 that are resident; round-4 sweep of 5 / 6 / 9 / 12 / 15, profiles/r04_c2_attempts.txt: 6 -- two full rounds
+  // of the three resident workgroups -- is 1-2 % ahead of 5, 12 and 15 fall behind).
+#ifndef NIS_APPLY_MIN_BPC
+#define NIS_APPLY_MIN_BPC 6
+#endif
+  if (n < NIS_APPLY_MIN_BPC) n = NIS_APPLY_MIN_BPC;
   if (getenv("NIS_DEBUG_OCC")) fprintf(stderr, "[nis] apply kernel (WM %d): numRegs %d lds %zu -> %d workgroups/CU\n", NIS_WM, at.numRegs, (size_t)at.sharedSizeBytes, n);
   return n;
 }
