@@ -190,6 +190,26 @@ __device__ __forceinline__ void bww_stage(const BwdK& k, double* lds_bn, int* ld
   for (int idx = tid; idx < (k.c.L + 1) * 4 * WM; idx += TPB) lds_bn[idx] = k.bn[idx];
 }
 
+// Timing-only instrumentation (-DNIS_HEAD_STAMPS, never in the shipped library): wave 0 of workgroup 0 accumulates the 100 MHz clock per
+// phase of the head and prints the sums (tools/build_variant.sh headstamps "-DNIS_WM=32 -DNIS_HEAD_STAMPS" flow_bwd_wm flow_bwd_wm32).
+#ifdef NIS_HEAD_STAMPS
+#define HS_T0() unsigned long long hst = __builtin_amdgcn_s_memrealtime(), hsacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define HS_T(k)                                                        \
+  do {                                                                 \
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();   \
+    hsacc[k] += now - hst;                                             \
+    hst = now;                                                         \
+  } while (0)
+#define HS_PRINT()                                                                                                                        \
+  if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0)                                                                             \
+  printf("head: recompute %llu | last layer + exp %llu | bijector %llu | dZ store %llu | d a_L %llu | tail %llu (x10 ns)\n", hsacc[0], hsacc[1], \
+         hsacc[2], hsacc[3], hsacc[4], hsacc[5])
+#else
+#define HS_T0()
+#define HS_T(k)
+#define HS_PRINT()
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // head: recompute the cell, bijector adjoint -> dZ planes, d a_L = W_L^T dZ, dy_L, sums of BN_L, a_L planes
 // BATCH: the launch carries G > 1 minibatches as blockIdx.z.  Moving the kernel's pointers to minibatch g costs 15-30 VGPRs in these
@@ -217,6 +237,7 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
   // BN_L sums live in LDS (sm[wave]: sum dy | sum dy*xhat), updated once per tile: 32 registers less in the bijector phase
   if (lane < SREC / 2) sm[wave][lane] = 0.0, sm[wave][SREC / 2 + lane] = 0.0;
   const long wstride = (long)gridDim.x * NW * 16 * ST;
+  HS_T0();
   for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
     double H[KQ][ST], XH[KQ][ST];
     {
@@ -236,6 +257,7 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
           }
         }
     }
+    HS_T(0);
 #pragma unroll 1
     for (int st = 0; st < ST; ++st) {
       double Hs[KQ], XHs[KQ];
@@ -261,29 +283,47 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
       for (int cb = 0; cb * ncb < c.T; ++cb) {
         const int r0 = cb * ncb * out;
         const int r1 = min(c.R, r0 + ncb * out);
-        double fa[KQ];                                  // fragments of the row tile being multiplied (prefetched one tile ahead)
+        // Row tiles of this batch.  As in the forward kernel's tile loop (flow_mfma.h): the NEXT tile's bias rows are requested at once (z
+        // holds this tile's copy) and each A fragment right behind the MFMA that read it, into the same registers -- the chain is
+        // dependent, so the requests go out 64 cycles apart and have the rest of the chain plus the exp phase to land (round 3 loaded
+        // a second set of fragments up front: 16 registers more in a kernel that spills, and this loop ran at 2.1x its datapath time:
+        // stamps in DESIGN 4f).  Interior tiles write their four rows unguarded at immediate offsets off one pointer; only a batch's
+        // first / last tile (rows of the neighbouring batch, rows past R) takes the guarded form.
+        double fa[KQ];
+        nis_d4 zb;
+        {
+          const int jf = r0 / 16;
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) fa[q] = w.wm_last[((size_t)(r0 / 16) * KQ + q) * 64 + lane];
+          for (int q = 0; q < KQ; ++q) fa[q] = w.wm_last[((size_t)jf * KQ + q) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zb[r] = w.bias_pad[16 * jf + gq + 4 * r];
+        }
         for (int jt = r0 / 16; jt * 16 < r1; ++jt) {
-          double fb[KQ];
-          const int jn = (jt + 1) * 16 < r1 ? jt + 1 : jt;
+          const int jn = (jt + 1) * 16 < r1 ? jt + 1 : jt;       // (last tile: re-requests itself, unused)
+          nis_d4 z = zb;
 #pragma unroll
-          for (int q = 0; q < KQ; ++q) fb[q] = w.wm_last[((size_t)jn * KQ + q) * 64 + lane];
-          nis_d4 z;
+          for (int r = 0; r < 4; ++r) zb[r] = w.bias_pad[16 * jn + gq + 4 * r];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) z[r] = w.bias_pad[16 * jt + gq + 4 * r];
-#pragma unroll
-          for (int q = 0; q < KQ; ++q) z = mfma(fa[q], Hs[q], z);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = 16 * jt + gq + 4 * r - r0;
-            if (j >= 0 && j < ncb * out && 16 * jt + gq + 4 * r < c.R)
-              ring[j * 16 + s] = (KIND == NIS_AFFINE && (j & 1)) ? z[r] : nis_exp(z[r], etab);   // affine: odd rows = raw shift
+          for (int q = 0; q < KQ; ++q) {
+            z = mfma(fa[q], Hs[q], z);
+            fa[q] = w.wm_last[((size_t)jn * KQ + q) * 64 + lane];
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA ...
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // ... then one VMEM read
           }
+          double* rw = ring + (16 * jt + gq - r0) * 16 + s;          // row 16 jt + gq + 4 r of the batch's image -> rw[64 r]
+          if (16 * jt >= r0 && 16 * jt + 16 <= r1) {                  // (wave-uniform) every row of the tile belongs to this batch
 #pragma unroll
-          for (int q = 0; q < KQ; ++q) fa[q] = fb[q];
+            for (int r = 0; r < 4; ++r) rw[64 * r] = (KIND == NIS_AFFINE && ((gq - r0) & 1)) ? z[r] : nis_exp(z[r], etab);   // affine: odd rows = raw shift (16 jt + 4 r is even)
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = 16 * jt + gq + 4 * r - r0;
+              if (j >= 0 && j < ncb * out && 16 * jt + gq + 4 * r < c.R) rw[64 * r] = (KIND == NIS_AFFINE && (j & 1)) ? z[r] : nis_exp(z[r], etab);
+            }
+          }
         }
         __builtin_amdgcn_wave_barrier();
+        HS_T(1);
         // (sample s, column slot gq) per lane.  Lanes without a column / sample run on dummy data with zero incoming
         // gradients, so that the MFMAs below stay in wave-uniform control flow and receive dZ = 0 from them.
         const int t = cb * ncb + gq;
@@ -440,6 +480,7 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
             }
 #undef NIS_GV
 #undef NIS_GW0
+          HS_T(2);
           if (valid) {
 #pragma unroll
             for (int q = 0; q < KM + 1; ++q)
@@ -448,8 +489,10 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
             for (int q = 0; q < KM; ++q)
               if (KEXACT || q < K) k.dzp[tmx(c.R, row0 + K + 1 + q, i)] = W[q];
           }
+          HS_T(3);
           bww_da<KM + 1, KEXACT>(wrow, V, K + 1, da);
           bww_da<KM, KEXACT>(wrow + (size_t)(K + 1) * WM, W, K, da);
+          HS_T(4);
         } else if (KIND == NIS_AFFINE) {
           // AffineCoupling (coupling_cells.py:56-68); the ring holds [20^-1 s0 = exp(z0), z1] per column slot (rows interleaved
           // at pack time), the dZ planes and W_L^T use the blob's row order [scale | shift][T]
@@ -545,8 +588,10 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
           sm[wave][WM + j] += t2;
         }
       }
+      HS_T(5);
     }
   }
+  HS_PRINT();
   __syncthreads();
   if (tid < SREC) {
     double t = 0.0;
@@ -836,7 +881,7 @@ __global__ __launch_bounds__(TPB) void k_bwd_reduce2_w(RedJob a, RedJob b) {
 __global__ void k_bwd_scatter_w(CellK c, const double* __restrict__ sums, const double* __restrict__ glast,
                                 const double* __restrict__ ghid, int ngh, double* __restrict__ gparams, int hidden_bias,
                                 const double* __restrict__ bn, int G, long sums_gs, long gl_gs) {
-  const int L = c.L, tid = threadIdx.x, nth = blockDim.x;
+  const int L = c.L, tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;    // (a few workgroups: one alone took 20 us per cell)
   auto over_g = [&](const double* p, long gs) {
     double t = 0.0;
     for (int g = 0; g < G; ++g) t += p[(size_t)g * gs];
@@ -1016,7 +1061,7 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
     const int gi = (int)std::max<long>(1, std::min<long>((N + TPB - 1) / TPB, std::max<long>(1, (long)device_cus() * 8 / G)));
     hipLaunchKernelGGL(k_bwd_input_w, dim3(gi, 1, Gz), dim3(TPB), 0, s, k);
   }
-  hipLaunchKernelGGL(k_bwd_scatter_w, dim3(1), dim3(TPB), 0, s, c, (const double*)sums, (const double*)glast, (const double*)ghid, p.ngh,
+  hipLaunchKernelGGL(k_bwd_scatter_w, dim3(16), dim3(TPB), 0, s, c, (const double*)sums, (const double*)glast, (const double*)ghid, p.ngh,
                      gparams, c.kind == NIS_AFFINE ? (k.invN == 0.0 ? 2 : 1) : 0, k.bn, G, (long)nsum, (long)ngem);
   return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
 }
