@@ -827,16 +827,17 @@ __device__ __forceinline__ void pwquad_bin_divide(double xb, int K, const double
   *amb = near_x || zone;
 }
 
+// the division-free part of the search: bin and raw left edge from the multiplied-out tests; returns true when THIS lane's decision
+// needs the search with the divisions (an edge inside the 2^-50 band around x * wn, or a width at or below 2^-50 of the TOTAL -- a
+// superset of "of the running sum at its edge" -- that may tie two edges; one v_min per edge on this path)
 template <int KM, bool KEXACT>
-__device__ __forceinline__ void pwquad_bin_raw(double xb, int Krt, const double (&W)[KM], double wn, int* idx_out, double* run_out, bool* amb_out = nullptr) {
+__device__ __forceinline__ bool pwquad_bin_fast(double xb, int Krt, const double (&W)[KM], double wn, int* idx_out, double* run_out) {
   const int K = KEXACT ? KM : Krt;
   const double q = xb * wn;
   const double qlo = q * (1.0 - 0x1p-50), qhi = q * (1.0 + 0x1p-50);
   double run = 0.0, bestrun = 0.0;
   int idx = 0;
   bool ambany = false;
-  // a width at or below 2^-50 of the TOTAL (a superset of "of the running sum at its edge") may tie two edges: such columns take the
-  // search with the divisions as well, which also decides whether the sample is flagged ambiguous (one v_min per edge on this path)
   double wmin = wn;
   // the last edge is wn itself (same additions in the same order as the caller's sum): with x <= 1 - 1e-6 (every caller clamps, :167) it is
   // neither at or below q (1 - 2^-50) nor inside the band, so K - 1 edges are examined
@@ -852,14 +853,27 @@ __device__ __forceinline__ void pwquad_bin_raw(double xb, int Krt, const double 
       idx = up ? k + 1 : idx;
     }
   ambany |= !(wmin > wn * 0x1p-50);
+  *idx_out = idx;
+  *run_out = bestrun;
+  return ambany;
+}
+// Wsum2[idx] = bestrun / wn (:186, :198) must exceed the 1e-30 sentinel, else bin 0 with left edge 0 wins; tested on the raw sum
+// (equivalent unless the quotient is within an ulp of 1e-30); then the clamp of the index
+__device__ __forceinline__ void pwquad_bin_finish(int K, double wn, int* idx_io, double* run_io) {
+  const bool none = !(*run_io > 1e-30 * wn);
+  int idx = none ? 0 : *idx_io;
+  *run_io = none ? 0.0 : *run_io;
+  *idx_io = (idx > K - 1) ? K - 1 : idx;
+}
+template <int KM, bool KEXACT>
+__device__ __forceinline__ void pwquad_bin_raw(double xb, int Krt, const double (&W)[KM], double wn, int* idx_out, double* run_out, bool* amb_out = nullptr) {
+  const int K = KEXACT ? KM : Krt;
+  int idx;
+  double bestrun;
+  const bool ambany = pwquad_bin_fast<KM, KEXACT>(xb, Krt, W, wn, &idx, &bestrun);
   bool amb = false;
   if (__any(ambany)) pwquad_bin_divide<KM>(xb, K, W, wn, &idx, &bestrun, &amb);      // one wave-uniform test per column; practically never taken
-  // Wsum2[idx] = bestrun / wn (:186, :198) must exceed the 1e-30 sentinel, else bin 0 with left edge 0 wins; tested on
-  // the raw sum (equivalent unless the quotient is within an ulp of 1e-30)
-  const bool none = !(bestrun > 1e-30 * wn);
-  idx = none ? 0 : idx;
-  bestrun = none ? 0.0 : bestrun;
-  idx = (idx > K - 1) ? K - 1 : idx;
+  pwquad_bin_finish(K, wn, &idx, &bestrun);
   *idx_out = idx;
   *run_out = bestrun;                                    // raw cumulative width left of the bin
   if (amb_out) *amb_out = amb;
