@@ -58,13 +58,28 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
     const double gam_e = c.gb[(fresh * 2 + 0) * WM + j], be_e = c.gb[(fresh * 2 + 1) * WM + j];
     const double be00_e = d1 ? c.gb[1 * WM + 0] : 0.0, w0_e = d1 ? c.wp[(size_t)j * WM + 0] : 0.0;
     const double gam1_e = d1 ? c.gb[(1 * 2 + 0) * WM + j] : 0.0, be1_e = d1 ? c.gb[(1 * 2 + 1) * WM + j] : 0.0;
+    // this thread's records, EIGHT at a time: the 24 loads go out together and the sums are formed in record order afterwards (same
+    // arithmetic, same order -- bit-identical to a one-by-one loop, which is a chain of np / S dependent L2 round trips: with 512 records
+    // of a matrix-core launch that chain was ~40 us of EVERY statistics / apply launch, i.e. most of such a launch at 2e5 samples)
     double an = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int b = s; b < np; b += S) {
-      const double* q = part + ((size_t)b * WM + j) * 3;
-      const double n = q[0], dl = q[1] - ref;
-      an += n;
-      a1 = fma(n, dl, a1);
-      a2 += fma(n * dl, dl, q[2]);
+    for (int b0 = s; b0 < np; b0 += 8 * S) {
+      double qn[8], qm[8], q2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + u * S;
+        const double* q = part + ((size_t)(b < np ? b : s) * WM + j) * 3;
+        qn[u] = q[0];
+        qm[u] = q[1];
+        q2[u] = q[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (b0 + u * S < np) {
+          const double n = qn[u], dl = qm[u] - ref;
+          an += n;
+          a1 = fma(n, dl, a1);
+          a2 += fma(n * dl, dl, q2[u]);
+        }
     }
     red[(s * WM + j) * 3 + 0] = an;
     red[(s * WM + j) * 3 + 1] = a1;
@@ -156,10 +171,20 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
       double acc = 0.0;
       if (j < npair) {
         const double ra = part[pa * 3 + 1], rb = part[pb * 3 + 1];
-        for (int b = s; b < np; b += S) {
-          const double* q = part + (size_t)b * WM * 3;
-          const double nb = q[0];
-          acc += fma(nb * (q[pa * 3 + 1] - ra), q[pb * 3 + 1] - rb, q[3 * P + j]);
+        for (int b0 = s; b0 < np; b0 += 8 * S) {               // eight records' loads in flight, sums in record order (see above)
+          double qn[8], qa[8], qb[8], qc[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int b = b0 + u * S;
+            const double* q = part + (size_t)(b < np ? b : s) * WM * 3;
+            qn[u] = q[0];
+            qa[u] = q[pa * 3 + 1];
+            qb[u] = q[pb * 3 + 1];
+            qc[u] = q[3 * P + j];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (b0 + u * S < np) acc += fma(qn[u] * (qa[u] - ra), qb[u] - rb, qc[u]);
         }
       }
       red[s * WM + j] = acc;
