@@ -72,9 +72,20 @@ __device__ __forceinline__ void bw_dense(const double* __restrict__ wm, int nq, 
 
 // Forward recompute with the SAVED statistics up to BN layer `upto` (1..L).  Feature of H[q] / XH[q]: 4 q + (lane>>4).
 //   acc: pre-BN activations of BN_upto | H: input of Linear_{upto-1} | XH: normalised input of BN_{upto-1}
+constexpr int XPRE = 2;          // pass-through features 4 q + gq, q < XPRE (the first 8), of the NEXT tile a chain kernel may request ahead (bww_prefetch_x)
+__device__ __forceinline__ void bww_prefetch_x(const CellK& c, const double* __restrict__ x, long ld, long N, long base, const int* lds_plane,
+                                               double (&xp)[XPRE]) {
+  const int lane = threadIdx.x & 63, gq = lane >> 4, s = lane & 15;
+  const long i = base + s;
+#pragma unroll
+  for (int q = 0; q < XPRE; ++q) {
+    const int kf = 4 * q + gq;
+    xp[q] = (kf < c.P && i < N) ? x[(size_t)lds_plane[kf] * ld + i] : 0.0;
+  }
+}
 __device__ __forceinline__ void bww_forward(const CellK& c, const double* __restrict__ x, long ld, long N, long base, const int* lds_plane,
                                             const double* lds_bn, const double* __restrict__ wm_all, int upto, double (&H)[KQ][ST],
-                                            double (&XH)[KQ][ST], nis_d4 (&acc)[JT][ST]) {
+                                            double (&XH)[KQ][ST], nis_d4 (&acc)[JT][ST], const double* xpre = nullptr) {
   const int lane = threadIdx.x & 63, gq = lane >> 4, s = lane & 15;
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
@@ -85,7 +96,7 @@ __device__ __forceinline__ void bww_forward(const CellK& c, const double* __rest
 #pragma unroll
     for (int st = 0; st < ST; ++st) {
       const long i = base + 16 * st + s;
-      const double xv = (kv && i < N) ? x[pl + i] : 0.0;
+      const double xv = (xpre && q < XPRE && ST == 1) ? xpre[q < XPRE ? q : 0] : (kv && i < N) ? x[pl + i] : 0.0;
       H[q][st] = kv ? fma(xv, sc, sh) : 0.0;
       XH[q][st] = kv ? (xv - mu) * rs : 0.0;
     }
@@ -609,6 +620,13 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
   __shared__ double lds_m[SREC];
   __shared__ double sm[NW][SREC];
   __shared__ double stage[STAGE];                    // staging tiles; the epilogue's cross-wave sum of dW reuses it
+  // widths <= 32: the weights this launch multiplies with -- the fragments of the dense layers it recomputes (at most LW) and W_{l-1}
+  // row-major for d a -- are copied to LDS once per workgroup: every tile used to stream them from L2, one dependent round trip per layer
+  // (stamps: the recompute was 40 of a launch's 64 us at 2e5 samples)
+  constexpr int LW = 3;
+  constexpr bool LDSW = WM <= 32;
+  __shared__ double lds_w[LDSW ? LW * WM * WM : 1];
+  __shared__ double lds_wt[LDSW ? WM * WM : 1];
   if (BATCH) bww_batch(k, &w);
   const CellK& c = k.c;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
@@ -617,7 +635,14 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
   if (tid < SREC) lds_m[tid] = k.sums[tid] * k.invN;
   __syncthreads();
   const double* bnl = lds_bn + (size_t)l * 4 * WM;
+  const bool staged = LDSW && l <= LW;               // (wave-uniform)
+  if (staged) {
+    for (int e = threadIdx.x; e < l * WM * WM; e += TPB) lds_w[e] = w.wm_all[e];
+    for (int e = threadIdx.x; e < WM * WM; e += TPB) lds_wt[e] = c.wp[(size_t)(l - 1) * WM * WM + e];
+    __syncthreads();
+  }
   const double* wt = c.wp + (size_t)(l - 1) * WM * WM + (size_t)gq * WM + s;       // W_{l-1}[4 ks + gq][16 qt + s]
+  const double* wts = lds_wt + (size_t)gq * WM + s;                                 // ... its LDS copy
   const int nqt = l == 1 ? (c.P + 15) / 16 : JT;
   double a1[KQ], a2[KQ];
 #pragma unroll
@@ -631,11 +656,27 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
   double* const tdh = stage + (size_t)wave * 2 * WM * TS;
   double* const ta = tdh + WM * TS;
   const long wstride = (long)gridDim.x * NW * 16 * ST;
+  HS_T0();
+  // the first pass-through columns of the NEXT tile are requested while the current one is worked on (history planes: an HBM round trip
+  // in front of every recompute otherwise)
+  double xpre[XPRE];
+  bww_prefetch_x(c, k.x, ld, N, ((long)blockIdx.x * NW + wave) * 16 * ST, lds_plane, xpre);
   for (long base = ((long)blockIdx.x * NW + wave) * 16 * ST; base < N; base += wstride) {
     double H[KQ][ST], XH[KQ][ST], DH[KQ][ST];
     {
+      // the incoming dy of this tile does not depend on the recompute: requested first, so that its round trip (the plane the previous
+      // launch wrote) runs beside the hidden stack instead of behind it (stamps: 29 of a launch's 81 us sat in this wait)
+      double dyv[KQ];
+      {
+        const long i = base + s;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) dyv[q] = i < N ? k.dyp[tmx(WM, 16 * (q >> 2) + gq + 4 * (q & 3), i)] : 0.0;
+      }
       nis_d4 acc[JT][ST];
-      bww_forward(c, k.x, ld, N, base, lds_plane, lds_bn, w.wm_all, l, H, XH, acc);
+      if (staged) bww_forward(c, k.x, ld, N, base, lds_plane, lds_bn, lds_w, l, H, XH, acc, xpre);
+      else bww_forward(c, k.x, ld, N, base, lds_plane, lds_bn, w.wm_all, l, H, XH, acc, xpre);
+      bww_prefetch_x(c, k.x, ld, N, base + wstride, lds_plane, xpre);
+      HS_T(0);
 #pragma unroll
       for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
@@ -647,7 +688,7 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
             const long i = base + 16 * st + s;
             const bool iv = i < N;
             const double xh = (acc[jt][st][r] - mu) * rs;
-            const double dy = iv ? k.dyp[tmx(WM, j, i)] : 0.0;
+            const double dy = dyv[q];
             const double dh = iv ? sc * (dy - m1 - xh * m2) : 0.0;          // scale_l = gamma_l * rstd_l
             DH[q][st] = dh;
           }
@@ -657,6 +698,7 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
     // accesses are served in order) and come back with the SAMPLES on the MFMA k index -- lane (i, k) supplies d h[16 it + i][4 m + k],
     // a[16 jt + i][4 m + k].  Rows of samples past N carry d h = 0.
     static_assert(ST == 1, "one sample tile per wave pass");
+    HS_T(1);
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
       tdh[(4 * q + gq) * TS + s] = DH[q][0];
@@ -677,17 +719,27 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
       }
     }
     __builtin_amdgcn_wave_barrier();
+    HS_T(2);
 #pragma unroll
     for (int qt = 0; qt < JT; ++qt) {
       nis_d4 dacc[ST];
 #pragma unroll
       for (int st = 0; st < ST; ++st) dacc[st] = nis_d4{0.0, 0.0, 0.0, 0.0};
       if (qt < nqt) {
+        if (staged) {                                  // (two loops: one pointer of each address space, no flat loads)
 #pragma unroll
-        for (int ks = 0; ks < KQ; ++ks) {
-          const double a = wt[(size_t)(4 * ks) * WM + 16 * qt];
+          for (int ks = 0; ks < KQ; ++ks) {
+            const double a = wts[(4 * ks) * WM + 16 * qt];
 #pragma unroll
-          for (int st = 0; st < ST; ++st) dacc[st] = mfma(a, DH[ks][st], dacc[st]);
+            for (int st = 0; st < ST; ++st) dacc[st] = mfma(a, DH[ks][st], dacc[st]);
+          }
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < KQ; ++ks) {
+            const double a = wt[(size_t)(4 * ks) * WM + 16 * qt];
+#pragma unroll
+            for (int st = 0; st < ST; ++st) dacc[st] = mfma(a, DH[ks][st], dacc[st]);
+          }
         }
       }
 #pragma unroll
@@ -703,7 +755,13 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
         }
       }
     }
+    HS_T(3);
   }
+#ifdef NIS_HEAD_STAMPS
+  if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+    printf("layer %d: recompute %llu | dy load + BN backward %llu | LDS stage + dW %llu | d a + dy store + sums %llu (x10 ns)\n", l, hsacc[0], hsacc[1],
+           hsacc[2], hsacc[3]);
+#endif
   bww_emit_sums(a1, a2, sm, k.part + (size_t)blockIdx.x * SREC);
   // dW records: wave after wave into one image (fixed summation order), then the workgroup's record in the GEMM's layout
   // (row groups of RPW * 16 rows x (WM + 1); the row-sum column stays zero: no bias behind a hidden Linear's BatchNorm)

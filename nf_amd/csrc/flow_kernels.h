@@ -62,10 +62,11 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
     // arithmetic, same order -- bit-identical to a one-by-one loop, which is a chain of np / S dependent L2 round trips: with 512 records
     // of a matrix-core launch that chain was ~40 us of EVERY statistics / apply launch, i.e. most of such a launch at 2e5 samples)
     double an = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int b0 = s; b0 < np; b0 += 8 * S) {
-      double qn[8], qm[8], q2[8];
+    constexpr int RB = 8;                         // (16: no faster, and the prologue's registers start to spill in the matrix-core kernels)
+    for (int b0 = s; b0 < np; b0 += RB * S) {
+      double qn[RB], qm[RB], q2[RB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < RB; ++u) {
         const int b = b0 + u * S;
         const double* q = part + ((size_t)(b < np ? b : s) * WM + j) * 3;
         qn[u] = q[0];
@@ -73,7 +74,7 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
         q2[u] = q[2];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < RB; ++u)
         if (b0 + u * S < np) {
           const double n = qn[u], dl = qm[u] - ref;
           an += n;
