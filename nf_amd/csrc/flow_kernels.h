@@ -62,7 +62,7 @@ __device__ __forceinline__ void load_coefs(const CellK& c, int g, int upto, int 
     // arithmetic, same order -- bit-identical to a one-by-one loop, which is a chain of np / S dependent L2 round trips: with 512 records
     // of a matrix-core launch that chain was ~40 us of EVERY statistics / apply launch, i.e. most of such a launch at 2e5 samples)
     double an = 0.0, a1 = 0.0, a2 = 0.0;
-    constexpr int RB = 8;                         // (16: no faster, and the prologue's registers start to spill in the matrix-core kernels)
+    constexpr int RB = 8;                         // (16 measured no faster)
     for (int b0 = s; b0 < np; b0 += RB * S) {
       double qn[RB], qm[RB], q2[RB];
 #pragma unroll
