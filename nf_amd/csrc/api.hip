@@ -313,24 +313,44 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
   };
   for (int ci = 0; ci < f->n_cells; ++ci)
     if (!params[ci] || !running[ci]) return NIS_E_ARG;
-  if (repack) {
+  if (repack) {                       // ONE launch for all cells (k_pack_cells)
     size_t bn_pack_off = 0;
+    std::vector<PackJob> jobs(f->n_cells);
     for (int ci = 0; ci < f->n_cells; ++ci) {
       const nis_cell_desc& cd = f->cells[ci];
       const CellLayout& L = lay[ci];
-      const CellK c = cell_shape(ci);
-      double* bns = (o.hist && !train && o.bnsave) ? o.bnsave + bn_pack_off : nullptr;
+      PackJob& j = jobs[ci];
+      memset(&j, 0, sizeof(j));
+      j.prm = params[ci];
+      j.run = (const double*)running[ci];
+      j.wp = body + L.off_wp;
+      j.wlast = body + L.off_wlast;
+      j.bias = body + L.off_bias;
+      j.gb = body + L.off_gb;
+      j.hb = body + L.off_hb;
+      j.coef = body + L.off_coef;
+      j.bnsave = (o.hist && !train && o.bnsave) ? o.bnsave + bn_pack_off : nullptr;
       bn_pack_off += (size_t)(cd.n_hidden + 1) * 4 * L.WM;
-      const int pgrid = (int)std::min<size_t>(64, ((size_t)c.R * L.WM + NIS_TPB - 1) / NIS_TPB);
-      NisProfScope ps(NIS_K_PACK, s);
-      HIP_OK(nis_launch_pack(c, L.WM, params[ci], (const double*)running[ci], train ? 0 : 1, body + L.off_wp, body + L.off_wlast,
-                             body + L.off_bias, body + L.off_gb, body + L.off_hb, cell_hidden_bias(cd) ? 1 : 0, bns, pgrid, s));
+      j.WM = L.WM;
+      j.P = cd.P;
+      j.L = cd.n_hidden;
+      j.R = cell_R(cd);
+      j.RT = L.RT;
+      for (int l = 0; l < cd.n_hidden; ++l) j.width[l] = cd.width[l];
+      j.eval_mode = train ? 0 : 1;
+      j.hidden_bias = cell_hidden_bias(cd) ? 1 : 0;
       if (L.WM >= 16 && use_mfma()) {
-        HIP_OK(nis_launch_pack_mfma(L.WM, c.L, c.R, L.RT, body + L.off_wp, body + L.off_wlast, body + L.off_bias, body + L.off_wm,
-                                    body + L.off_wmlast, body + L.off_biaspad, cd.kind == NIS_AFFINE ? d - cd.P : 0,
-                                    nis_mf_regmode(cd.kind, cd.K, d - cd.P, L.WM), d - cd.P, cd.K, pgrid, s));
+        j.wm_all = body + L.off_wm;
+        j.wm_last = body + L.off_wmlast;
+        j.bias_pad = body + L.off_biaspad;
+        j.affT = cd.kind == NIS_AFFINE ? d - cd.P : 0;
+        j.regmode = nis_mf_regmode(cd.kind, cd.K, d - cd.P, L.WM);
+        j.T = d - cd.P;
+        j.K = cd.K;
       }
     }
+    NisProfScope ps(NIS_K_PACK, s);
+    HIP_OK(nis_launch_pack_cells(jobs, s));
   }
   auto packed_done = [&]() {
     f->packed_token = o.pack_token;
@@ -809,14 +829,14 @@ static size_t bwd_pack_doubles(const nis_cell_desc& cd, size_t WM) {
   return n;
 }
 
-// doubles of one call's adjoint scratch: gradient planes of the G minibatches, the largest cell workspace, the packed parameter image
+// doubles of one call's adjoint scratch: gradient planes of the G minibatches, the largest cell workspace, the packed parameter images
 static void bwd_ws_layout(const nis_flow* f, int G, int64_t N, size_t* gplanes, size_t* cellws, size_t* pk) {
   std::vector<CellLayout> lay;
   nis_flow_layout(f, 1, &lay, nullptr);
   *cellws = *pk = 0;
   for (int ci = 0; ci < f->n_cells; ++ci) {
     *cellws = std::max(*cellws, nis_bwd_cell_workspace_doubles(f->cells[ci], lay[ci].WM, N, G));
-    *pk = std::max(*pk, bwd_pack_doubles(f->cells[ci], lay[ci].WM));
+    *pk += (bwd_pack_doubles(f->cells[ci], lay[ci].WM) + 15) / 16 * 16;          // every cell its own image: packed in one launch
   }
   *gplanes = ((size_t)G * (f->d + 1) * N + 15) / 16 * 16;          // 128-byte aligned: the wide adjoint uses vector loads
   *cellws = (*cellws + 15) / 16 * 16;
@@ -874,6 +894,41 @@ static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld
     m.col[d] = d;
     HIP_OK(nis_launch_scatter_rows(gxj, (long)N, d + 1, m, g, (long)N, tgrid, s));
   }
+  // parameter images of all cells (reference row order, train-mode BatchNorm affine): one launch, every cell its own region of `pk`
+  std::vector<PackJob> jobs(f->n_cells);
+  {
+    double* at = pk;
+    for (int ci = 0; ci < f->n_cells; ++ci) {
+      const nis_cell_desc& cd = f->cells[ci];
+      const size_t WM = lay[ci].WM, R = cell_R(cd), nl = cd.n_hidden, RT = (R + 15) / 16;
+      PackJob& j = jobs[ci];
+      memset(&j, 0, sizeof(j));
+      j.prm = params[ci];
+      j.wp = at;
+      j.wlast = j.wp + nl * WM * WM;
+      j.bias = j.wlast + R * WM;
+      j.gb = j.bias + (R + 7) / 8 * 8;
+      j.coef = j.gb + (nl + 1) * 2 * WM;
+      double* end = j.coef + (nl + 1) * 2 * WM;
+      j.WM = (int)WM;
+      j.P = cd.P;
+      j.L = cd.n_hidden;
+      j.R = (int)R;
+      j.RT = (int)RT;
+      for (int l = 0; l < cd.n_hidden; ++l) j.width[l] = cd.width[l];
+      j.hidden_bias = cell_hidden_bias(cd) ? 1 : 0;
+      if (WM >= 16) {
+        j.wm_all = end;
+        j.wm_last = j.wm_all + nl * WM * WM;
+        j.bias_pad = j.wm_last + RT * 16 * WM;
+        end = j.bias_pad + RT * 16;
+        j.affT = cd.kind == NIS_AFFINE ? d - cd.P : 0;
+      }
+      if ((size_t)(end - at) != bwd_pack_doubles(cd, WM)) return NIS_E_ARG;
+      at += (bwd_pack_doubles(cd, WM) + 15) / 16 * 16;
+    }
+    HIP_OK(nis_launch_pack_cells(jobs, s));
+  }
   const size_t bn_total = nis_flow_bnsave_count(f);
   size_t bn_off = bn_total;
   for (int ci = f->n_cells - 1; ci >= 0; --ci) {
@@ -896,32 +951,16 @@ static int flow_backward_impl(nis_flow* f, const double* planes_hist, int64_t ld
     c.first = (ci == 0 && !w_has_jac) ? 1 : 0;
     c.G = 1;
     c.Gy = 1;
-    const size_t WM = L.WM, R = c.R, nl = c.L;
-    double* wp = pk;
-    double* wlast = wp + nl * WM * WM;
-    double* bias = wlast + R * WM;
-    double* gb = bias + (R + 7) / 8 * 8;
-    double* coef = gb + (nl + 1) * 2 * WM;
-    c.wp = wp;
-    c.wlast = wlast;
-    c.bias = bias;
-    c.gb = gb;
-    c.coef = coef;
-    HIP_OK(nis_launch_pack(c, (int)WM, params[ci], nullptr, 0, wp, wlast, bias, gb, nullptr, cell_hidden_bias(cd) ? 1 : 0, nullptr,
-                           WM >= 16 ? 32 : 1, s));
+    const PackJob& pj = jobs[ci];
+    c.wp = pj.wp;
+    c.wlast = pj.wlast;
+    c.bias = pj.bias;
+    c.gb = pj.gb;
+    c.coef = pj.coef;
     MfmaW mw;
-    mw.wm_all = mw.wm_last = mw.bias_pad = nullptr;
-    if (WM >= 16) {
-      const size_t RT = (R + 15) / 16;
-      double* wm_all = coef + (nl + 1) * 2 * WM;
-      double* wm_last = wm_all + nl * WM * WM;
-      double* bias_pad = wm_last + RT * 16 * WM;
-      HIP_OK(nis_launch_pack_mfma((int)WM, c.L, c.R, (int)RT, wp, wlast, bias, wm_all, wm_last, bias_pad, cd.kind == NIS_AFFINE ? d - cd.P : 0,
-                                  0, 0, 0, 32, s));
-      mw.wm_all = wm_all;
-      mw.wm_last = wm_last;
-      mw.bias_pad = bias_pad;
-    }
+    mw.wm_all = pj.wm_all;
+    mw.wm_last = pj.wm_last;
+    mw.bias_pad = pj.bias_pad;
     int rc = nis_bwd_cell_run(c, cd, L.WM, planes_hist + (size_t)ci * set, planes_hist + (size_t)(ci + 1) * set, g, bnsave + bn_off,
                               (long)ld, (long)N, G, hist_gs, set, seed.eval_bn ? 0L : (long)bn_total, cellws, gparams[ci], mw,
                               seed.eval_bn, s);

@@ -58,10 +58,19 @@ int nis_env_int(const char* name, int dflt);
 static inline int nis_stream_grid(int64_t N) { return (int)std::max<int64_t>(1, std::min<int64_t>(NIS_MAXB, (N + NIS_TPB - 1) / NIS_TPB)); }
 
 // ---- api_pack.hip
-hipError_t nis_launch_pack(const CellK& c, int WM, const double* prm, const double* run, int eval_mode, double* wp, double* wlast,
-                           double* bias, double* gb, double* hb, int hidden_bias, double* bnsave, int grid, hipStream_t s);
-hipError_t nis_launch_pack_mfma(int WM, int L, int R, int RT, const double* wp, const double* wlast, const double* bias, double* wm_all,
-                                double* wm_last, double* bias_pad, int affT, int regmode, int T, int K, int grid, hipStream_t s);
+// one cell's parameter images (api_pack.hip, k_pack_cells)
+struct PackJob {
+  const double *prm, *run;                                   // the cell's parameter blob; running statistics (eval mode)
+  double *wp, *wlast, *bias, *gb, *hb, *coef, *bnsave;       // hb, bnsave optional; coef: eval mode
+  double *wm_all, *wm_last, *bias_pad;                       // matrix-core fragment images (nullptr: none)
+  int WM, P, L, R, RT, width[NIS_MAX_HIDDEN];
+  int eval_mode, hidden_bias, affT, regmode, T, K;
+};
+#define NIS_PACK_CELLS 16
+struct PackJobs {
+  PackJob j[NIS_PACK_CELLS];
+};
+hipError_t nis_launch_pack_cells(const std::vector<PackJob>& jobs, hipStream_t s);
 
 // ---- api_ingest.hip
 struct ColMap {

@@ -106,46 +106,54 @@ extern "C" size_t nis_flow_workspace_bytes(const nis_flow* f, int64_t n_batches)
   return WS_HEADER + nis_flow_layout(f, G, nullptr, nullptr) * sizeof(double);
 }
 // ---------------------------------------------------------------------------------------------
-// k_pack: reference-order parameter blob -> zero-padded WM-strided weights (+ eval-mode BN affine).
-__global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double* __restrict__ prm, const double* __restrict__ run,
-                                                  int eval_mode, double* wp, double* wlast, double* bias, double* gb, double* hb,
-                                                  int hidden_bias, double* bnsave) {
+// k_pack_cells: reference-order parameter blobs -> the images the kernels read, for up to NIS_PACK_CELLS cells per launch (grid.y):
+//   zero-padded WM-strided weights wp / wlast / bias, the BatchNorm affine gb (+ hb, + eval-mode coefficients and the adjoint's saved
+//   record), and for the matrix-core kernels (wm_all != nullptr) the per-(row tile, k-step) fragments of 64 contiguous doubles, lane l
+//   holding W[16 jt + (l & 15)][4 q + (l >> 4)] (the A operand of v_mfma_f64_16x16x4_f64), all taken from the blob directly.
+//   affT > 0 (NIS_AFFINE with T transformed columns): the last layer's rows [scale | shift][T] are interleaved to [t][scale, shift], so
+//   that a column's outputs are contiguous like those of the piecewise cells.  regmode == NIS_PACK_REL: the relative image of a PWQuad
+//   last layer (nis_common.h, nis_rel_row).
+// One launch per optimizer step and direction instead of two per cell (the launches were 5 us each, in series: 0.17 ms of a C5 step).
+__global__ __launch_bounds__(NIS_TPB) void k_pack_cells(PackJobs J) {
+  const PackJob& c = J.j[blockIdx.y];
   const int tid = blockIdx.x * NIS_TPB + threadIdx.x, nth = gridDim.x * NIS_TPB;
+  const int WM = c.WM;
   size_t off = 0;
   int roff = 0;
+  auto feat = [&](int l) { return l == 0 ? c.P : c.width[l - 1]; };
   for (int l = 0; l <= c.L; ++l) {
-    const int F = cellk_feat(c, l);
+    const int F = feat(l);
     const int O = l < c.L ? c.width[l] : c.R;
-    const double* gam = prm + off;
-    const double* bet = prm + off + F;
-    const double* W = prm + off + 2 * F;
+    const double* gam = c.prm + off;
+    const double* bet = c.prm + off + F;
+    const double* W = c.prm + off + 2 * F;
     // bias of the Linear that FEEDS this BN layer (NIS_AFFINE): the kernels evaluate the Linear without it -- a constant
     // in front of a BatchNorm cancels -- and account for it where it is visible: the running mean and the eval-mode shift
-    const double* hbin = (hidden_bias && l >= 1) ? prm + off - F : nullptr;
+    const double* hbin = (c.hidden_bias && l >= 1) ? c.prm + off - F : nullptr;
     for (int j = tid; j < WM; j += nth) {
       const double g = j < F ? gam[j] : 0.0, b = j < F ? bet[j] : 0.0;
       const double hbv = (hbin && j < F) ? hbin[j] : 0.0;
-      gb[(l * 2 + 0) * WM + j] = g;
-      gb[(l * 2 + 1) * WM + j] = b;
-      if (hb) hb[l * WM + j] = hbv;
-      if (eval_mode) {                       // BatchNorm1d.eval(): running statistics
+      c.gb[(l * 2 + 0) * WM + j] = g;
+      c.gb[(l * 2 + 1) * WM + j] = b;
+      if (c.hb) c.hb[l * WM + j] = hbv;
+      if (c.eval_mode) {                     // BatchNorm1d.eval(): running statistics
         double sc = 0.0, sh = 0.0;
         if (j < F) {
-          sc = g / sqrt(run[roff + F + j] + NIS_BN_EPS);
-          sh = b - (run[roff + j] - hbv) * sc;
+          sc = g / sqrt(c.run[roff + F + j] + NIS_BN_EPS);
+          sh = b - (c.run[roff + j] - hbv) * sc;
         }
         c.coef[(l * 2 + 0) * WM + j] = sc;
         c.coef[(l * 2 + 1) * WM + j] = sh;
-        if (bnsave) {                        // eval-mode forward with history: what the adjoint reads (scale | shift | mean | rstd)
-          bnsave[(l * 4 + 0) * WM + j] = sc;
-          bnsave[(l * 4 + 1) * WM + j] = sh;
-          bnsave[(l * 4 + 2) * WM + j] = j < F ? run[roff + j] - hbv : 0.0;
-          bnsave[(l * 4 + 3) * WM + j] = j < F ? 1.0 / sqrt(run[roff + F + j] + NIS_BN_EPS) : 0.0;
+        if (c.bnsave) {                      // eval-mode forward with history: what the adjoint reads (scale | shift | mean | rstd)
+          c.bnsave[(l * 4 + 0) * WM + j] = sc;
+          c.bnsave[(l * 4 + 1) * WM + j] = sh;
+          c.bnsave[(l * 4 + 2) * WM + j] = j < F ? c.run[roff + j] - hbv : 0.0;
+          c.bnsave[(l * 4 + 3) * WM + j] = j < F ? 1.0 / sqrt(c.run[roff + F + j] + NIS_BN_EPS) : 0.0;
         }
       }
     }
     if (l < c.L) {
-      double* dst = wp + (size_t)l * WM * WM;
+      double* dst = c.wp + (size_t)l * WM * WM;
       for (int e = tid; e < WM * WM; e += nth) {
         const int j = e / WM, i = e % WM;
         dst[e] = (j < O && i < F) ? W[(size_t)j * F + i] : 0.0;
@@ -153,71 +161,74 @@ __global__ __launch_bounds__(NIS_TPB) void k_pack(CellK c, int WM, const double*
     } else {
       for (size_t e = tid; e < (size_t)c.R * WM; e += nth) {
         const int r = (int)(e / WM), i = (int)(e % WM);
-        wlast[e] = (i < F) ? W[(size_t)r * F + i] : 0.0;
+        c.wlast[e] = (i < F) ? W[(size_t)r * F + i] : 0.0;
       }
       const double* bs = W + (size_t)O * F;
-      for (int r = tid; r < c.R; r += nth) bias[r] = bs[r];
+      for (int r = tid; r < c.R; r += nth) c.bias[r] = bs[r];
     }
     off += 2 * (size_t)F + (size_t)O * F;
-    if (l < c.L && hidden_bias) off += O;
+    if (l < c.L && c.hidden_bias) off += O;
     roff += 2 * F;
   }
-}
-
-// k_pack_mfma: padded row-major images -> per-(row tile, k-step) fragments of 64 contiguous doubles, lane l holding
-// W[16 jt + (l & 15)][4 q + (l >> 4)]  (the A operand of v_mfma_f64_16x16x4_f64).
-// affT > 0 (NIS_AFFINE with T transformed columns): the last layer's rows [scale | shift][T] are interleaved to
-// [t][scale, shift], so that a column's outputs are contiguous like those of the piecewise cells.
-// regmode == NIS_PACK_REL: the relative image of a PWQuad last layer (nis_common.h, nis_rel_row).
-// T, K: transformed columns and bins of the cell.
-__global__ __launch_bounds__(NIS_TPB) void k_pack_mfma(int WM, int L, int R, int RT, const double* __restrict__ wp,
-                                                       const double* __restrict__ wlast, const double* __restrict__ bias,
-                                                       double* __restrict__ wm_all, double* __restrict__ wm_last,
-                                                       double* __restrict__ bias_pad, int affT, int regmode, int T, int K) {
-  const size_t tid = (size_t)blockIdx.x * NIS_TPB + threadIdx.x, nth = (size_t)gridDim.x * NIS_TPB;
-  const int JT = WM / 16, KQ = WM / 4;
-  const size_t nh = (size_t)L * WM * WM;
-  for (size_t e = tid; e < nh; e += nth) {
-    const int lane = (int)(e & 63);
-    const size_t frag = e >> 6;
-    const int q = (int)(frag % KQ), jt = (int)((frag / KQ) % JT), l = (int)(frag / ((size_t)KQ * JT));
-    const int j = 16 * jt + (lane & 15), k = 4 * q + (lane >> 4);
-    wm_all[e] = wp[(size_t)l * WM * WM + (size_t)j * WM + k];
+  if (!c.wm_all) return;
+  const int KQ = WM / 4;
+  size_t offw = 0;                                          // blob offset of layer l's weight matrix
+  for (int l = 0; l <= c.L; ++l) {
+    const int F = feat(l), O = l < c.L ? c.width[l] : c.R;
+    offw += 2 * (size_t)F;
+    if (l == c.L) break;
+    for (size_t e = tid; e < (size_t)WM * WM; e += nth) {
+      const int lane = (int)(e & 63);
+      const size_t frag = e >> 6;
+      const int q = (int)(frag % KQ), jt = (int)(frag / KQ);
+      const int j = 16 * jt + (lane & 15), k = 4 * q + (lane >> 4);
+      c.wm_all[(size_t)l * WM * WM + e] = (j < O && k < F) ? c.prm[offw + (size_t)j * F + k] : 0.0;
+    }
+    offw += (size_t)O * F + (c.hidden_bias ? O : 0);
   }
-  const size_t nl = (size_t)RT * KQ * 64;
+  const int FL = feat(c.L);
+  const double* WL = c.prm + offw;
+  const double* bs = WL + (size_t)c.R * FL;
+  auto rows_of = [&](int j, int* js) {                      // packed row j <- blob row (minus blob row *js); < 0: a zero row
+    int jo = c.affT > 0 ? (j & 1) * c.affT + (j >> 1) : j;
+    *js = -1;
+    if (c.regmode == NIS_PACK_REL) jo = nis_rel_row(c.T, c.K, j, js);
+    else if (j >= c.R) return -1;
+    return (jo >= 0 && jo < c.R) ? jo : -1;
+  };
+  const size_t nl = (size_t)c.RT * KQ * 64;
   for (size_t e = tid; e < nl; e += nth) {
     const int lane = (int)(e & 63);
     const size_t frag = e >> 6;
     const int q = (int)(frag % KQ), jt = (int)(frag / KQ);
     const int j = 16 * jt + (lane & 15), k = 4 * q + (lane >> 4);
-    int jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;                // packed row j <- blob row jo
-    int js = -1;
-    if (regmode == NIS_PACK_REL) jo = nis_rel_row(T, K, j, &js);
-    double v = (regmode ? jo >= 0 && jo < R : j < R) ? wlast[(size_t)jo * WM + k] : 0.0;
-    if (js >= 0) v -= wlast[(size_t)js * WM + k];
-    wm_last[e] = v;
+    int js;
+    const int jo = rows_of(j, &js);
+    double v = (jo >= 0 && k < FL) ? WL[(size_t)jo * FL + k] : 0.0;
+    if (js >= 0 && k < FL) v -= WL[(size_t)js * FL + k];
+    c.wm_last[e] = v;
   }
-  for (size_t e = tid; e < (size_t)RT * 16; e += nth) {
-    const int j = (int)e;
-    int jo = affT > 0 ? (j & 1) * affT + (j >> 1) : j;
-    int js = -1;
-    if (regmode == NIS_PACK_REL) jo = nis_rel_row(T, K, j, &js);
-    double v = (regmode ? jo >= 0 && jo < R : e < (size_t)R) ? bias[jo] : 0.0;
-    if (js >= 0) v -= bias[js];
-    bias_pad[e] = v;
+  for (size_t e = tid; e < (size_t)c.RT * 16; e += nth) {
+    int js;
+    const int jo = rows_of((int)e, &js);
+    double v = jo >= 0 ? bs[jo] : 0.0;
+    if (js >= 0) v -= bs[js];
+    c.bias_pad[e] = v;
   }
 }
 
-hipError_t nis_launch_pack(const CellK& c, int WM, const double* prm, const double* run, int eval_mode, double* wp, double* wlast,
-                           double* bias, double* gb, double* hb, int hidden_bias, double* bnsave, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_pack, dim3(std::max(1, grid)), dim3(NIS_TPB), 0, s, c, WM, prm, run, eval_mode, wp, wlast, bias, gb, hb, hidden_bias,
-                     bnsave);
-  return hipGetLastError();
-}
-
-hipError_t nis_launch_pack_mfma(int WM, int L, int R, int RT, const double* wp, const double* wlast, const double* bias, double* wm_all,
-                                double* wm_last, double* bias_pad, int affT, int regmode, int T, int K, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_pack_mfma, dim3(std::max(1, grid)), dim3(NIS_TPB), 0, s, WM, L, R, RT, wp, wlast, bias, wm_all, wm_last, bias_pad, affT,
-                     regmode, T, K);
+// jobs of any number of cells: NIS_PACK_CELLS per launch
+hipError_t nis_launch_pack_cells(const std::vector<PackJob>& jobs, hipStream_t s) {
+  for (size_t at = 0; at < jobs.size(); at += NIS_PACK_CELLS) {
+    PackJobs J;
+    const int n = (int)std::min<size_t>(NIS_PACK_CELLS, jobs.size() - at);
+    size_t most = 0;
+    for (int i = 0; i < n; ++i) {
+      J.j[i] = jobs[at + i];
+      most = std::max(most, (size_t)std::max(jobs[at + i].R, jobs[at + i].RT * 16) * jobs[at + i].WM);
+    }
+    const int grid = (int)std::min<size_t>(32, (most + NIS_TPB - 1) / NIS_TPB);
+    hipLaunchKernelGGL(k_pack_cells, dim3(std::max(1, grid), n), dim3(NIS_TPB), 0, s, J);
+  }
   return hipGetLastError();
 }

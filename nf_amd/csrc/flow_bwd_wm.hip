@@ -788,12 +788,71 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
   }
 }
 
-// BN_0 backward: gradient of the pass-through columns
-__global__ __launch_bounds__(TPB) void k_bwd_input_w(BwdK k) {
+// Reduced records -> gradient blob in the reference's parameter order (include/nis_hip.h).
+//   sums : pass p (0 = head, L - l + 1 = layer kernel l) holds the sums of BN_{L-p}: [sum dy | sum dy xhat]
+//   glast: GEMM result of the last Linear (row groups of GREC); ghid + m*ngh*GREC: of hidden Linear m
+// hidden_bias (NIS_AFFINE): 1 = train-mode BatchNorm, 2 = eval mode (`bn`: the saved scale | shift | mean | rstd records).
+// G minibatches: minibatch g's reduced records sit sums_gs / gl_gs doubles behind minibatch g - 1's; the blob receives their SUM.
+// Runs as extra workgroups of the cell's LAST chain launch (k_bwd_input_w: both only read the reduced records): as a launch of its own
+// it cost 7 us per cell at one minibatch and 21 us at five.
+struct ScatterW {
+  const double *sums, *glast, *ghid, *bn;
+  double* gparams;
+  int ngh, hidden_bias, G, nblk;
+  long sums_gs, gl_gs;
+};
+__device__ __forceinline__ void bww_scatter(const CellK& c, const ScatterW& a, int tid, int nth) {
+  const int L = c.L, G = a.G;
+  auto over_g = [&](const double* p, long gs) {          // minibatch order; four loads in flight
+    double t = 0.0;
+    int g = 0;
+    for (; g + 4 <= G; g += 4) {
+      const double v0 = p[(size_t)g * gs], v1 = p[(size_t)(g + 1) * gs], v2 = p[(size_t)(g + 2) * gs], v3 = p[(size_t)(g + 3) * gs];
+      t += v0;
+      t += v1;
+      t += v2;
+      t += v3;
+    }
+    for (; g < G; ++g) t += p[(size_t)g * gs];
+    return t;
+  };
+  size_t off = 0;
+  for (int l = 0; l <= L; ++l) {
+    const int F = cellk_feat(c, l);
+    const int O = l < L ? c.width[l] : c.R;
+    const double* sl = a.sums + (size_t)(L - l) * SREC;
+    for (int j = tid; j < F; j += nth) {
+      a.gparams[off + j] = over_g(sl + WM + j, a.sums_gs);
+      a.gparams[off + F + j] = over_g(sl + j, a.sums_gs);
+    }
+    off += 2 * (size_t)F;
+    const double* src = l < L ? a.ghid + (size_t)l * a.ngh * GREC : a.glast;
+    for (int e = tid; e < O * F; e += nth) {
+      const int r = e / F, q = e % F;
+      a.gparams[off + e] = over_g(src + (size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + q, a.gl_gs);
+    }
+    off += (size_t)O * F;
+    if (a.hidden_bias && l < L) {          // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0;
+      const double* s1 = a.sums + (size_t)(L - l - 1) * SREC;      // eval mode: scale_{l+1} * sum dy_{l+1}  (one BatchNorm record for all minibatches)
+      for (int e = tid; e < O; e += nth) a.gparams[off + e] = a.hidden_bias == 2 ? a.bn[((l + 1) * 4 + 0) * WM + e] * over_g(s1 + e, a.sums_gs) : 0.0;
+      off += O;
+    }
+  }
+  for (int r = tid; r < c.R; r += nth)
+    a.gparams[off + r] = over_g(a.glast + (size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + WM, a.gl_gs);
+}
+
+// BN_0 backward: gradient of the pass-through columns (workgroups [0, gridDim.x - sa.nblk)); the rest: bww_scatter
+__global__ __launch_bounds__(TPB) void k_bwd_input_w(BwdK k, ScatterW sa) {
+  const int gi = (int)gridDim.x - sa.nblk;
+  if ((int)blockIdx.x >= gi) {
+    if (blockIdx.z == 0) bww_scatter(k.c, sa, ((int)blockIdx.x - gi) * TPB + threadIdx.x, sa.nblk * TPB);
+    return;
+  }
   bww_batch(k, nullptr);
   const CellK& c = k.c;
   const double invN = k.invN;
-  const long stride = (long)gridDim.x * TPB;
+  const long stride = (long)gi * TPB;
   for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < k.N; i += stride)
     for (int p = 0; p < c.P; ++p) {
       const size_t at = (size_t)c.in_plane[p] * k.ld + i;
@@ -853,13 +912,16 @@ __global__ __launch_bounds__(TPB, 2) void k_bwd_xty_w(const double* __restrict__
 #pragma unroll
     for (int qt = 0; qt < JT; ++qt) acc[n][qt] = nis_d4{0.0, 0.0, 0.0, 0.0};
   }
+  // tiles in DESCENDING order: the head wrote the high tiles last, and what is left of them in the Infinity Cache is read before it is
+  // evicted (135 -> 117 us per C5 cell at 2e5; the kernel is bound by its reads either way: with the MFMAs removed it takes 132 us, and
+  // staging the tiles through LDS in whole rows -- global_load_lds, swizzled image, ds_read_b128 fragments -- gave 120 us in this order)
   const long ntiles = (N + 15) / 16, tstride = gridDim.x;
-  long tile = blockIdx.x;
+  long tile = ntiles - 1 - blockIdx.x;
   XtyOps cur, nxt;
-  if (tile < ntiles) xty_load(Ap, R, rt0, Bp, N, tile, cur);
-  for (; tile < ntiles; tile += tstride) {
-    const bool more = tile + tstride < ntiles;
-    if (more) xty_load(Ap, R, rt0, Bp, N, tile + tstride, nxt);
+  if (tile >= 0) xty_load(Ap, R, rt0, Bp, N, tile, cur);
+  for (; tile >= 0; tile -= tstride) {
+    const bool more = tile - tstride >= 0;
+    if (more) xty_load(Ap, R, rt0, Bp, N, tile - tstride, nxt);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -929,46 +991,6 @@ __global__ __launch_bounds__(TPB) void k_bwd_reduce2_w(RedJob a, RedJob b) {
     __syncthreads();
   }
   if (slice == 0 && e < j.nacc) out[(size_t)y * j.nacc + e] = sm[0][el];
-}
-
-// Reduced records -> gradient blob in the reference's parameter order (include/nis_hip.h).
-//   sums : pass p (0 = head, L - l + 1 = layer kernel l) holds the sums of BN_{L-p}: [sum dy | sum dy xhat]
-//   glast: GEMM result of the last Linear (row groups of GREC); ghid + m*ngh*GREC: of hidden Linear m
-// hidden_bias (NIS_AFFINE): 1 = train-mode BatchNorm, 2 = eval mode (`bn`: the saved scale | shift | mean | rstd records).
-// G minibatches: minibatch g's reduced records sit sums_gs / gl_gs doubles behind minibatch g - 1's; the blob receives their SUM.
-__global__ void k_bwd_scatter_w(CellK c, const double* __restrict__ sums, const double* __restrict__ glast,
-                                const double* __restrict__ ghid, int ngh, double* __restrict__ gparams, int hidden_bias,
-                                const double* __restrict__ bn, int G, long sums_gs, long gl_gs) {
-  const int L = c.L, tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;    // (a few workgroups: one alone took 20 us per cell)
-  auto over_g = [&](const double* p, long gs) {
-    double t = 0.0;
-    for (int g = 0; g < G; ++g) t += p[(size_t)g * gs];
-    return t;
-  };
-  size_t off = 0;
-  for (int l = 0; l <= L; ++l) {
-    const int F = cellk_feat(c, l);
-    const int O = l < L ? c.width[l] : c.R;
-    const double* sl = sums + (size_t)(L - l) * SREC;
-    for (int j = tid; j < F; j += nth) {
-      gparams[off + j] = over_g(sl + WM + j, sums_gs);
-      gparams[off + F + j] = over_g(sl + j, sums_gs);
-    }
-    off += 2 * (size_t)F;
-    const double* src = l < L ? ghid + (size_t)l * ngh * GREC : glast;
-    for (int e = tid; e < O * F; e += nth) {
-      const int r = e / F, q = e % F;
-      gparams[off + e] = over_g(src + (size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + q, gl_gs);
-    }
-    off += (size_t)O * F;
-    if (hidden_bias && l < L) {          // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0;
-      const double* s1 = sums + (size_t)(L - l - 1) * SREC;      // eval mode: scale_{l+1} * sum dy_{l+1}  (one BatchNorm record for all minibatches)
-      for (int e = tid; e < O; e += nth) gparams[off + e] = hidden_bias == 2 ? bn[((l + 1) * 4 + 0) * WM + e] * over_g(s1 + e, sums_gs) : 0.0;
-      off += O;
-    }
-  }
-  for (int r = tid; r < c.R; r += nth)
-    gparams[off + r] = over_g(glast + (size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + WM, gl_gs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1117,9 +1139,8 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   k.sums = sums + (size_t)L * SREC;
   {
     const int gi = (int)std::max<long>(1, std::min<long>((N + TPB - 1) / TPB, std::max<long>(1, (long)device_cus() * 8 / G)));
-    hipLaunchKernelGGL(k_bwd_input_w, dim3(gi, 1, Gz), dim3(TPB), 0, s, k);
+    ScatterW sa = {sums, glast, ghid, k.bn, gparams, p.ngh, c.kind == NIS_AFFINE ? (k.invN == 0.0 ? 2 : 1) : 0, G, 32, (long)nsum, (long)ngem};
+    hipLaunchKernelGGL(k_bwd_input_w, dim3(gi + sa.nblk, 1, Gz), dim3(TPB), 0, s, k, sa);
   }
-  hipLaunchKernelGGL(k_bwd_scatter_w, dim3(16), dim3(TPB), 0, s, c, (const double*)sums, (const double*)glast, (const double*)ghid, p.ngh,
-                     gparams, c.kind == NIS_AFFINE ? (k.invN == 0.0 ? 2 : 1) : 0, k.bn, G, (long)nsum, (long)ngem);
   return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
 }
