@@ -214,7 +214,7 @@ static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid, int
   // the statistics kernels keep THEIR residency (two 256-thread workgroups per CU) whatever the apply kernel's workgroup shape is.  They
   // hold no LDS image and ~100 VGPRs, but 4 / 6 / 8 workgroups per CU measured 0 ... 8 % SLOWER (round 2: C3 13.9 -> 14.2 ms, C5
   // 7.6 -> 8.2 ms per iteration): every workgroup's prologue merges the previous layer's records, one per workgroup
-  *grid_stats = *ok ? nis_grid_for(2, G, N, per_wg) : 1;
+  *grid_stats = *ok ? nis_grid_for(2, G, N, per_wg) : 1;      // (one per CU: C5 training step -1 %, C3 / C4 / C5 iterations +4 / +2 / +2.5 %)
 }
 
 // Descriptor-level mirror of launch_apply's SPEC conditions (flow_wm.hip): every cell of a d = 2 PWQuad chain with 3-wide

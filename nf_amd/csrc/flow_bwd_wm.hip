@@ -965,7 +965,7 @@ struct RedJob {
   long part_gs, out_gs;
 };
 __global__ __launch_bounds__(TPB) void k_bwd_reduce2_w(RedJob a, RedJob b) {
-  __shared__ double sm[64][4];
+  __shared__ double sm[NW][4];
   const bool second = (int)blockIdx.y >= a.ny;
   const RedJob& j = second ? b : a;
   const int y = (int)blockIdx.y - (second ? a.ny : 0);
@@ -973,23 +973,22 @@ __global__ __launch_bounds__(TPB) void k_bwd_reduce2_w(RedJob a, RedJob b) {
   const int e = blockIdx.x * 4 + el;
   const double* part = j.part + (size_t)blockIdx.z * j.part_gs + (size_t)y * j.nparts * j.nacc;
   double* out = j.out + (size_t)blockIdx.z * j.out_gs;
-  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-  if (e < j.nacc) {
-    int b_ = slice;
-    for (; b_ + 192 < j.nparts; b_ += 256) {
-      t0 += part[(size_t)b_ * j.nacc + e];
-      t1 += part[(size_t)(b_ + 64) * j.nacc + e];
-      t2 += part[(size_t)(b_ + 128) * j.nacc + e];
-      t3 += part[(size_t)(b_ + 192) * j.nacc + e];
+  double t = 0.0;
+  if (e < j.nacc) {                                   // eight records per round trip (512 records: one), summed in record order
+    for (int b0 = slice; b0 < j.nparts; b0 += 512) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = b0 + 64 * u < j.nparts ? part[(size_t)(b0 + 64 * u) * j.nacc + e] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += v[u];
     }
-    for (; b_ < j.nparts; b_ += 64) t0 += part[(size_t)b_ * j.nacc + e];
   }
-  sm[slice][el] = (t0 + t1) + (t2 + t3);
+  // the 64 slices of an element: 16 inside each wave (lanes differing in bits 2..5), then the four waves' partials
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+  if ((threadIdx.x & 63) < 4) sm[threadIdx.x >> 6][el] = t;
   __syncthreads();
-  for (int h = 32; h > 0; h >>= 1) {
-    if (slice < h) sm[slice][el] += sm[slice + h][el];
-    __syncthreads();
-  }
+  if (slice == 0) sm[0][el] = (sm[0][el] + sm[1][el]) + (sm[2][el] + sm[3][el]);
   if (slice == 0 && e < j.nacc) out[(size_t)y * j.nacc + e] = sm[0][el];
 }
 
