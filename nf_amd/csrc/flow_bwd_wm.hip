@@ -1016,14 +1016,42 @@ int pick_ncb(int out) {
 long ldw_of(long N) { return (N + 15) / 16 * 16; }
 int groups_of(int rows) { return (rows + RPW * 16 - 1) / (RPW * 16); }
 
+// side stream of the last-layer GEMM (one per process: the library is driven from one thread)
+struct Side {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+Side& side() {                                   // per device; created on first use (never inside a stream capture: a captured step is
+  static Side sd[32];                            // preceded by its eager warm-up run)
+  static bool tried[32] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+  Side& d = sd[dev];
+  if (!tried[dev]) {
+    tried[dev] = true;
+    d.ok = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&d.join, hipEventDisableTiming) == hipSuccess;
+  }
+  return d;
+}
+
 struct Plan {
-  int nb;            // workgroups of the head / layer launches
+  int nb;            // workgroups of the head launch
+  int nbl;           // workgroups of the layer launches
+  bool side;         // the last layer's GEMM runs beside the layer chain (bwd_wide_run)
   int ngl, ngh;      // row groups of the last-layer / hidden GEMMs
   int nxl, nsg;      // last layer's GEMM: workgroups over the sample tiles, blocks of NW * XRT row tiles (grid y)
   size_t part;       // doubles of the record area of the chain kernels (BatchNorm sums: nb x SREC)
-  size_t partg;      // doubles of the record area of the weight-gradient GEMMs
+  size_t partx;      // doubles of the record area of the last layer's GEMM (its own: that launch runs beside the layer chain)
+  size_t parth;      // doubles of the record area of the hidden layers' weight gradients (one record per workgroup of k_bwd_layer_w)
 };
 
+// share of the chip the side-stream GEMM takes, in quarter workgroups per CU (the layer launches get the remaining slots); measured at
+// C5 / 2e5: 1 -> 8.96 ms per step (the GEMM becomes the critical path), 2 -> 7.42, 3 -> 7.33, 4 -> 7.45, 5 -> 7.40, 6 -> 7.45
+constexpr int XTY_WG_PER_CU4 = 3;
+constexpr long SIDE_MIN_SAMPLES = 65536;
 Plan plan_for(int R, long N, int G) {         // the G minibatches of a launch (blockIdx.z) share the chip
   Plan p;
   const int cus = device_cus();
@@ -1032,9 +1060,15 @@ Plan plan_for(int R, long N, int G) {         // the G minibatches of a launch (
   p.ngl = groups_of(R);
   p.ngh = groups_of(WM);
   p.nsg = (p.ngl * RPW + NW * XRT - 1) / (NW * XRT);
-  p.nxl = (int)std::max<long>(1, std::min<long>((N + 15) / 16, std::max(1, cus * 2 / (p.nsg * G))));      // 2 resident workgroups per CU
+  // big batches: the last layer's GEMM on the side stream, ONE of its workgroups per CU and one of the layer kernel's in the other slot
+  // (two rounds of 256 layer workgroups would pay the launch's prologue twice).  Small batches keep one stream: the fork / join costs
+  // more than the GEMM's few microseconds (C5 topology, 5 x 2000: 2.4 -> 2.8 ms per step with it)
+  p.side = (long)N * G >= SIDE_MIN_SAMPLES;
+  p.nxl = (int)std::max<long>(1, std::min<long>((N + 15) / 16, std::max(1, cus * (p.side ? XTY_WG_PER_CU4 : 8) / 4 / (p.nsg * G))));
+  p.nbl = p.side ? (int)std::max<long>(1, std::min<long>(p.nb, ((long)cus * 2 - (long)p.nxl * p.nsg * G) / G)) : p.nb;      // the slots the GEMM leaves
   p.part = (size_t)p.nb * SREC;
-  p.partg = std::max((size_t)p.ngl * p.nxl, (size_t)p.ngh * p.nb) * GREC;      // hidden layers: one record per workgroup of k_bwd_layer_w
+  p.partx = (size_t)p.ngl * p.nxl * GREC;
+  p.parth = (size_t)p.ngh * p.nbl * GREC;
   return p;
 }
 }  // namespace
@@ -1051,7 +1085,7 @@ size_t bwd_wide_workspace_doubles<NIS_WM>(const nis_cell_desc& cd, int64_t N, in
   const int out = cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K;
   const int R = T * out;
   const Plan p = plan_for(R, (long)N, G);
-  return (size_t)G * ((size_t)(2 * WM + R) * ldw_of((long)N) + p.part + p.partg + (size_t)(cd.n_hidden + 2) * SREC +
+  return (size_t)G * ((size_t)(2 * WM + R) * ldw_of((long)N) + p.part + p.partx + p.parth + (size_t)(cd.n_hidden + 2) * SREC +
                       (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC);
 }
 
@@ -1077,21 +1111,23 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   k.alp = ws + (size_t)WM * ldw;
   k.dzp = ws + (size_t)2 * WM * ldw;
   double* part = ws + (size_t)G * wsp;
-  double* partg = part + (size_t)G * p.part;
-  double* sums = partg + (size_t)G * p.partg;
+  double* partx = part + (size_t)G * p.part;
+  double* parth = partx + (size_t)G * p.partx;
+  double* sums = parth + (size_t)G * p.parth;
   double* glast = sums + (size_t)G * nsum;                 // minibatch g: glast + g * ngem, its hidden-layer results ngl * GREC behind
   double* ghid = glast + (size_t)p.ngl * GREC;
   k.part = part;
   k.sums = nullptr;
-  w.partg = partg;
-  w.partg_gs = (long)p.partg;
-  w.nb = p.nb;
+  w.partg = parth;
+  w.partg_gs = (long)p.parth;
+  w.nb = p.nbl;
   CellK& cm = k.c;                                  // (k is this function's own copy)
   const unsigned Gz = (unsigned)G;
-  auto reduce_pair = [&](double* sums_out, int nparts, int ngroups, int nx, double* gemm_out) {
-    RedJob a = {part, sums_out, nparts, SREC, 1, (long)p.part, (long)nsum};
-    RedJob b = {partg, gemm_out, nx, GREC, ngroups, (long)p.partg, (long)ngem};
-    hipLaunchKernelGGL(k_bwd_reduce2_w, dim3((GREC + 3) / 4, 1 + ngroups, Gz), dim3(TPB), 0, s, a, b);
+  // BatchNorm sums of a chain kernel (job a) and / or the records of a weight-gradient GEMM (job b): ONE launch
+  auto reduce_jobs = [&](hipStream_t st, double* sums_out, int nparts, const double* grec, long grec_gs, int ngroups, int nx, double* gemm_out) {
+    RedJob a = {part, sums_out, nparts, SREC, sums_out ? 1 : 0, (long)p.part, (long)nsum};
+    RedJob b = {grec, gemm_out, nx, GREC, gemm_out ? ngroups : 0, grec_gs, (long)ngem};
+    hipLaunchKernelGGL(k_bwd_reduce2_w, dim3((GREC + 3) / 4, a.ny + b.ny, Gz), dim3(TPB), 0, st, a, b);
   };
   cm.mf_ncb = pick_ncb(c.out);
   if (cm.mf_ncb < 1) return NIS_E_UNSUPPORTED;
@@ -1123,18 +1159,32 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   else
     NIS_HEAD(NIS_PWQUAD, NIS_KM_BIG, false);
 #undef NIS_HEAD
-  // dW_L = dZ a_L^T, db_L = row sums of dZ; then ONE launch reduces the head's BatchNorm sums and the GEMM's records
-  hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.nsg, Gz), dim3(TPB), 0, s, (const double*)k.dzp, c.R, (const double*)k.alp, N, partg, p.ngl,
-                     (long)wsp, (long)p.partg);
-  reduce_pair(sums, p.nb, p.ngl, p.nxl, glast);
+  // dW_L = dZ a_L^T, db_L = row sums of dZ, and the reduction of its records: on the SIDE stream.  Nothing in the layer chain reads what
+  // they write (only the scatter at the end of the cell does), the GEMM is bound by its 422 MB of dZ reads and the chain by latencies, so
+  // the two share the chip: one GEMM workgroup per CU, the chain's workgroups in the other slot (serially the GEMM's 117 us stood in
+  // front of the chain).  Joined before the cell's last launch; the next cell's head overwrites dZ / a_L only after that.
+  hipStream_t sx = s;
+  Side* sd = nullptr;
+  if (p.side) {
+    sd = &side();
+    if (!sd->ok) return NIS_E_HIP;
+    sx = sd->stream;
+    if (hipEventRecord(sd->fork, s) != hipSuccess || hipStreamWaitEvent(sx, sd->fork, 0) != hipSuccess) return NIS_E_HIP;
+  }
+  hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.nsg, Gz), dim3(TPB), 0, sx, (const double*)k.dzp, c.R, (const double*)k.alp, N, partx,
+                     p.ngl, (long)wsp, (long)p.partx);
+  reduce_jobs(sx, nullptr, 0, partx, (long)p.partx, p.ngl, p.nxl, glast);
+  if (sd && hipEventRecord(sd->join, sx) != hipSuccess) return NIS_E_HIP;
+  reduce_jobs(s, sums, p.nb, nullptr, 0, 0, 0, nullptr);
   for (int l = L; l >= 1; --l) {
     const int pass = L - l + 1;
     k.sums = sums + (size_t)(pass - 1) * SREC;
-    if (G > 1) hipLaunchKernelGGL(k_bwd_layer_w<true>, dim3(p.nb, 1, Gz), dim3(TPB), 0, s, k, w, l);
-    else hipLaunchKernelGGL(k_bwd_layer_w<false>, dim3(p.nb, 1, 1), dim3(TPB), 0, s, k, w, l);
+    if (G > 1) hipLaunchKernelGGL(k_bwd_layer_w<true>, dim3(p.nbl, 1, Gz), dim3(TPB), 0, s, k, w, l);
+    else hipLaunchKernelGGL(k_bwd_layer_w<false>, dim3(p.nbl, 1, 1), dim3(TPB), 0, s, k, w, l);
     // (dW_{l-1} = d h_l a_{l-1}^T: accumulated by the layer kernel itself, one record per workgroup)
-    reduce_pair(sums + (size_t)pass * SREC, p.nb, p.ngh, p.nb, ghid + (size_t)(l - 1) * p.ngh * GREC);
+    reduce_jobs(s, sums + (size_t)pass * SREC, p.nbl, parth, (long)p.parth, p.ngh, p.nbl, ghid + (size_t)(l - 1) * p.ngh * GREC);
   }
+  if (sd && hipStreamWaitEvent(s, sd->join, 0) != hipSuccess) return NIS_E_HIP;
   k.sums = sums + (size_t)L * SREC;
   {
     const int gi = (int)std::max<long>(1, std::min<long>((N + TPB - 1) / TPB, std::max<long>(1, (long)device_cus() * 8 / G)));

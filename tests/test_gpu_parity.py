@@ -2150,6 +2150,43 @@ def test_captured_training_step_equals_eager(shape, monkeypatch):
         np.testing.assert_allclose(sa[k], sb[k], rtol=1e-11, atol=1e-15, err_msg=k)
 
 
+def test_captured_wide_training_step_with_the_side_stream_equals_eager(monkeypatch):
+    """Matrix-core adjoint at a batch that takes the side stream (flow_bwd_wm.hip, bwd_wide_run: the last layer's weight-gradient GEMM
+    runs beside the layer chain once N x G >= 65 536): the fork / join must survive a stream capture (flow.TrainPlan) and give the
+    gradients of the eager launches, which in turn equal the one-stream path of a batch below the threshold (checked against the oracle
+    elsewhere); two epochs of two minibatches of 33 000."""
+    import copy
+    from nf_amd import integrands
+    shape = dict(kind="pwquad", d=4, n_cells=2, K=8, NN=[16, 16])
+    torch.manual_seed(33)
+    base = build_manager(shape)
+    f = integrands.Normal(0.5, 0.3, 4)
+    g = torch.Generator().manual_seed(10)
+    draws = [torch.rand(33000, 4, dtype=torch.double, generator=g) for _ in range(16)]
+
+    def run(graph):
+        if graph:
+            monkeypatch.setenv("NIS_TRAIN_GRAPH", "1")
+        else:
+            monkeypatch.delenv("NIS_TRAIN_GRAPH", raising=False)
+        NF = build_manager(shape)
+        NF._model = copy.deepcopy(base._model)
+        NF.best_model = NF._model
+        it = iter(draws)
+        NF.sample_hook = lambda n, dd, dtype, stage: next(it)[:n].to(dtype)
+        optim = torch.optim.Adamax(NF._model.parameters(), lr=2e-3, weight_decay=1e-4)
+        NF._train_variance_forward_seq(f, optim, False, None, 66000, 2, 0, True, True, mini_batch_size=33000, integrate=False, preburn_time=0)
+        eng = NF._model.engine()
+        assert bool(getattr(eng, "_train_plans", None)) == graph
+        return t2n(torch.stack(NF.history)), [t2n(p.grad) for p in NF._model.parameters()]
+
+    ha, ga = run(True)
+    hb, gb = run(False)
+    np.testing.assert_allclose(ha, hb, rtol=1e-12)
+    for x, y in zip(ga, gb):
+        np.testing.assert_allclose(x, y, rtol=1e-10, atol=1e-16)
+
+
 def test_captured_training_step_with_more_chunks_than_one_plan_holds(monkeypatch):
     """a TrainPlan owns ONE history.  An epoch of more minibatches than one fused call carries runs every chunk's
     forward before the single loss.backward() (manager.py:212-280); the second chunk of equal shape must NOT reuse the plan while the
