@@ -273,7 +273,11 @@ int nis_flow_backward_loss(nis_flow* f, const double* planes_hist, int64_t ld, i
  *     matrix (strides 1, d, N d) or the output planes of the history (strides ld, 1, (n_cells + 1)(d + 1) ld; x_cols = out_col).
  *     J_i of minibatch g at jac[g jac_batch_stride + i jstride].  workspace >= nis_loss_workspace_bytes_batched(G, N).
  *   nis_flow_backward_loss_batched: gparams[c] = sum over the minibatches of gloss * d loss_g / d(parameter blob of cell c).
- *     workspace >= nis_flow_backward_workspace_bytes_batched(f, G, N). */
+ *     workspace >= nis_flow_backward_workspace_bytes_batched(f, G, N).
+ * Streams: every backward entry point orders ALL its work on `stream` (what the caller enqueues behind the call sees the results).  For
+ *   matrix-core cells at N * n_batches >= 65 536 the last layer's weight-gradient GEMM runs on a side stream the library creates once per
+ *   device (forked from and joined back into `stream` with events inside the call), so the first such call must not happen while
+ *   `stream` is being captured (capture a step only after one eager run, as flow.TrainPlan does); one host thread per device. */
 int nis_flow_forward_hist_batched(nis_flow* f, const void* w, int32_t w_dtype, int32_t n_batches, int64_t N,
                                   const double* const* params, double* const* running, long long* const* tracked, int32_t bn_mode,
                                   int64_t pack_token, double* planes_hist, int64_t ld, double* bnsave, double* xj_out,
