@@ -71,6 +71,10 @@ __device__ __forceinline__ void bw_dense(const double* __restrict__ wm, int nq, 
 }
 
 // Forward recompute with the SAVED statistics up to BN layer `upto` (1..L).  Feature of H[q] / XH[q]: 4 q + (lane>>4).
+// (Saving h_1 .. h_{L-1} from the head so that the layer kernels start one dense layer below their BatchNorm instead of at x -- built,
+// parity-green, removed: at C5 / 2e5 the head's 16 extra stores per tile and 34 more spilled registers cost 40 us per cell where the layer
+// launches gained 16, their loops being bound by the latency of a tile's loads and MFMA chain, not by the count of dense layers; in the
+// 5 x 2 000 regime the step moved by 1-2 %, inside its run-to-run spread.)
 //   acc: pre-BN activations of BN_upto | H: input of Linear_{upto-1} | XH: normalised input of BN_{upto-1}
 constexpr int XPRE = 2;          // pass-through features 4 q + gq, q < XPRE (the first 8), of the NEXT tile a chain kernel may request ahead (bww_prefetch_x)
 __device__ __forceinline__ void bww_prefetch_x(const CellK& c, const double* __restrict__ x, long ld, long N, long base, const int* lds_plane,
@@ -633,14 +637,13 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
   bww_stage(k, lds_bn, lds_plane);
   const long ld = k.ld, N = k.N;
   if (tid < SREC) lds_m[tid] = k.sums[tid] * k.invN;
-  __syncthreads();
   const double* bnl = lds_bn + (size_t)l * 4 * WM;
   const bool staged = LDSW && l <= LW;               // (wave-uniform)
-  if (staged) {
+  if (staged) {                                      // (same round trip as the records above: one barrier for the whole prologue)
     for (int e = threadIdx.x; e < l * WM * WM; e += TPB) lds_w[e] = w.wm_all[e];
     for (int e = threadIdx.x; e < WM * WM; e += TPB) lds_wt[e] = c.wp[(size_t)(l - 1) * WM * WM + e];
-    __syncthreads();
   }
+  __syncthreads();
   const double* wt = c.wp + (size_t)(l - 1) * WM * WM + (size_t)gq * WM + s;       // W_{l-1}[4 ks + gq][16 qt + s]
   const double* wts = lds_wt + (size_t)gq * WM + s;                                 // ... its LDS copy
   const int nqt = l == 1 ? (c.P + 15) / 16 : JT;
@@ -766,25 +769,42 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
   // dW records: wave after wave into one image (fixed summation order), then the workgroup's record in the GEMM's layout
   // (row groups of RPW * 16 rows x (WM + 1); the row-sum column stays zero: no bias behind a hidden Linear's BatchNorm)
   __syncthreads();
-  for (int wv = 0; wv < NW; ++wv) {
-    if (wave == wv) {
+  constexpr bool ALLW = NW * WM * WM <= STAGE;        // every wave its own image (one barrier), summed in wave order below -- same sums
+  if constexpr (ALLW) {
 #pragma unroll
-      for (int it = 0; it < JT; ++it)
+    for (int it = 0; it < JT; ++it)
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
+      for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int e = (16 * it + gq + 4 * r) * WM + 16 * jt + s;
-            stage[e] = (wv == 0 ? 0.0 : stage[e]) + dW[it][jt][r];
-          }
-    }
+        for (int r = 0; r < 4; ++r) stage[wave * WM * WM + (16 * it + gq + 4 * r) * WM + 16 * jt + s] = dW[it][jt][r];
     __syncthreads();
+  } else {
+    for (int wv = 0; wv < NW; ++wv) {
+      if (wave == wv) {
+#pragma unroll
+        for (int it = 0; it < JT; ++it)
+#pragma unroll
+          for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int e = (16 * it + gq + 4 * r) * WM + 16 * jt + s;
+              stage[e] = (wv == 0 ? 0.0 : stage[e]) + dW[it][jt][r];
+            }
+      }
+      __syncthreads();
+    }
   }
   constexpr int NGH = (WM + RPW * 16 - 1) / (RPW * 16);
   for (int e = tid; e < NGH * GREC; e += TPB) {
     const int grp = e / GREC, in = e - grp * GREC;
     const int row = grp * RPW * 16 + in / (WM + 1), col = in % (WM + 1);
-    w.partg[((size_t)grp * w.nb + blockIdx.x) * GREC + in] = (row < WM && col < WM) ? stage[row * WM + col] : 0.0;
+    double v = 0.0;
+    if (row < WM && col < WM) {
+      v = stage[row * WM + col];
+      if constexpr (ALLW)
+        for (int wv = 1; wv < NW; ++wv) v += stage[wv * WM * WM + row * WM + col];
+    }
+    w.partg[((size_t)grp * w.nb + blockIdx.x) * GREC + in] = v;
   }
 }
 
