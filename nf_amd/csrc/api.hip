@@ -214,7 +214,8 @@ static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid, int
   // the statistics kernels keep THEIR residency (two 256-thread workgroups per CU) whatever the apply kernel's workgroup shape is.  They
   // hold no LDS image and ~100 VGPRs, but 4 / 6 / 8 workgroups per CU measured 0 ... 8 % SLOWER (round 2: C3 13.9 -> 14.2 ms, C5
   // 7.6 -> 8.2 ms per iteration): every workgroup's prologue merges the previous layer's records, one per workgroup
-  *grid_stats = *ok ? nis_grid_for(2, G, N, per_wg) : 1;      // (one per CU: C5 training step -1 %, C3 / C4 / C5 iterations +4 / +2 / +2.5 %)
+  const int sw = nis_mf_stats_tpb(WM) / 256;                  // workgroups of 256 threads one statistics workgroup stands for
+  *grid_stats = *ok ? nis_grid_for(2 / sw, G, N, per_wg * sw) : 1;      // (one per CU: C5 training step -1 %, C3 / C4 / C5 iterations +4 / +2 / +2.5 %)
 }
 
 // Descriptor-level mirror of launch_apply's SPEC conditions (flow_wm.hip): every cell of a d = 2 PWQuad chain with 3-wide
@@ -497,7 +498,7 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
       } else if (c.dcov) {
         c.derive1 = 1;
         // the covariance pass is a latency-bound stream (8 loads, 44 FMAs per sample, <= 128 VGPRs): two workgroups per CU (four: equal at G = 3, slower at G = 1 -- every consumer merges the records)
-        constexpr int bpc_cov = 2;
+        constexpr int bpc_cov = 2;                   // (one 512-thread workgroup per CU, as the matrix-core statistics kernel has: no gain here)
         c.nparts[0] = nis_grid_for(bpc_cov, Gg, N, 256);
       }
       // single pass-through column on the fp64 VALU kernels: BN_0, Linear_0 and BN_1 collapse into one affine map of x

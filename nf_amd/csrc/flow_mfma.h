@@ -239,18 +239,19 @@ __device__ __forceinline__ void mf_hidden_reg(const CellK& c, const MfWreg<WM, P
 #define NIS_MF_STATS_WAVES 2
 #endif
 template <int WM>
-__global__ __launch_bounds__(NIS_MF_TPB, WM <= 32 ? NIS_MF_STATS_WAVES : 1) void k_bn_stats_mfma(CellK c, const double* __restrict__ planes, long ld, long N, int layer,
+__global__ __launch_bounds__(WM <= 32 ? NIS_MF_STATS_TPB : NIS_MF_TPB, WM <= 32 ? NIS_MF_STATS_WAVES * NIS_MF_TPB / NIS_MF_STATS_TPB : 1) void k_bn_stats_mfma(CellK c, const double* __restrict__ planes, long ld, long N, int layer,
                                                               const double* __restrict__ wm_all) {
-  constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ, NW = NIS_MF_TPB / 64;
+  constexpr int TPBS = WM <= 32 ? NIS_MF_STATS_TPB : NIS_MF_TPB;      // (nis_common.h)
+  constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ, NW = TPBS / 64;
   __shared__ double lds_coef[NIS_MAX_HIDDEN * 2 * WM];
-  __shared__ double red[3 * NIS_MF_TPB];
+  __shared__ double red[3 * TPBS];
   __shared__ int lds_plane[NIS_MAX_DIM];
   __shared__ double wmom[NW][WM][3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
   const int g = c.g0 + blockIdx.y;
   planes += (size_t)g * c.plane_gs;
   if (tid < NIS_MAX_DIM) lds_plane[tid] = c.in_plane[tid];
-  load_coefs<WM, NIS_MF_TPB>(c, g, layer, c.pmerge ? cellk_fresh(c, layer) : -1, blockIdx.x == 0, lds_coef, red);
+  load_coefs<WM, TPBS>(c, g, layer, c.pmerge ? cellk_fresh(c, layer) : -1, blockIdx.x == 0, lds_coef, red);
 
   double S1[JT][4], S2[JT][4], shf[JT][4];
 #pragma unroll

@@ -348,7 +348,7 @@ int mfma_blocks_per_cu<NIS_WM>(const CellK& c_in) {
 template <>
 hipError_t launch_stats_mfma<NIS_WM>(const CellK& c, const MfmaW& w, const double* planes, long ld, long N, int layer, int grid,
                                      hipStream_t s) {
-  hipLaunchKernelGGL((k_bn_stats_mfma<NIS_WM>), dim3(grid, c.Gy), dim3(NIS_MF_TPB), 0, s, c, planes, ld, N, layer, w.wm_all);
+  hipLaunchKernelGGL((k_bn_stats_mfma<NIS_WM>), dim3(grid, c.Gy), dim3(nis_mf_stats_tpb(NIS_WM)), 0, s, c, planes, ld, N, layer, w.wm_all);
   return hipGetLastError();
 }
 

@@ -158,6 +158,13 @@ __device__ __forceinline__ double nis_sqrt(double x) {
   return x == 0.0 ? 0.0 : g;
 }
 
+// matrix-core statistics kernel (k_bn_stats_mfma), widths <= 32: threads per workgroup.  512 = ONE workgroup of eight waves per CU instead
+// of two of four: the same waves, half the records -- every consumer merges the records of its freshest BatchNorm layer in its prologue
+// (load_coefs), 24-byte-strided loads whose cost grows with records x readers per CU
+#ifndef NIS_MF_STATS_TPB
+#define NIS_MF_STATS_TPB 512
+#endif
+static inline int nis_mf_stats_tpb(int wm) { return wm <= 32 ? NIS_MF_STATS_TPB : 256; }
 static inline int nis_pick_wm(int m) { return m <= 4 ? 4 : m <= 8 ? 8 : m <= 16 ? 16 : m <= 32 ? 32 : m <= 64 ? 64 : -1; }
 // bin-array size of the PWQuad kernels: register arrays up to 32 bins; NIS_KM_BIG (33 .. NIS_MAX_BINS bins): the heights / widths of
 // a column live in per-thread scratch arrays and every loop over the bins is a runtime loop (pwquad_column_big)
