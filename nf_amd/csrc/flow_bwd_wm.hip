@@ -592,12 +592,7 @@ __global__ __launch_bounds__(TPB, KM > 16 ? 1 : WPS) void k_bwd_head_w(BwdK k, B
           k.dyp[tmx(WM, j, i)] = dy;
           k.alp[tmx(WM, j, i)] = Hs[q];
         }
-        double t1 = dy, t2 = dy * XHs[q];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-          t1 += __shfl_xor(t1, o, 64);
-          t2 += __shfl_xor(t2, o, 64);
-        }
+        const double t1 = row16_sum(dy), t2 = row16_sum(dy * XHs[q]);
         if (s == 0) {
           sm[wave][j] += t1;
           sm[wave][WM + j] += t2;

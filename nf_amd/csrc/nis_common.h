@@ -45,6 +45,21 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 __device__ __forceinline__ double wave_first(double v) { return __shfl(v, 0, 64); }
+// Sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), the result in every lane of the row: four data-parallel-primitive
+// moves on the vector pipe -- lane ^ 1, lane ^ 2 inside a quad, then the quads of an 8-lane half mirrored, then the halves of the row --
+// instead of four ds_bpermute round trips through the LDS crossbar (__shfl_xor)
+template <int CTRL>
+__device__ __forceinline__ double nis_dpp_mov(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += nis_dpp_mov<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+  v += nis_dpp_mov<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+  v += nis_dpp_mov<0x141>(v);      // row_half_mirror
+  v += nis_dpp_mov<0x140>(v);      // row_mirror
+  return v;
+}
 
 // ---- float64 exp for the bijector: exp(x) = 2^m * T[j] * (1 + p(r)),  k = rint(x*64/ln2) = 64 m + j,
 // r = x - k ln2/64 (two-step Cody-Waite), p = degree-5 Taylor (|r| < 5.5e-3 -> truncation 4e-17).
