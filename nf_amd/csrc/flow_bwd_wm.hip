@@ -831,33 +831,50 @@ __device__ __forceinline__ void bww_scatter(const CellK& c, const ScatterW& a, i
     for (; g < G; ++g) t += p[(size_t)g * gs];
     return t;
   };
-  size_t off = 0;
-  for (int l = 0; l <= L; ++l) {
-    const int F = cellk_feat(c, l);
-    const int O = l < L ? c.width[l] : c.R;
-    const double* sl = a.sums + (size_t)(L - l) * SREC;
-    for (int j = tid; j < F; j += nth) {
-      a.gparams[off + j] = over_g(sl + WM + j, a.sums_gs);
-      a.gparams[off + F + j] = over_g(sl + j, a.sums_gs);
+  // ONE flat index over the blob ([gamma | beta | W | (bias)] per layer, then the last bias): every thread's loads go out together (walking
+  // the layers section by section was a chain of ~12 dependent round trips: 15 us on the cell's critical path)
+  auto seg = [&](int l) {
+    const size_t F = cellk_feat(c, l), O = l < L ? c.width[l] : c.R;
+    return 2 * F + O * F + ((a.hidden_bias && l < L) ? O : 0);
+  };
+  size_t tot = c.R;
+  for (int l = 0; l <= L; ++l) tot += seg(l);
+  for (size_t e = tid; e < tot; e += nth) {
+    size_t rem = e;
+    int l = 0;
+    for (; l <= L; ++l) {
+      const size_t sg = seg(l);
+      if (rem < sg) break;
+      rem -= sg;
     }
-    off += 2 * (size_t)F;
-    const double* src = l < L ? a.ghid + (size_t)l * a.ngh * GREC : a.glast;
-    for (int e = tid; e < O * F; e += nth) {
-      const int r = e / F, q = e % F;
-      a.gparams[off + e] = over_g(src + (size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + q, a.gl_gs);
+    double v;
+    if (l > L) {                              // bias of the last Linear: row sums of dZ
+      const int r = (int)rem;
+      v = over_g(a.glast + (size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + WM, a.gl_gs);
+    } else {
+      const size_t F = cellk_feat(c, l), O = l < L ? c.width[l] : c.R;
+      const double* sl = a.sums + (size_t)(L - l) * SREC;
+      if (rem < F) {
+        v = over_g(sl + WM + rem, a.sums_gs);
+      } else if (rem < 2 * F) {
+        v = over_g(sl + (rem - F), a.sums_gs);
+      } else if (rem < 2 * F + O * F) {
+        const size_t ee = rem - 2 * F;
+        const int r = (int)(ee / F), q = (int)(ee % F);
+        const double* src = l < L ? a.ghid + (size_t)l * a.ngh * GREC : a.glast;
+        v = over_g(src + (size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + q, a.gl_gs);
+      } else {                                // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0;
+        const int o = (int)(rem - 2 * F - O * F);                      // eval mode: scale_{l+1} * sum dy_{l+1}  (one BatchNorm record for all minibatches)
+        const double* s1 = a.sums + (size_t)(L - l - 1) * SREC;
+        v = a.hidden_bias == 2 ? a.bn[((l + 1) * 4 + 0) * WM + o] * over_g(s1 + o, a.sums_gs) : 0.0;
+      }
     }
-    off += (size_t)O * F;
-    if (a.hidden_bias && l < L) {          // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0;
-      const double* s1 = a.sums + (size_t)(L - l - 1) * SREC;      // eval mode: scale_{l+1} * sum dy_{l+1}  (one BatchNorm record for all minibatches)
-      for (int e = tid; e < O; e += nth) a.gparams[off + e] = a.hidden_bias == 2 ? a.bn[((l + 1) * 4 + 0) * WM + e] * over_g(s1 + e, a.sums_gs) : 0.0;
-      off += O;
-    }
+    a.gparams[e] = v;
   }
-  for (int r = tid; r < c.R; r += nth)
-    a.gparams[off + r] = over_g(a.glast + (size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + WM, a.gl_gs);
 }
 
-// BN_0 backward: gradient of the pass-through columns (workgroups [0, gridDim.x - sa.nblk)); the rest: bww_scatter
+// BN_0 backward: gradient of the pass-through columns (workgroups [0, gridDim.x - sa.nblk)); the rest: bww_scatter.
+// (16 us per C5 cell at 2e5 with or without the scatter role, with the columns one by one or eight at a time: it moves 51 MB.)
 __global__ __launch_bounds__(TPB) void k_bwd_input_w(BwdK k, ScatterW sa) {
   const int gi = (int)gridDim.x - sa.nblk;
   if ((int)blockIdx.x >= gi) {
@@ -869,11 +886,28 @@ __global__ __launch_bounds__(TPB) void k_bwd_input_w(BwdK k, ScatterW sa) {
   const double invN = k.invN;
   const long stride = (long)gi * TPB;
   for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < k.N; i += stride)
-    for (int p = 0; p < c.P; ++p) {
-      const size_t at = (size_t)c.in_plane[p] * k.ld + i;
-      const double xh = (k.x[at] - k.bn[2 * WM + p]) * k.bn[3 * WM + p];
-      const double dy = k.dyp[tmx(WM, p, i)];
-      k.g[at] += k.bn[p] * (dy - k.sums[p] * invN - xh * k.sums[WM + p] * invN);
+    for (int p0 = 0; p0 < c.P; p0 += 8) {          // eight columns at a time, EVERY load (the columns' BatchNorm records and sums too) before
+      double xv[8], dv[8], gv[8];                  // the first store: g may alias anything as far as the compiler knows, so column by column
+      double sc[8], mu[8], rs[8], m1[8], m2[8];    // each update waited for the previous store and re-read its scalars behind it
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + u < c.P ? p0 + u : p0;
+        const size_t at = (size_t)c.in_plane[p] * k.ld + i;
+        xv[u] = k.x[at];
+        dv[u] = k.dyp[tmx(WM, p, i)];
+        gv[u] = k.g[at];
+        sc[u] = k.bn[p];
+        mu[u] = k.bn[2 * WM + p];
+        rs[u] = k.bn[3 * WM + p];
+        m1[u] = k.sums[p] * invN;
+        m2[u] = k.sums[WM + p];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p0 + u < c.P) {
+          const double xh = (xv[u] - mu[u]) * rs[u];
+          k.g[(size_t)c.in_plane[p0 + u] * k.ld + i] = gv[u] + sc[u] * (dv[u] - m1[u] - xh * m2[u] * invN);
+        }
     }
 }
 
