@@ -67,6 +67,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise NisError(f"{LIB_PATH} not found: build it with `python -m nf_amd.build` "
                        "(nf_amd has no CPU / PyTorch fallback for its kernels)")
+    # torch FIRST: its wheel bundles its own libamdhip64 / libhsa-runtime64, and the library must bind to the SAME runtime the tensors,
+    # streams and events it is handed live in.  Loaded before torch it pulls in /opt/rocm's copy, the process then holds two HIP runtimes
+    # and the first launch fails with "no ROCm-capable device is detected" (seen with build() followed by smoke() in one process).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
     L.nis_cell_param_count.restype = sz

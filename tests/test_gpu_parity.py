@@ -2096,6 +2096,17 @@ def test_integrate_with_a_python_callable_batched_flow_equals_one_forward_per_it
     assert np.isfinite(float(sig)) and float(err) > 0
 
 
+def test_build_then_smoke_in_one_process():
+    """The driver's two hooks in ONE interpreter, build() first: the library is opened before anything imported torch there (it used to
+    bind to a second HIP runtime then, and smoke()'s first launch failed)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke(); print('BUILD_SMOKE_OK')"], capture_output=True,
+                       text=True, cwd=root, timeout=900)
+    assert r.returncode == 0 and "BUILD_SMOKE_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
 def test_no_access_past_the_end_of_caller_buffers():
     """tools/guard_check.py: inputs, kept planes and outputs of the main entry points placed at the very end of their own allocator
     segment, small and ragged batch sizes (a prefetch past a batch of fewer than 64 samples once read off the end of `w`).  A memory

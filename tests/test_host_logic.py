@@ -341,3 +341,16 @@ int main() {
     assert r.returncode == 0, r.stderr[-2000:]
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+def test_library_is_loaded_behind_torch():
+    """nf_amd._lib.lib() must import torch before it opens libnis_hip.so: torch's wheel carries its own HIP runtime, and the library has to
+    bind to that one (loaded first it brought /opt/rocm's copy along: two runtimes in one process, every launch failing with "no
+    ROCm-capable device" -- __graft_entry__.build() followed by smoke() in one process)."""
+    import subprocess
+    import sys
+    code = ("import sys; from nf_amd import _lib; assert 'torch' not in sys.modules; _lib.lib(); assert 'torch' in sys.modules; "
+            "hip = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}); print(len(hip), hip)")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.split()[0] == "1", r.stdout          # exactly one HIP runtime mapped
