@@ -14,6 +14,7 @@ import sys
 
 
 def short(n):
+    n = n.replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*", "", n).replace("void ", "").strip()
     return re.sub(r"<.*", "", n)
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 profile set, on the GPU box:   bash tools/profile_round4.sh [what]     what: all | bench | kernels | train | trainpmc | c2 | rambo | wide
+# Round-4 profile set, on the GPU box:   bash tools/profile_round4.sh [what]     what: all | bench | kernels | train | trainpmc | trainpmc5 | c2 | rambo | wide
 # Writes gpurun_out/r04_*; copy what should be judged into profiles/.  Counters run in their own passes, without tracing
 # (rocprofv3 --pmc only).  `kernels`: ONE config per rocprofv3 --kernel-trace --stats run, so that per-config kernel timings
 # (apply / statistics / ingest / tail split) are artefacts: r04_kernels_<cfg>.csv.
@@ -48,6 +48,15 @@ if [ $WHAT = all ] || [ $WHAT = trainpmc ]; then
   pmc train_fetch FETCH_SIZE python3 tools/train_probe.py C2 4e6 1 3 batched
   pmc train_write WRITE_SIZE python3 tools/train_probe.py C2 4e6 1 3 batched
   python3 tools/pmc_json.py $OUT/r04_pmc_train_c2.json 1 sets=6 valu=$OUT/r04_pmc_train_valu/p_counter_collection.csv fetch=$OUT/r04_pmc_train_fetch/p_counter_collection.csv write=$OUT/r04_pmc_train_write/p_counter_collection.csv > $OUT/r04_pmc_train_c2.txt
+fi
+if [ $WHAT = all ] || [ $WHAT = trainpmc5 ]; then
+  # counters of the matrix-core training kernels (C5 topology, one minibatch of 2e5, 3 optimizer steps after warm-up): MFMA busy cycles,
+  # instruction counts, waits, HBM bytes -- per kernel; what `attainable` of the adjoint's head is computed from
+  pmc train5_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64 SQ_WAVE_CYCLES SQ_BUSY_CYCLES" python3 tools/train_probe.py C5 2e5 1 3 batched
+  pmc train5_wait "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_WAVE_CYCLES" python3 tools/train_probe.py C5 2e5 1 3 batched
+  pmc train5_fetch FETCH_SIZE python3 tools/train_probe.py C5 2e5 1 3 batched
+  pmc train5_write WRITE_SIZE python3 tools/train_probe.py C5 2e5 1 3 batched
+  python3 tools/pmc_json.py $OUT/r04_pmc_train_c5.json 1 sets=6 mfma=$OUT/r04_pmc_train5_mfma/p_counter_collection.csv coex=$OUT/r04_pmc_train5_wait/p_counter_collection.csv fetch=$OUT/r04_pmc_train5_fetch/p_counter_collection.csv write=$OUT/r04_pmc_train5_write/p_counter_collection.csv > $OUT/r04_pmc_train_c5.txt
 fi
 if [ $WHAT = all ] || [ $WHAT = c2 ]; then
   pmc c2_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" python3 tools/run_c2_set.py 20 4
