@@ -626,6 +626,8 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
   constexpr bool LDSW = WM <= 32;
   __shared__ double lds_w[LDSW ? LW * WM * WM : 1];
   __shared__ double lds_wt[LDSW ? WM * WM : 1];
+  // the chain is the critical path; the GEMM's waves on the same SIMDs (side stream) are not: issue priority over them (7.14 -> 7.08 ms per C5 step)
+  __builtin_amdgcn_s_setprio(3);
   if (BATCH) bww_batch(k, &w);
   const CellK& c = k.c;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
@@ -1212,18 +1214,21 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   // they write (only the scatter at the end of the cell does), the GEMM is bound by its 422 MB of dZ reads and the chain by latencies, so
   // the two share the chip: one GEMM workgroup per CU, the chain's workgroups in the other slot (serially the GEMM's 117 us stood in
   // front of the chain).  Joined before the cell's last launch; the next cell's head overwrites dZ / a_L only after that.
-  hipStream_t sx = s;
   Side* sd = nullptr;
   if (p.side) {
     sd = &side();
     if (!sd->ok) return NIS_E_HIP;
-    sx = sd->stream;
-    if (hipEventRecord(sd->fork, s) != hipSuccess || hipStreamWaitEvent(sx, sd->fork, 0) != hipSuccess) return NIS_E_HIP;
   }
-  hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.nsg, Gz), dim3(TPB), 0, sx, (const double*)k.dzp, c.R, (const double*)k.alp, N, partx,
-                     p.ngl, (long)wsp, (long)p.partx);
-  reduce_jobs(sx, nullptr, 0, partx, (long)p.partx, p.ngl, p.nxl, glast);
-  if (sd && hipEventRecord(sd->join, sx) != hipSuccess) return NIS_E_HIP;
+  bool side_err = false;
+  auto launch_gemm = [&]() {
+    hipStream_t sx = sd ? sd->stream : s;
+    if (sd && (hipEventRecord(sd->fork, s) != hipSuccess || hipStreamWaitEvent(sx, sd->fork, 0) != hipSuccess)) side_err = true;
+    hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.nsg, Gz), dim3(TPB), 0, sx, (const double*)k.dzp, c.R, (const double*)k.alp, N, partx,
+                       p.ngl, (long)wsp, (long)p.partx);
+    reduce_jobs(sx, nullptr, 0, partx, (long)p.partx, p.ngl, p.nxl, glast);
+    if (sd && hipEventRecord(sd->join, sx) != hipSuccess) side_err = true;
+  };
+  launch_gemm();             // (forked behind the first reduction instead: equal; behind the first layer launch: 7.1 -> 7.3 ms per C5 step)
   reduce_jobs(s, sums, p.nb, nullptr, 0, 0, 0, nullptr);
   for (int l = L; l >= 1; --l) {
     const int pass = L - l + 1;
@@ -1233,6 +1238,7 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
     // (dW_{l-1} = d h_l a_{l-1}^T: accumulated by the layer kernel itself, one record per workgroup)
     reduce_jobs(s, sums + (size_t)pass * SREC, p.nbl, parth, (long)p.parth, p.ngh, p.nbl, ghid + (size_t)(l - 1) * p.ngh * GREC);
   }
+  if (side_err) return NIS_E_HIP;
   if (sd && hipStreamWaitEvent(s, sd->join, 0) != hipSuccess) return NIS_E_HIP;
   k.sums = sums + (size_t)L * SREC;
   {
