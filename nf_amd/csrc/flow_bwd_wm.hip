@@ -1100,7 +1100,8 @@ struct Plan {
 };
 
 // share of the chip the side-stream GEMM takes, in quarter workgroups per CU (the layer launches get the remaining slots); measured at
-// C5 / 2e5: 1 -> 8.96 ms per step (the GEMM becomes the critical path), 2 -> 7.42, 3 -> 7.33, 4 -> 7.45, 5 -> 7.40, 6 -> 7.45
+// C5 / 2e5: 1 -> 8.96 ms per step (the GEMM becomes the critical path), 2 -> 7.42, 3 -> 7.33, 4 -> 7.45, 5 -> 7.40, 6 -> 7.45; again with the
+// layer kernel's issue priority in place: 2 -> 7.30, 3 -> 7.17, 4 -> 7.32, 5 -> 7.65
 constexpr int XTY_WG_PER_CU4 = 3;
 constexpr long SIDE_MIN_SAMPLES = 65536;
 Plan plan_for(int R, long N, int G) {         // the G minibatches of a launch (blockIdx.z) share the chip
