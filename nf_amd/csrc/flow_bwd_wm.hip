@@ -807,16 +807,20 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
 
 // Reduced records -> gradient blob in the reference's parameter order (include/nis_hip.h).
 //   sums : pass p (0 = head, L - l + 1 = layer kernel l) holds the sums of BN_{L-p}: [sum dy | sum dy xhat]
-//   glast: GEMM result of the last Linear (row groups of GREC); ghid + m*ngh*GREC: of hidden Linear m
+//   glast: GEMM result of the last Linear (row groups of GREC); the hidden Linears' come from bww_reduce_hidden
 // hidden_bias (NIS_AFFINE): 1 = train-mode BatchNorm, 2 = eval mode (`bn`: the saved scale | shift | mean | rstd records).
 // G minibatches: minibatch g's reduced records sit sums_gs / gl_gs doubles behind minibatch g - 1's; the blob receives their SUM.
 // Runs as extra workgroups of the cell's LAST chain launch (k_bwd_input_w: both only read the reduced records): as a launch of its own
 // it cost 7 us per cell at one minibatch and 21 us at five.
 struct ScatterW {
-  const double *sums, *glast, *ghid, *bn;
+  const double *sums, *glast, *bn;
   double* gparams;
-  int ngh, hidden_bias, G, nblk;
+  int hidden_bias, G, nblk;
   long sums_gs, gl_gs;
+  // the hidden Linears' weight gradients: the layer kernels' records (one area per layer), reduced HERE by nred more workgroups
+  const double* parth;
+  long parth_gs, layer_stride;       // doubles between the minibatches' / the layers' record areas
+  int nbl, nquads, nred;             // records per row group; workgroups per layer (four entries of WM x (WM + 1) each); nquads * L
 };
 __device__ __forceinline__ void bww_scatter(const CellK& c, const ScatterW& a, int tid, int nth) {
   const int L = c.L, G = a.G;
@@ -861,10 +865,10 @@ __device__ __forceinline__ void bww_scatter(const CellK& c, const ScatterW& a, i
       } else if (rem < 2 * F) {
         v = over_g(sl + (rem - F), a.sums_gs);
       } else if (rem < 2 * F + O * F) {
+        if (l < L) continue;                  // hidden Linear: bww_reduce_hidden
         const size_t ee = rem - 2 * F;
         const int r = (int)(ee / F), q = (int)(ee % F);
-        const double* src = l < L ? a.ghid + (size_t)l * a.ngh * GREC : a.glast;
-        v = over_g(src + (size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + q, a.gl_gs);
+        v = over_g(a.glast + (size_t)(r / (RPW * 16)) * GREC + (r % (RPW * 16)) * (WM + 1) + q, a.gl_gs);
       } else {                                // NIS_AFFINE: a bias in front of a train-mode BatchNorm has gradient sum(dh) == 0;
         const int o = (int)(rem - 2 * F - O * F);                      // eval mode: scale_{l+1} * sum dy_{l+1}  (one BatchNorm record for all minibatches)
         const double* s1 = a.sums + (size_t)(L - l - 1) * SREC;
@@ -877,10 +881,64 @@ __device__ __forceinline__ void bww_scatter(const CellK& c, const ScatterW& a, i
 
 // BN_0 backward: gradient of the pass-through columns (workgroups [0, gridDim.x - sa.nblk)); the rest: bww_scatter.
 // (16 us per C5 cell at 2e5 with or without the scatter role, with the columns one by one or eight at a time: it moves 51 MB.)
+// dW_m of hidden Linear m = sum over the layer kernel's per-workgroup records (and over the minibatches), straight into the blob: a
+// workgroup owns four entries, 64 slices of the records each, fixed order -- what k_bwd_reduce2_w did for them beside the BatchNorm sums
+// in the middle of the chain, where it shared the chip with the side-stream GEMM (11-14 us per launch instead of 6)
+__device__ __forceinline__ void bww_reduce_hidden(const CellK& c, const ScatterW& a, int wg) {
+  __shared__ double sm[4][NW][4];
+  const int m = wg / a.nquads, quad = wg - m * a.nquads;
+  const int el = threadIdx.x & 3, slice = threadIdx.x >> 2, e = quad * 4 + el;
+  const int row = e / (WM + 1), col = e - row * (WM + 1);
+  const int F = cellk_feat(c, m), O = c.width[m];
+  const bool ok = row < O && col < F;
+  size_t off = 0;                                        // blob offset of W_m
+  for (int l = 0; l < m; ++l) {
+    const size_t Fl = cellk_feat(c, l), Ol = c.width[l];
+    off += 2 * Fl + Ol * Fl + (a.hidden_bias ? Ol : 0);
+  }
+  off += 2 * (size_t)F;
+  const size_t in = (size_t)(row / (RPW * 16)) * a.nbl * GREC + (size_t)(row % (RPW * 16)) * (WM + 1) + col;
+  double tot = 0.0;
+  constexpr int GC = 4;                                  // minibatches per pass: their loads and reductions run side by side
+  for (int g0 = 0; g0 < a.G; g0 += GC) {
+    double t[GC];
+#pragma unroll
+    for (int gg = 0; gg < GC; ++gg) {
+      t[gg] = 0.0;
+      if (ok && g0 + gg < a.G) {
+        const double* part = a.parth + (size_t)(g0 + gg) * a.parth_gs + (size_t)m * a.layer_stride + in;
+        for (int b0 = slice; b0 < a.nbl; b0 += 512) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = b0 + 64 * u < a.nbl ? part[(size_t)(b0 + 64 * u) * GREC] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[gg] += v[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int gg = 0; gg < GC; ++gg) {
+#pragma unroll
+      for (int o = 4; o < 64; o <<= 1) t[gg] += __shfl_xor(t[gg], o, 64);
+      if ((threadIdx.x & 63) < 4) sm[gg][threadIdx.x >> 6][el] = t[gg];
+    }
+    __syncthreads();
+    if (slice == 0) {
+#pragma unroll
+      for (int gg = 0; gg < GC; ++gg)
+        if (g0 + gg < a.G) tot += (sm[gg][0][el] + sm[gg][1][el]) + (sm[gg][2][el] + sm[gg][3][el]);
+    }
+    __syncthreads();
+  }
+  if (slice == 0 && ok) a.gparams[off + (size_t)row * F + col] = tot;
+}
+
 __global__ __launch_bounds__(TPB) void k_bwd_input_w(BwdK k, ScatterW sa) {
-  const int gi = (int)gridDim.x - sa.nblk;
+  const int gi = (int)gridDim.x - sa.nblk - sa.nred;
   if ((int)blockIdx.x >= gi) {
-    if (blockIdx.z == 0) bww_scatter(k.c, sa, ((int)blockIdx.x - gi) * TPB + threadIdx.x, sa.nblk * TPB);
+    if (blockIdx.z != 0) return;
+    if ((int)blockIdx.x < gi + sa.nblk) bww_scatter(k.c, sa, ((int)blockIdx.x - gi) * TPB + threadIdx.x, sa.nblk * TPB);
+    else bww_reduce_hidden(k.c, sa, (int)blockIdx.x - gi - sa.nblk);
     return;
   }
   bww_batch(k, nullptr);
@@ -1137,7 +1195,7 @@ size_t bwd_wide_workspace_doubles<NIS_WM>(const nis_cell_desc& cd, int64_t N, in
   const int out = cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K;
   const int R = T * out;
   const Plan p = plan_for(R, (long)N, G);
-  return (size_t)G * ((size_t)(2 * WM + R) * ldw_of((long)N) + p.part + p.partx + p.parth + (size_t)(cd.n_hidden + 2) * SREC +
+  return (size_t)G * ((size_t)(2 * WM + R) * ldw_of((long)N) + p.part + p.partx + (size_t)cd.n_hidden * p.parth + (size_t)(cd.n_hidden + 2) * SREC +
                       (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC);
 }
 
@@ -1164,14 +1222,13 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   k.dzp = ws + (size_t)2 * WM * ldw;
   double* part = ws + (size_t)G * wsp;
   double* partx = part + (size_t)G * p.part;
-  double* parth = partx + (size_t)G * p.partx;
-  double* sums = parth + (size_t)G * p.parth;
+  double* parth = partx + (size_t)G * p.partx;                // minibatch g, hidden Linear m: parth + (g * L + m) * p.parth
+  double* sums = parth + (size_t)G * L * p.parth;
   double* glast = sums + (size_t)G * nsum;                 // minibatch g: glast + g * ngem, its hidden-layer results ngl * GREC behind
-  double* ghid = glast + (size_t)p.ngl * GREC;
   k.part = part;
   k.sums = nullptr;
   w.partg = parth;
-  w.partg_gs = (long)p.parth;
+  w.partg_gs = (long)((size_t)L * p.parth);
   w.nb = p.nbl;
   CellK& cm = k.c;                                  // (k is this function's own copy)
   const unsigned Gz = (unsigned)G;
@@ -1179,7 +1236,7 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   auto reduce_jobs = [&](hipStream_t st, double* sums_out, int nparts, const double* grec, long grec_gs, int ngroups, int nx, double* gemm_out) {
     RedJob a = {part, sums_out, nparts, SREC, sums_out ? 1 : 0, (long)p.part, (long)nsum};
     RedJob b = {grec, gemm_out, nx, GREC, gemm_out ? ngroups : 0, grec_gs, (long)ngem};
-    hipLaunchKernelGGL(k_bwd_reduce2_w, dim3((GREC + 3) / 4, a.ny + b.ny, Gz), dim3(TPB), 0, st, a, b);
+    hipLaunchKernelGGL(k_bwd_reduce2_w, dim3(((b.ny ? GREC : SREC) + 3) / 4, a.ny + b.ny, Gz), dim3(TPB), 0, st, a, b);
   };
   cm.mf_ncb = pick_ncb(c.out);
   if (cm.mf_ncb < 1) return NIS_E_UNSUPPORTED;
@@ -1234,18 +1291,35 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   for (int l = L; l >= 1; --l) {
     const int pass = L - l + 1;
     k.sums = sums + (size_t)(pass - 1) * SREC;
+    w.partg = parth + (size_t)(l - 1) * p.parth;
     if (G > 1) hipLaunchKernelGGL(k_bwd_layer_w<true>, dim3(p.nbl, 1, Gz), dim3(TPB), 0, s, k, w, l);
     else hipLaunchKernelGGL(k_bwd_layer_w<false>, dim3(p.nbl, 1, 1), dim3(TPB), 0, s, k, w, l);
-    // (dW_{l-1} = d h_l a_{l-1}^T: accumulated by the layer kernel itself, one record per workgroup)
-    reduce_jobs(s, sums + (size_t)pass * SREC, p.nbl, parth, (long)p.parth, p.ngh, p.nbl, ghid + (size_t)(l - 1) * p.ngh * GREC);
+    // (dW_{l-1} = d h_l a_{l-1}^T: accumulated by the layer kernel itself, one record per workgroup in the layer's own area; the cell's last
+    // launch sums them)
+    reduce_jobs(s, sums + (size_t)pass * SREC, p.nbl, nullptr, 0, 0, 0, nullptr);
   }
   if (side_err) return NIS_E_HIP;
   if (sd && hipStreamWaitEvent(s, sd->join, 0) != hipSuccess) return NIS_E_HIP;
   k.sums = sums + (size_t)L * SREC;
   {
     const int gi = (int)std::max<long>(1, std::min<long>((N + TPB - 1) / TPB, std::max<long>(1, (long)device_cus() * 8 / G)));
-    ScatterW sa = {sums, glast, ghid, k.bn, gparams, p.ngh, c.kind == NIS_AFFINE ? (k.invN == 0.0 ? 2 : 1) : 0, G, 32, (long)nsum, (long)ngem};
-    hipLaunchKernelGGL(k_bwd_input_w, dim3(gi + sa.nblk, 1, Gz), dim3(TPB), 0, s, k, sa);
+    ScatterW sa;
+    sa.sums = sums;
+    sa.glast = glast;
+    sa.bn = k.bn;
+    sa.gparams = gparams;
+    sa.hidden_bias = c.kind == NIS_AFFINE ? (k.invN == 0.0 ? 2 : 1) : 0;
+    sa.G = G;
+    sa.nblk = 32;
+    sa.sums_gs = (long)nsum;
+    sa.gl_gs = (long)ngem;
+    sa.parth = parth;
+    sa.parth_gs = (long)((size_t)L * p.parth);
+    sa.layer_stride = (long)p.parth;
+    sa.nbl = p.nbl;
+    sa.nquads = (WM * (WM + 1) + 3) / 4;
+    sa.nred = sa.nquads * L;
+    hipLaunchKernelGGL(k_bwd_input_w, dim3(gi + sa.nblk + sa.nred, 1, Gz), dim3(TPB), 0, s, k, sa);
   }
   return hipGetLastError() == hipSuccess ? NIS_OK : NIS_E_HIP;
 }
