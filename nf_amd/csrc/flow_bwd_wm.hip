@@ -1283,11 +1283,14 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
     if (sd && (hipEventRecord(sd->fork, s) != hipSuccess || hipStreamWaitEvent(sx, sd->fork, 0) != hipSuccess)) side_err = true;
     hipLaunchKernelGGL(k_bwd_xty_w, dim3(p.nxl, p.nsg, Gz), dim3(TPB), 0, sx, (const double*)k.dzp, c.R, (const double*)k.alp, N, partx,
                        p.ngl, (long)wsp, (long)p.partx);
-    reduce_jobs(sx, nullptr, 0, partx, (long)p.partx, p.ngl, p.nxl, glast);
-    if (sd && hipEventRecord(sd->join, sx) != hipSuccess) side_err = true;
+    if (sd) {
+      reduce_jobs(sx, nullptr, 0, partx, (long)p.partx, p.ngl, p.nxl, glast);
+      if (hipEventRecord(sd->join, sx) != hipSuccess) side_err = true;
+    }
   };
   launch_gemm();             // (forked behind the first reduction instead: equal; behind the first layer launch: 7.1 -> 7.3 ms per C5 step)
-  reduce_jobs(s, sums, p.nb, nullptr, 0, 0, 0, nullptr);
+  if (sd) reduce_jobs(s, sums, p.nb, nullptr, 0, 0, 0, nullptr);
+  else reduce_jobs(s, sums, p.nb, partx, (long)p.partx, p.ngl, p.nxl, glast);      // one stream: the head's sums and the GEMM's records in ONE launch
   for (int l = L; l >= 1; --l) {
     const int pass = L - l + 1;
     k.sums = sums + (size_t)(pass - 1) * SREC;
