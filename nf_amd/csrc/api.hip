@@ -214,7 +214,7 @@ static void mfma_plan(const CellK& c, int G, int64_t N, bool* ok, int* grid, int
   // the statistics kernels keep THEIR residency (two 256-thread workgroups per CU) whatever the apply kernel's workgroup shape is.  They
   // hold no LDS image and ~100 VGPRs, but 4 / 6 / 8 workgroups per CU measured 0 ... 8 % SLOWER (round 2: C3 13.9 -> 14.2 ms, C5
   // 7.6 -> 8.2 ms per iteration): every workgroup's prologue merges the previous layer's records, one per workgroup
-  const int sw = nis_mf_stats_tpb(WM) / 256;                  // workgroups of 256 threads one statistics workgroup stands for
+  const int sw = nis_mf_stats_tpb(WM, (long long)G * N) / 256;                  // workgroups of 256 threads one statistics workgroup stands for
   *grid_stats = *ok ? nis_grid_for(2 / sw, G, N, per_wg * sw) : 1;      // (one per CU: C5 training step -1 %, C3 / C4 / C5 iterations +4 / +2 / +2.5 %)
 }
 

@@ -46,6 +46,11 @@ struct BwdW {
   double* partg;                                // k_bwd_layer_w: records of dW_{l-1} (row groups of GREC per workgroup, the GEMM's record layout)
   long partg_gs;                                //   doubles between the minibatches' record areas
   int nb;                                       //   workgroups per minibatch (record index = group * nb + blockIdx.x)
+  // small batches (one stream): a layer kernel merges the BatchNorm-sum records of the launch in front of it in its own prologue -- no
+  // reduction launch in between -- and its workgroup 0 leaves the reduced sums for the scatter
+  const double* prev;                           // nprev records of SREC doubles (nullptr: BwdK::sums holds the reduced sums)
+  double* sums_w;
+  int nprev;
 };
 
 // Workspace buffers (dZ, dy, d h, a) are tile-major: [16-sample tile][feature][16 samples], so one wave's tile is a
@@ -196,7 +201,13 @@ __device__ __forceinline__ void bww_batch(BwdK& k, BwdW* w) {
   k.dzp += g * k.wsp_gs;
   k.part += g * k.part_gs;
   if (k.sums) k.sums += g * k.sums_gs;
-  if (w) w->partg += g * w->partg_gs;
+  if (w) {
+    w->partg += g * w->partg_gs;
+    if (w->prev) {
+      w->prev += g * k.part_gs;
+      w->sums_w += g * k.sums_gs;
+    }
+  }
 }
 
 __device__ __forceinline__ void bww_stage(const BwdK& k, double* lds_bn, int* lds_plane) {
@@ -633,7 +644,22 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, s = lane & 15;
   bww_stage(k, lds_bn, lds_plane);
   const long ld = k.ld, N = k.N;
-  if (tid < SREC) lds_m[tid] = k.sums[tid] * k.invN;
+  constexpr int ES = SREC <= 64 ? 64 : 128, NS = TPB / ES;      // record entries per slice of threads; slices
+  if (w.prev) {                                      // (uniform) the producing launch's records, merged here: slice sl takes records sl, sl + NS, ...
+    const int sl = tid / ES, e = tid % ES;
+    double t = 0.0;
+    if (e < SREC)
+      for (int b0 = sl; b0 < w.nprev; b0 += NS * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = b0 + NS * u < w.nprev ? w.prev[(size_t)(b0 + NS * u) * SREC + e] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+      }
+    if (e < SREC) sm[sl][e] = t;
+  } else if (tid < SREC) {
+    lds_m[tid] = k.sums[tid] * k.invN;
+  }
   const double* bnl = lds_bn + (size_t)l * 4 * WM;
   const bool staged = LDSW && l <= LW;               // (wave-uniform)
   if (staged) {                                      // (same round trip as the records above: one barrier for the whole prologue)
@@ -641,6 +667,15 @@ __global__ __launch_bounds__(TPB, WPS) void k_bwd_layer_w(BwdK k, BwdW w, int l)
     for (int e = threadIdx.x; e < WM * WM; e += TPB) lds_wt[e] = c.wp[(size_t)(l - 1) * WM * WM + e];
   }
   __syncthreads();
+  if (w.prev) {
+    if (tid < SREC) {
+      double tot = 0.0;
+      for (int r = 0; r < NS; ++r) tot += sm[r][tid];
+      lds_m[tid] = tot * k.invN;
+      if (blockIdx.x == 0) w.sums_w[tid] = tot;
+    }
+    __syncthreads();                                 // (sm is the epilogue's scratch as well)
+  }
   const double* wt = c.wp + (size_t)(l - 1) * WM * WM + (size_t)gq * WM + s;       // W_{l-1}[4 ks + gq][16 qt + s]
   const double* wts = lds_wt + (size_t)gq * WM + s;                                 // ... its LDS copy
   const int nqt = l == 1 ? (c.P + 15) / 16 : JT;
@@ -1073,29 +1108,34 @@ struct RedJob {
   int nparts, nacc, ny;
   long part_gs, out_gs;
 };
+// EL entries per workgroup, 256 / EL slices of the records each: 4 x 64 for the hundreds of records of a big batch (one round trip of
+// eight loads per thread), 16 x 16 for small batches (a launch of 4-entry workgroups over the last layer's records was 13 000 workgroups
+// for 100 records each: 25 us)
+template <int EL>
 __global__ __launch_bounds__(TPB) void k_bwd_reduce2_w(RedJob a, RedJob b) {
-  __shared__ double sm[NW][4];
+  constexpr int NSL = TPB / EL;                          // slices
+  __shared__ double sm[NW][EL];
   const bool second = (int)blockIdx.y >= a.ny;
   const RedJob& j = second ? b : a;
   const int y = (int)blockIdx.y - (second ? a.ny : 0);
-  const int el = threadIdx.x & 3, slice = threadIdx.x >> 2;
-  const int e = blockIdx.x * 4 + el;
+  const int el = threadIdx.x % EL, slice = threadIdx.x / EL;
+  const int e = blockIdx.x * EL + el;
   const double* part = j.part + (size_t)blockIdx.z * j.part_gs + (size_t)y * j.nparts * j.nacc;
   double* out = j.out + (size_t)blockIdx.z * j.out_gs;
   double t = 0.0;
-  if (e < j.nacc) {                                   // eight records per round trip (512 records: one), summed in record order
-    for (int b0 = slice; b0 < j.nparts; b0 += 512) {
+  if (e < j.nacc) {                                   // eight records per round trip, summed in record order
+    for (int b0 = slice; b0 < j.nparts; b0 += 8 * NSL) {
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = b0 + 64 * u < j.nparts ? part[(size_t)(b0 + 64 * u) * j.nacc + e] : 0.0;
+      for (int u = 0; u < 8; ++u) v[u] = b0 + NSL * u < j.nparts ? part[(size_t)(b0 + NSL * u) * j.nacc + e] : 0.0;
 #pragma unroll
       for (int u = 0; u < 8; ++u) t += v[u];
     }
   }
-  // the 64 slices of an element: 16 inside each wave (lanes differing in bits 2..5), then the four waves' partials
+  // the slices of an entry: those inside each wave (lanes differing in the bits above EL), then the four waves' partials
 #pragma unroll
-  for (int o = 4; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
-  if ((threadIdx.x & 63) < 4) sm[threadIdx.x >> 6][el] = t;
+  for (int o = EL; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+  if ((threadIdx.x & 63) < EL) sm[threadIdx.x >> 6][el] = t;
   __syncthreads();
   if (slice == 0) sm[0][el] = (sm[0][el] + sm[1][el]) + (sm[2][el] + sm[3][el]);
   if (slice == 0 && e < j.nacc) out[(size_t)y * j.nacc + e] = sm[0][el];
@@ -1195,7 +1235,7 @@ size_t bwd_wide_workspace_doubles<NIS_WM>(const nis_cell_desc& cd, int64_t N, in
   const int out = cd.kind == NIS_PWQUAD ? 2 * cd.K + 1 : cd.kind == NIS_AFFINE ? 2 : cd.K;
   const int R = T * out;
   const Plan p = plan_for(R, (long)N, G);
-  return (size_t)G * ((size_t)(2 * WM + R) * ldw_of((long)N) + p.part + p.partx + (size_t)cd.n_hidden * p.parth + (size_t)(cd.n_hidden + 2) * SREC +
+  return (size_t)G * ((size_t)(2 * WM + R) * ldw_of((long)N) + 2 * p.part + p.partx + (size_t)cd.n_hidden * p.parth + (size_t)(cd.n_hidden + 2) * SREC +
                       (size_t)(p.ngl + cd.n_hidden * p.ngh) * GREC);
 }
 
@@ -1220,13 +1260,17 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   k.dyp = ws;
   k.alp = ws + (size_t)WM * ldw;
   k.dzp = ws + (size_t)2 * WM * ldw;
-  double* part = ws + (size_t)G * wsp;
-  double* partx = part + (size_t)G * p.part;
+  double* part = ws + (size_t)G * wsp;                        // two record areas: a layer kernel that merges its predecessor's records
+  double* part2 = part + (size_t)G * p.part;                  //   in its prologue writes its own into the other one
+  double* partx = part2 + (size_t)G * p.part;
   double* parth = partx + (size_t)G * p.partx;                // minibatch g, hidden Linear m: parth + (g * L + m) * p.parth
   double* sums = parth + (size_t)G * L * p.parth;
   double* glast = sums + (size_t)G * nsum;                 // minibatch g: glast + g * ngem, its hidden-layer results ngl * GREC behind
   k.part = part;
   k.sums = nullptr;
+  w.prev = nullptr;
+  w.sums_w = nullptr;
+  w.nprev = 0;
   w.partg = parth;
   w.partg_gs = (long)((size_t)L * p.parth);
   w.nb = p.nbl;
@@ -1234,9 +1278,13 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   const unsigned Gz = (unsigned)G;
   // BatchNorm sums of a chain kernel (job a) and / or the records of a weight-gradient GEMM (job b): ONE launch
   auto reduce_jobs = [&](hipStream_t st, double* sums_out, int nparts, const double* grec, long grec_gs, int ngroups, int nx, double* gemm_out) {
-    RedJob a = {part, sums_out, nparts, SREC, sums_out ? 1 : 0, (long)p.part, (long)nsum};
+    RedJob a = {k.part, sums_out, nparts, SREC, sums_out ? 1 : 0, (long)p.part, (long)nsum};      // (the area the last producer wrote)
     RedJob b = {grec, gemm_out, nx, GREC, gemm_out ? ngroups : 0, grec_gs, (long)ngem};
-    hipLaunchKernelGGL(k_bwd_reduce2_w, dim3(((b.ny ? GREC : SREC) + 3) / 4, a.ny + b.ny, Gz), dim3(TPB), 0, st, a, b);
+    const int nacc = b.ny ? GREC : SREC;
+    if (std::max(a.ny ? nparts : 0, b.ny ? nx : 0) <= 128)
+      hipLaunchKernelGGL(k_bwd_reduce2_w<16>, dim3((nacc + 15) / 16, a.ny + b.ny, Gz), dim3(TPB), 0, st, a, b);
+    else
+      hipLaunchKernelGGL(k_bwd_reduce2_w<4>, dim3((nacc + 3) / 4, a.ny + b.ny, Gz), dim3(TPB), 0, st, a, b);
   };
   cm.mf_ncb = pick_ncb(c.out);
   if (cm.mf_ncb < 1) return NIS_E_UNSUPPORTED;
@@ -1291,15 +1339,22 @@ int bwd_wide_run<NIS_WM>(const CellK& c, BwdK k, const MfmaW& mw, double* ws, do
   launch_gemm();             // (forked behind the first reduction instead: equal; behind the first layer launch: 7.1 -> 7.3 ms per C5 step)
   if (sd) reduce_jobs(s, sums, p.nb, nullptr, 0, 0, 0, nullptr);
   else reduce_jobs(s, sums, p.nb, partx, (long)p.partx, p.ngl, p.nxl, glast);      // one stream: the head's sums and the GEMM's records in ONE launch
+  const bool pmerge = !sd;                               // small batches: the layer kernels below the first merge their predecessor's records
   for (int l = L; l >= 1; --l) {
     const int pass = L - l + 1;
     k.sums = sums + (size_t)(pass - 1) * SREC;
     w.partg = parth + (size_t)(l - 1) * p.parth;
+    if (pmerge && l < L) {
+      w.prev = k.part;                                   // what layer l + 1 wrote
+      w.nprev = p.nbl;
+      w.sums_w = sums + (size_t)(pass - 1) * SREC;
+      k.part = k.part == part ? part2 : part;
+    }
     if (G > 1) hipLaunchKernelGGL(k_bwd_layer_w<true>, dim3(p.nbl, 1, Gz), dim3(TPB), 0, s, k, w, l);
     else hipLaunchKernelGGL(k_bwd_layer_w<false>, dim3(p.nbl, 1, 1), dim3(TPB), 0, s, k, w, l);
     // (dW_{l-1} = d h_l a_{l-1}^T: accumulated by the layer kernel itself, one record per workgroup in the layer's own area; the cell's last
     // launch sums them)
-    reduce_jobs(s, sums + (size_t)pass * SREC, p.nbl, nullptr, 0, 0, 0, nullptr);
+    if (!pmerge || l == 1) reduce_jobs(s, sums + (size_t)pass * SREC, p.nbl, nullptr, 0, 0, 0, nullptr);
   }
   if (side_err) return NIS_E_HIP;
   if (sd && hipStreamWaitEvent(s, sd->join, 0) != hipSuccess) return NIS_E_HIP;

@@ -238,10 +238,9 @@ __device__ __forceinline__ void mf_hidden_reg(const CellK& c, const MfWreg<WM, P
 #ifndef NIS_MF_STATS_WAVES
 #define NIS_MF_STATS_WAVES 2
 #endif
-template <int WM>
-__global__ __launch_bounds__(WM <= 32 ? NIS_MF_STATS_TPB : NIS_MF_TPB, WM <= 32 ? NIS_MF_STATS_WAVES * NIS_MF_TPB / NIS_MF_STATS_TPB : 1) void k_bn_stats_mfma(CellK c, const double* __restrict__ planes, long ld, long N, int layer,
+template <int WM, int TPBS>
+__global__ __launch_bounds__(TPBS, WM <= 32 ? NIS_MF_STATS_WAVES * NIS_MF_TPB / TPBS : 1) void k_bn_stats_mfma(CellK c, const double* __restrict__ planes, long ld, long N, int layer,
                                                               const double* __restrict__ wm_all) {
-  constexpr int TPBS = WM <= 32 ? NIS_MF_STATS_TPB : NIS_MF_TPB;      // (nis_common.h)
   constexpr int ST = MfCfg<WM>::ST, JT = MfCfg<WM>::JT, KQ = MfCfg<WM>::KQ, NW = TPBS / 64;
   __shared__ double lds_coef[NIS_MAX_HIDDEN * 2 * WM];
   __shared__ double red[3 * TPBS];

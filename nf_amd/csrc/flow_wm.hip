@@ -348,7 +348,10 @@ int mfma_blocks_per_cu<NIS_WM>(const CellK& c_in) {
 template <>
 hipError_t launch_stats_mfma<NIS_WM>(const CellK& c, const MfmaW& w, const double* planes, long ld, long N, int layer, int grid,
                                      hipStream_t s) {
-  hipLaunchKernelGGL((k_bn_stats_mfma<NIS_WM>), dim3(grid, c.Gy), dim3(nis_mf_stats_tpb(NIS_WM)), 0, s, c, planes, ld, N, layer, w.wm_all);
+  if (nis_mf_stats_tpb(NIS_WM, (long long)c.Gy * N) == NIS_MF_STATS_TPB && NIS_MF_STATS_TPB != NIS_MF_TPB)
+    hipLaunchKernelGGL((k_bn_stats_mfma<NIS_WM, NIS_WM <= 32 ? NIS_MF_STATS_TPB : NIS_MF_TPB>), dim3(grid, c.Gy), dim3(NIS_MF_STATS_TPB), 0, s, c, planes, ld, N, layer, w.wm_all);
+  else
+    hipLaunchKernelGGL((k_bn_stats_mfma<NIS_WM, NIS_MF_TPB>), dim3(grid, c.Gy), dim3(NIS_MF_TPB), 0, s, c, planes, ld, N, layer, w.wm_all);
   return hipGetLastError();
 }
 
