@@ -41,6 +41,9 @@ if [ $WHAT = all ] || [ $WHAT = train ]; then
   python3 tools/train_probe.py C5 2000 5 20 both 2>&1 | grep "^C" >> $OUT/r04_train_probe.txt
   # (launches of one tile per wave: the step's time moves by +-8 % from run to run on one box -- three more runs of 150 steps)
   for i in 1 2 3; do python3 tools/train_probe.py C5 2000 5 150 batched 2>&1 | grep "^C" >> $OUT/r04_train_probe.txt; done
+  # the same steps as two hipGraph replays (flow.TrainPlan, opt-in NIS_TRAIN_GRAPH=1): what the kernel boundaries of the eager chain cost
+  for i in 1 2 3; do NIS_TRAIN_GRAPH=1 python3 tools/train_probe.py C5 2000 5 150 batched 2>&1 | grep "^C" | sed 's/batched /captured/' >> $OUT/r04_train_probe.txt; done
+  NIS_TRAIN_GRAPH=1 python3 tools/train_probe.py C5 2e5 1 8 batched 2>&1 | grep "^C" | sed 's/batched /captured/' >> $OUT/r04_train_probe.txt
   python3 tools/host_sections.py 2000 5 2>&1 | grep -v "Warn\|amdgpu" >> $OUT/r04_train_probe.txt
   tools/probe/rambo_traffic 1000000 40 > $OUT/r04_rambo_traffic_probe.txt 2>&1 || true
 fi
