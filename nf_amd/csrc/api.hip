@@ -499,7 +499,9 @@ static int flow_run(nis_flow* f, const void* w, int32_t w_dtype, int64_t N, cons
         c.derive1 = 1;
         // the covariance pass is a latency-bound stream (8 loads, 44 FMAs per sample, <= 128 VGPRs): two workgroups per CU (four: equal at G = 3, slower at G = 1 -- every consumer merges the records)
         constexpr int bpc_cov = 2;                   // (one 512-thread workgroup per CU, as the matrix-core statistics kernel has: no gain here)
-        c.nparts[0] = nis_grid_for(bpc_cov, Gg, N, 256);
+        // ... and at least eight samples per thread: at 2e5 samples 98 workgroups instead of 512 -- the pass itself is a chain of latencies
+        // either way (15-20 us), its consumer merges a fifth of the records (C5 training step 7.06 -> 7.00 ms; 1e6-sample iterations equal)
+        c.nparts[0] = nis_grid_for(bpc_cov, Gg, N, 256 * 8);
       }
       // single pass-through column on the fp64 VALU kernels: BN_0, Linear_0 and BN_1 collapse into one affine map of x
       // (needs the layer-1 statistics launch to be gone: train mode with derive1, or eval mode)
